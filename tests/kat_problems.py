@@ -1,0 +1,103 @@
+"""The reference's hand-written known-answer problems
+(/root/reference/test/moi_proxsdp_unit.jl, test/test_terminationstatus.jl),
+rebuilt directly in the standard form that MOI hands to `chambolle_pock`
+(/root/reference/src/MOI_wrapper.jl:229-292).  Used by the oracle tests (CPU)
+and by the HIP parity tests (GPU) so both solve identical arrays.
+
+MOI conventions reproduced here: `EqualTo(v)` on `f(x)` becomes a Zeros row
+`f(x) - v`, so b = v; `GreaterThan(0)` on x becomes the Nonpositives row `-x <= 0`;
+a VectorAffineFunction-in-Nonpositives row `g(x) + k <= 0` gives G row g, h = -k.
+Variable indices below are 1-based in the comments (as in the Julia tests) and
+0-based in the code."""
+import numpy as np
+import scipy.sparse as sp
+
+from proxsdp_jl_amd.problems import Problem
+
+
+def _mat(rows, ncols):
+    """rows: list of {col: coef}."""
+    r, c, v = [], [], []
+    for i, row in enumerate(rows):
+        for j, val in row.items():
+            r.append(i); c.append(j); v.append(float(val))
+    return sp.csc_matrix((v, (r, c)), shape=(len(rows), ncols))
+
+
+def _cvec(n, terms):
+    c = np.zeros(n)
+    for j, v in terms.items():
+        c[j] += v
+    return c
+
+
+def simple_lp():
+    """moi_proxsdp_unit.jl:1-49 / test_terminationstatus.jl:1-38.
+    min -4x1-3x2, 2x1+x2=4, x1+2x2=4, x>=0  ->  -9.33333, x=(1.3333,1.3333)."""
+    return Problem(n=2, A=_mat([{0: 2, 1: 1}, {0: 1, 1: 2}], 2), b=np.array([4.0, 4.0]),
+                   G=_mat([{0: -1}, {1: -1}], 2), h=np.zeros(2),
+                   c=_cvec(2, {0: -4, 1: -3}), name="simple_lp")
+
+
+def simple_lp_2_1d_sdp():
+    """moi_proxsdp_unit.jl:51-95: the same LP with two 1x1 PSD cones."""
+    return Problem(n=2, A=_mat([{0: 2, 1: 1}, {0: 1, 1: 2}], 2), b=np.array([4.0, 4.0]),
+                   G=_mat([], 2), h=np.zeros(0), c=_cvec(2, {0: -4, 1: -3}),
+                   psd=[np.array([0]), np.array([1])], name="simple_lp_2_1d_sdp")
+
+
+def lp_in_SDP_equality_form():
+    """moi_proxsdp_unit.jl:97-138: 4x4 PSD (10 vars); 2X1+X3+X6=4, X1+2X3+X10=4,
+    min -4X1-3X3 -> -9.33333, X=[1.3333,0,1.3333,0,...]."""
+    return Problem(n=10, A=_mat([{0: 2, 2: 1, 5: 1}, {0: 1, 2: 2, 9: 1}], 10),
+                   b=np.array([4.0, 4.0]), G=_mat([], 10), h=np.zeros(0),
+                   c=_cvec(10, {0: -4, 2: -3}), psd=[np.arange(10)],
+                   name="lp_in_SDP_equality_form")
+
+
+def lp_in_SDP_inequality_form():
+    """moi_proxsdp_unit.jl:140-182: 2x2 PSD; 2X1+X3<=4, X1+2X3<=4; MAX 4X1+3X3 -> 9.33333."""
+    return Problem(n=3, A=_mat([], 3), b=np.zeros(0),
+                   G=_mat([{0: 2, 2: 1}, {0: 1, 2: 2}], 3), h=np.array([4.0, 4.0]),
+                   c=_cvec(3, {0: -4, 2: -3}), psd=[np.arange(3)], max_sense=True,
+                   name="lp_in_SDP_inequality_form")
+
+
+def sdp_from_moi():
+    """moi_proxsdp_unit.jl:184-223: 2x2 PSD, X2=1, min X1+X3 -> 2, X=ones(3)."""
+    return Problem(n=3, A=_mat([{1: 1}], 3), b=np.array([1.0]), G=_mat([], 3), h=np.zeros(0),
+                   c=_cvec(3, {0: 1, 2: 1}), psd=[np.arange(3)], name="sdp_from_moi")
+
+
+def double_sdp_from_moi():
+    """moi_proxsdp_unit.jl:225-271: two such blocks -> 4."""
+    return Problem(n=6, A=_mat([{1: 1}, {4: 1}], 6), b=np.array([1.0, 1.0]),
+                   G=_mat([], 6), h=np.zeros(0), c=_cvec(6, {0: 1, 2: 1, 3: 1, 5: 1}),
+                   psd=[np.arange(3), np.arange(3, 6)], name="double_sdp_from_moi")
+
+
+def sdp_wiki(max_sense=False):
+    """moi_proxsdp_unit.jl:302-338 (Wikipedia SDP): 3x3 PSD, X1=X3=X6=1,
+    -0.2<=X2<=-0.1, 0.4<=X5<=0.5; min X4 -> -0.978, max X4 -> 0.872."""
+    A = _mat([{0: 1}, {2: 1}, {5: 1}], 6)
+    G = _mat([{1: 1}, {1: -1}, {4: 1}, {4: -1}], 6)
+    h = np.array([-0.1, 0.2, 0.5, -0.4])
+    sign = -1.0 if max_sense else 1.0
+    return Problem(n=6, A=A, b=np.ones(3), G=G, h=h, c=_cvec(6, {3: sign}),
+                   psd=[np.arange(6)], max_sense=max_sense,
+                   name="sdp_wiki_max" if max_sense else "sdp_wiki_min")
+
+
+# name -> (builder, expected user-sense objective, atol, expected primal or None)
+KATS = {
+    "simple_lp": (simple_lp, -9.33333, 1e-2, np.array([1.3333, 1.3333])),
+    "simple_lp_2_1d_sdp": (simple_lp_2_1d_sdp, -9.33333, 1e-2, np.array([1.3333, 1.3333])),
+    "lp_in_SDP_equality_form": (lp_in_SDP_equality_form, -9.33333, 1e-2,
+                                np.array([1.3333, 0, 1.3333, 0, 0, 0, 0, 0, 0, 0])),
+    "lp_in_SDP_inequality_form": (lp_in_SDP_inequality_form, 9.33333, 1e-2,
+                                  np.array([1.3333, 0, 1.3333])),
+    "sdp_from_moi": (sdp_from_moi, 2.0, 1e-2, np.ones(3)),
+    "double_sdp_from_moi": (double_sdp_from_moi, 4.0, 1e-2, np.ones(6)),
+    "sdp_wiki_min": (lambda: sdp_wiki(False), -0.978, 1e-2, None),
+    "sdp_wiki_max": (lambda: sdp_wiki(True), 0.872, 1e-2, None),
+}

@@ -1,0 +1,184 @@
+"""Pins the CPU oracle (oracle/) against every known-answer test the reference
+holds for the hot path:
+
+  KA1-KA7  /root/reference/test/moi_proxsdp_unit.jl (objective/primal, atol 1e-2,
+           solver tol 1e-6 as test/moitest.jl:15-23), under all three eig settings
+           (:358-370)
+  KA8      MIMO n=2..5 property  (test/moi_mimo.jl:71-75)
+  KA9      SDPLIB mcp124-1 / gpp124-2 at tol 1e-3: lambda_min >= -1e-4
+           (test/moi_sdplib.jl:53-56) + literature optima
+  KA10     termination statuses (test/test_terminationstatus.jl:40-73)
+"""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import Options
+from oracle import eig as oeig
+from proxsdp_jl_amd import problems as P
+
+from kat_problems import KATS, simple_lp, sdp_wiki
+
+
+def _opt(**kw):
+    o = Options()
+    o.tol_gap = 1e-6
+    o.tol_feasibility = 1e-6
+    o.time_limit = 30.0
+    for k, v in kw.items():
+        o.set(k, v)
+    return o
+
+
+@pytest.mark.parametrize("name", list(KATS))
+def test_known_answers(name):
+    build, expected, atol, xexp = KATS[name]
+    r = oracle.solve(build(), _opt())
+    assert r.status == 1                      # MOI.OPTIMAL
+    assert abs(r.objval - expected) <= atol
+    assert r.primal_feasible_user_tol and r.dual_feasible_user_tol
+    if xexp is not None:
+        assert np.allclose(r.primal, xexp, atol=atol)
+
+
+@pytest.mark.parametrize("settings", [
+    dict(eigsolver=1, min_size_krylov_eigs=1),     # ARPACK (ncv > n -> full-eig fallback)
+    dict(eigsolver=2, min_size_krylov_eigs=1),     # KrylovKit-style Lanczos on a 3x3
+    dict(full_eig_decomp=True),
+])
+def test_sdp_wiki_all_eig_paths(settings):
+    """moi_proxsdp_unit.jl:358-370."""
+    rmin = oracle.solve(sdp_wiki(False), _opt(**settings))
+    rmax = oracle.solve(sdp_wiki(True), _opt(**settings))
+    assert rmin.status == 1 and abs(rmin.objval - (-0.978)) <= 1e-2
+    assert rmax.status == 1 and abs(rmax.objval - 0.872) <= 1e-2
+    if settings.get("eigsolver") == 2:
+        assert rmin.stats["lanczos_matvecs"] > 0 and rmin.stats["full_eigs"] == 0
+    if settings.get("eigsolver") == 1:
+        assert rmin.stats["krylov_fallbacks"] == rmin.iter
+
+
+def test_termination_statuses():
+    """test_terminationstatus.jl:40-73."""
+    assert oracle.solve(simple_lp(), Options()).status == 1
+    o = Options()
+    o.max_iter = 1
+    assert oracle.solve(simple_lp(), o).status == 3          # ITERATION_LIMIT
+    o = Options()
+    for k in ("tol_gap", "tol_feasibility", "tol_primal", "tol_dual",
+              "tol_feasibility_dual", "tol_psd"):
+        o.set(k, 1e-16)
+    o.time_limit = 0.0
+    assert oracle.solve(simple_lp(), o).status == 2          # TIME_LIMIT
+
+
+def test_unknown_option_is_an_error():
+    """MOI_wrapper.jl:84-93 / moitest.jl:153-156."""
+    with pytest.raises(KeyError):
+        Options().set("unsupportedarg", 10)
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 5])
+def test_mimo_property(n):
+    """moi_mimo.jl:71-75: every |X_ij| in (0.99, 1.01)."""
+    pr = P.mimo(n, seed=123)
+    r = oracle.solve(pr, _opt())
+    X = P.unpack_psd(r.primal, n + 1)
+    assert r.status == 1
+    assert np.all(np.abs(X) > 0.99) and np.all(np.abs(X) < 1.01)
+
+
+@pytest.mark.parametrize("fname,lit", [("mcp124-1", -141.99), ("gpp124-2", 46.8623)])
+def test_sdplib_low_accuracy(fname, lit, golden_dir):
+    """moitest.jl:119-143: default Lanczos path (n > 100), tol 1e-3."""
+    pr = P.sdplib(golden_dir / "sdplib" / f"{fname}.dat-s")
+    o = Options()
+    o.tol_gap = 1e-3
+    o.tol_feasibility = 1e-3
+    r = oracle.solve(pr, o)
+    X = P.unpack_psd(r.primal, pr.psd_sides()[0])
+    assert r.status == 1
+    assert np.linalg.eigvalsh(X).min() >= -1e-4
+    assert abs(r.objval - lit) <= 5e-3 * (1 + abs(lit))
+    assert r.stats["lanczos_matvecs"] > 0 and r.stats["full_eigs"] == 0
+
+
+def test_readme_maxcut():
+    """README.md:62-86; optimum 18 = 0.25 * 4 * (cut weight 18)."""
+    r = oracle.solve(P.maxcut_readme(), Options())
+    assert r.status == 1 and abs(r.objval - 18.0) < 1e-2
+    X = P.unpack_psd(r.primal, 4)
+    assert np.allclose(np.abs(X), 1.0, atol=1e-2)
+
+
+# ----------------------------------------------------------------- eigen layer
+def _planted(n, top, seed, bulk=(-5.0, 1.0)):
+    rng = np.random.default_rng(seed)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    lam = np.concatenate([np.asarray(top, float), rng.uniform(bulk[0], bulk[1], n - len(top))])
+    X = (Q * lam) @ Q.T
+    return (X + X.T) / 2, lam
+
+
+@pytest.mark.parametrize("n,nev", [(101, 2), (257, 5), (300, 12)])
+def test_lanczos_matches_dense_eig(n, nev):
+    X, lam = _planted(n, [50, 40, 30, 20, 10, 9, 8, 7, 6.5, 6, 5.5, 5.2], 7)
+    ncv = max(2 * nev + 1, 25)
+    vals, vecs, conv, numiter, numops = oeig.krylovkit_eigsolve(
+        lambda v: oeig.symv_upper(np.triu(X), v), oeig.start_vector(n), nev, ncv, 100, 1e-12)
+    ref = np.sort(np.linalg.eigvalsh(X))[::-1]
+    assert conv >= nev and len(vals) >= nev
+    assert np.allclose(vals[:nev], ref[:nev], rtol=0, atol=1e-10)
+    resid = np.linalg.norm(X @ vecs - vecs * vals, axis=0)
+    assert np.all(resid[:nev] < 1e-9)
+    assert np.allclose(vecs.T @ vecs, np.eye(vecs.shape[1]), atol=1e-10)
+
+
+def test_lanczos_invariant_subspace_and_zero_matrix():
+    x0 = oeig.start_vector(50)
+    vals, vecs, conv, _, numops = oeig.krylovkit_eigsolve(lambda v: 0 * v, x0, 2, 25, 100, 1e-12)
+    assert list(vals) == [0.0] and conv == 1 and numops == 1      # howmany reduced to K=1
+    X3 = np.array([[1, -0.15, 0.0], [0, 1, 0.45], [0, 0, 1.0]])
+    vals, vecs, conv, _, numops = oeig.krylovkit_eigsolve(
+        lambda v: oeig.symv_upper(X3, v), oeig.start_vector(3), 2, 25, 100, 1e-12)
+    assert conv == 3 and numops == 3 and len(vals) == 3           # returns all converged
+    full = np.triu(X3) + np.triu(X3, 1).T
+    assert np.allclose(vals, np.sort(np.linalg.eigvalsh(full))[::-1])
+
+
+def test_start_vector_is_deterministic_and_normalised():
+    a = oeig.start_vector(1000, 1234, 3)
+    b = oeig.start_vector(1000, 1234, 3)
+    assert np.array_equal(a, b)
+    assert abs(np.linalg.norm(a) - 1) < 1e-14
+    assert abs(a.mean()) < 0.01 and not np.array_equal(a, oeig.start_vector(1000, 1235, 3))
+    # prefix property: the first k entries do not depend on n (up to the normalisation)
+    c = oeig.start_vector(10, 1234, 3)
+    assert np.allclose(c / c[0], a[:10] / a[0])
+
+
+# ----------------------------------------------------------------- harness pieces
+def test_sdpa_reader_quirks(golden_dir):
+    """base_sdplib.jl:24-26: n = length(c); gpp instances get side m, not the block size."""
+    n, m, F, c = P.read_sdpa(golden_dir / "sdplib" / "gpp124-2.dat-s")
+    assert (n, m) == (125, 125) and F[0].shape == (125, 125)
+    n, m, F, c = P.read_sdpa(golden_dir / "sdplib" / "mcp124-1.dat-s")
+    assert (n, m) == (124, 124)
+    assert abs(F[0] - F[0].T).max() == 0
+    # objective stored negated (base_sdplib.jl:37-38): file has "0 1 1 1 0.25"
+    assert F[0][0, 0] == -0.25
+    pr = P.sdplib(golden_dir / "sdplib" / "mcp124-1.dat-s")
+    assert pr.A.shape == (124, 124 * 125 // 2) and pr.A.nnz == 124
+
+
+def test_maxcut_generator_shapes():
+    pr = P.maxcut(50, seed=1)
+    assert pr.n == 50 * 51 // 2 and pr.A.shape[0] == 50 and pr.A.nnz == 50
+    assert pr.max_sense and np.all(pr.b == 1)
+    L = P.erdos_renyi_laplacian(50, 1)
+    assert abs(L.sum(axis=1)).max() == 0
+    # objective coefficient convention: 2x on off-diagonals
+    d = P.tri_index(np.arange(50), np.arange(50))
+    assert np.allclose(pr.c[d], -0.25 * L.diagonal())
+    i, j = 3, int(np.nonzero(L[3].toarray().ravel() < 0)[0][0])
+    assert np.isclose(pr.c[P.tri_index(i, j)], -0.25 * 2 * L[i, j])
