@@ -1,0 +1,152 @@
+#!/usr/bin/env python
+"""bench.py -- PDHG iterations/sec on the metric's instance (BASELINE.json):
+Max-Cut SDP, Erdos-Renyi graph, n = 4000, one PSD cone, tol 1e-4 defaults.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one PDHG iteration (primal step with the PSD projection, linesearch
+dual step, residuals/gap) of ONE solve; W untimed iterations precede the K timed
+ones inside the same solve (max_iter = W+K), the split being taken from the
+per-iteration host clock the library stamps after each iteration's final stream
+synchronisation.  The whole call is bracketed by barrier + cuda.synchronize.
+The problem is uploaded before the loop starts (inputs resident in HBM).
+
+N > 1: the single-PSD-block path does not shard (SURVEY.md section 8e,
+DESIGN.md section 7) -> N independent replicas (seed = rank), no data-path
+collective, scaling "weak"; value = total iterations of all ranks / max time.
+
+Extra objects on the JSON line: "roofline" for the dominant kernel
+(k_symv_packed; HIP events recorded by the library on its own stream around
+every 4th launch inside the timed solve) and "cpu_baseline" (the NumPy/SciPy
+oracle -- a restatement, NOT the Julia reference, which cannot run here -- on a
+bounded sample of the same instance, rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--n", type=int, default=4000, help="PSD side (metric: 4000)")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline sample budget")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--time-to-tol", action="store_true",
+                    help="also run the full solve to tol 1e-4 and report time_to_tol_s")
+    ap.add_argument("--profile-every", type=int, default=4)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    from proxsdp_jl_amd import binding, problems
+    from proxsdp_jl_amd.optimizer import Optimizer
+
+    if binding.device_count() <= 0:
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    n = args.n
+    K, W = args.steps, args.warmup
+    pr = problems.maxcut(n, seed=args.seed + rank)
+    N = n * (n + 1) // 2
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    opt = Optimizer(max_iter=W + K, device_id=local_rank, profile_symv_every=args.profile_every)
+    sync()
+    t0 = time.time()
+    sol = opt.optimize(pr, trace_capacity=W + K)
+    sync()
+    wall = time.time() - t0
+    tr = sol.trace
+    if len(tr) < W + K:
+        raise SystemExit(f"solve stopped after {len(tr)} iterations (< warmup+steps): status {sol.status}")
+    t_start = tr[W - 1, 12] if W > 0 else 0.0
+    t_steps = float(tr[W + K - 1, 12] - t_start)
+    if dist is not None:
+        t = torch.tensor([t_steps], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t_steps = float(t.item())
+    value = world * K / t_steps
+
+    st = sol.stats
+    symv_ms = st["symv_profiled_ms"] / max(1, st["symv_profiled"])
+    symv_bytes = 8.0 * N + 16.0 * n                       # algorithmic bytes of one mat-vec
+    achieved = symv_bytes / (symv_ms * 1e-3) / 1e9 if symv_ms > 0 else 0.0
+    mv_timed = float(tr[W:W + K, 13].sum())
+    trials_timed = float(tr[W:W + K, 11].sum())
+    out = {
+        "metric": "PDHG iterations/sec, Max-Cut SDP n=%d (tol_gap=tol_feasibility=1e-4 defaults)" % n,
+        "value": value, "unit": "iterations/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": 1e3 * t_steps / K, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "Max-Cut SDP, Erdos-Renyi G(n,12/(n-1)) unit weights, n=%d, one PSD cone, "
+                               "Nx=%d, p=%d equality rows; reference default options" % (n, N, n),
+                   "parallelism": "replicas x%d (single PSD block does not shard)" % world,
+                   "timed_iterations": [W + 1, W + K],
+                   "lanczos_matvecs_per_step": mv_timed / K, "linesearch_trials_per_step": trials_timed / K,
+                   "target_rank": int(tr[W + K - 1, 10])},
+        "roofline": {"bound": "hbm", "kernel": "k_symv_packed", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "bytes_per_launch": symv_bytes, "avg_launch_ms": symv_ms,
+                     "launches_profiled": int(st["symv_profiled"]), "launches": int(st["symv_launches"]),
+                     "loop_algorithmic_GBs": st["algorithmic_bytes"] / max(st["loop_time"], 1e-9) / 1e9},
+        "solve_wall_s": wall, "init_s": st["init_time"], "exit_s": st["exit_time"],
+    }
+
+    if rank == 0 and world == 1 and args.time_to_tol:
+        o2 = Optimizer(device_id=local_rank, time_limit=600.0)
+        s2 = o2.optimize(pr)
+        out["time_to_tol"] = {"status": o2.termination_status(), "time_s": s2.time, "iterations": int(s2.iter),
+                              "objective": o2.objective_value(), "gap": s2.gap,
+                              "whole_solve_it_per_s": s2.iter / max(s2.stats["loop_time"], 1e-9),
+                              "final_rank": int(s2.final_rank)}
+
+    if rank == 0 and world == 1 and not args.no_cpu:
+        import oracle                                           # baseline leg only
+        ncores = os.cpu_count() or 1
+        o = oracle.Options()
+        o.time_limit = args.cpu_seconds
+        tc = time.time()
+        ref = oracle.solve(pr, o)
+        cpu_it = max(int(ref.iter), 1)
+        cpu_loop = ref.stats["loop_time"]
+        gpu_same = float(tr[min(cpu_it, len(tr)) - 1, 12])
+        out["cpu_baseline"] = {"value": cpu_it / cpu_loop, "unit": "iterations/s", "cores": ncores,
+                               "kind": "port",
+                               "sample": "NumPy/SciPy oracle restatement (not Julia), iterations 1-%d of the same "
+                                         "instance, %.1f s of CPU work, OpenBLAS threads=%d" % (cpu_it, cpu_loop, ncores),
+                               "gpu_it_per_s_same_iterations": min(cpu_it, len(tr)) / max(gpu_same, 1e-9),
+                               "wall_s": time.time() - tc}
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,265 @@
+/*
+ * proxsdp_hip.h -- C ABI of libproxsdp_hip.so, the MI355X (gfx950) implementation
+ * of ProxSDP's PDHG hot path.
+ *
+ * Drop-in boundary.  The reference has no FFI: its solver is entered through ONE
+ * call, `sol = chambolle_pock(aff, con, options)` at
+ * /root/reference/src/MOI_wrapper.jl:310 (inside `_optimize!`, :220-342).
+ * `proxsdp_hip_solve` replaces exactly that call: its three arguments carry
+ *     AffineSets + ConicSets   /root/reference/src/structs.jl:32-58
+ *     Options                  /root/reference/src/options.jl:1-132
+ *     Result                   /root/reference/src/structs.jl:60-81
+ * A Julia binding calls it with `ccall` (see INTEGRATION.md and julia/); the
+ * Python ctypes binding in proxsdp.jl_amd/binding.py is what the tests use.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; all pointers are HOST pointers, borrowed for
+ *     the duration of the call, never freed or written by the library (the
+ *     reference mutates `aff` in place -- scaling.jl:24, pdhg.jl:647-663 -- the
+ *     library works on private copies).
+ *   - return value: 0 = the solve ran to a solver status (whatever it is);
+ *     < 0 = the call failed (PROXSDP_E_*), text in proxsdp_hip_last_error().
+ *     Nothing unwinds across the ABI.  There is NO CPU fallback: without a
+ *     usable HIP device every compute entry point returns PROXSDP_E_HIP.
+ *   - Float64 arithmetic throughout (the reference is Float64 only).
+ */
+#ifndef PROXSDP_HIP_H
+#define PROXSDP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PROXSDP_HIP_ABI_VERSION 1
+
+/* error codes (negative return values) */
+#define PROXSDP_E_INVALID  (-1)   /* invalid argument / inconsistent problem data */
+#define PROXSDP_E_HIP      (-2)   /* HIP runtime / rocSOLVER failure, no device   */
+#define PROXSDP_E_NOMEM    (-3)   /* host or device allocation failed             */
+#define PROXSDP_E_UNSUPP   (-4)   /* option combination not implemented           */
+#define PROXSDP_E_INTERNAL (-5)
+
+/* solver status: Result.status, /root/reference/src/MOI_wrapper.jl:381-399 */
+#define PROXSDP_STATUS_NOT_CALLED       0
+#define PROXSDP_STATUS_OPTIMAL          1
+#define PROXSDP_STATUS_TIME_LIMIT       2
+#define PROXSDP_STATUS_ITERATION_LIMIT  3
+#define PROXSDP_STATUS_INFEAS_OR_UNBND  4
+#define PROXSDP_STATUS_DUAL_INFEASIBLE  5
+#define PROXSDP_STATUS_INFEASIBLE       6
+
+/* SparseMatrixCSC{Float64,Int64} (structs.jl:36-37) */
+typedef struct proxsdp_csc {
+    int64_t nrows;
+    int64_t ncols;
+    const int64_t* colptr;   /* ncols+1 entries, base = problem.index_base */
+    const int64_t* rowval;   /* nnz entries,     base = problem.index_base */
+    const double*  nzval;    /* nnz entries */
+} proxsdp_csc;
+
+/* AffineSets + ConicSets as assembled at MOI_wrapper.jl:229-292:
+ *   minimise c'x   s.t.  A x = b,  G x <= h,  x restricted to the cones.
+ * PSD cones are MOI PositiveSemidefiniteConeTriangle variable lists (upper
+ * triangle, column by column); SOC cones are (t, x...) variable lists. */
+typedef struct proxsdp_problem {
+    int64_t n;                 /* number of scalar variables            (aff.n) */
+    int64_t p;                 /* equality rows                         (aff.p) */
+    int64_t m;                 /* inequality rows                       (aff.m) */
+    proxsdp_csc A;             /* p x n */
+    proxsdp_csc G;             /* m x n */
+    const double* b;           /* p */
+    const double* h;           /* m */
+    const double* c;           /* n, already sign-flipped for MAX sense (:252-255) */
+    int64_t n_psd;
+    const int64_t* psd_ptr;    /* n_psd+1 offsets into psd_idx (0-based offsets)   */
+    const int64_t* psd_idx;    /* SDPSet.vec_i of every cone, concatenated         */
+    int64_t n_soc;
+    const int64_t* soc_ptr;    /* n_soc+1 */
+    const int64_t* soc_idx;    /* SOCSet.idx concatenated */
+    int32_t index_base;        /* 0 or 1: base of colptr/rowval/psd_idx/soc_idx    */
+    int32_t reserved0;
+    /* optional (may be NULL): Lanczos start vectors, one per PSD cone, sides
+     * concatenated.  The reference uses normalize!(randn(MersenneTwister(seed), n))
+     * (eigsolver.jl:392-411), which only Julia can generate; when NULL the library
+     * uses its own counter-based generator (csrc/host_util.hpp, mirrored in
+     * oracle/eig.py:start_vector). */
+    const double* eig_resid;
+} proxsdp_problem;
+
+/* Options (options.jl:1-132): same names, same defaults (proxsdp_hip_default_options).
+ * Booleans are int32 0/1.  Fields that have no use in the reference's src/ are kept
+ * for name parity and ignored (convergence_check, min_beta, max_beta, reduce_rank,
+ * warm_start_eig, disable_julia_logger, timer_*). */
+typedef struct proxsdp_options {
+    int64_t struct_size;       /* = sizeof(proxsdp_options), set by default_options */
+    /* printing */
+    int32_t log_verbose;  int32_t log_freq;
+    int32_t timer_verbose; int32_t timer_file; int32_t disable_julia_logger;
+    int32_t warn_on_limit; int32_t extended_log; int32_t extended_log2; int32_t log_repeat_header;
+    int32_t pad0;
+    double  time_limit;
+    /* tolerances */
+    double tol_gap, tol_feasibility, tol_feasibility_dual, tol_primal, tol_dual, tol_psd, tol_soc;
+    int32_t check_dual_feas; int32_t check_dual_feas_freq;
+    double  max_obj; int32_t min_iter_max_obj; int32_t pad1;
+    /* infeasibility */
+    int32_t min_iter_time_infeas; int32_t pad2;
+    double infeas_gap_tol, infeas_limit_gap_tol, infeas_stable_gap_tol,
+           infeas_feasibility_tol, infeas_stable_feasibility_tol;
+    int32_t certificate_search; int32_t pad3;
+    double certificate_obj_tol, certificate_fail_tol;
+    double min_beta, max_beta, initial_beta;
+    /* adaptive steps */
+    double initial_adapt_level, adapt_decay; int32_t adapt_window; int32_t pad4;
+    /* PDHG */
+    int32_t convergence_window; int32_t convergence_check;
+    int64_t max_iter; int64_t min_iter; int64_t divergence_min_update;
+    int64_t max_iter_lp; int64_t max_iter_conic; int64_t max_iter_local;
+    int32_t advanced_initialization; int32_t line_search_flag;
+    int32_t max_linsearch_steps; int32_t pad5;
+    double delta, initial_theta, linsearch_decay;
+    /* spectral decomposition */
+    int32_t full_eig_decomp; int32_t max_target_rank_krylov_eigs;
+    int32_t min_size_krylov_eigs; int32_t warm_start_eig;
+    int32_t rank_increment; int32_t rank_increment_factor;
+    int32_t eigsolver; int32_t eigsolver_min_lanczos; int64_t eigsolver_resid_seed;
+    double  arpack_tol; int32_t arpack_resid_init; int32_t arpack_reset_resid; int64_t arpack_max_iter;
+    int32_t krylovkit_reset_resid; int32_t krylovkit_resid_init;
+    double  krylovkit_tol; int32_t krylovkit_max_iter; int32_t krylovkit_eager; int32_t krylovkit_verbose;
+    int32_t reduce_rank; int32_t rank_slack; int32_t pad6;
+    int64_t full_eig_freq; int64_t full_eig_len;
+    /* equilibration (off by default; =1 is PROXSDP_E_UNSUPP) */
+    int32_t equilibration; int32_t equilibration_iters;
+    double  equilibration_lb, equilibration_ub, equilibration_limit;
+    int32_t equilibration_force; int32_t approx_norm;
+    /* ---- library-only knobs (no reference counterpart) ---- */
+    int32_t device_id;         /* HIP device ordinal, default 0                      */
+    int32_t trace_capacity;    /* rows available in result.trace (0 = no trace)      */
+    int32_t profile_symv_every;/* >0: bracket every k-th symv launch with HIP events  */
+    int32_t pad7;
+} proxsdp_options;
+
+#define PROXSDP_TRACE_COLS 14
+/* trace row: iter, prim_obj, dual_obj, gap, feas, prim_res, dual_res, primal_step,
+ *            beta, theta, target_rank(block 0), linesearch trials,
+ *            elapsed (s since the loop started, host clock after the iteration's last
+ *            stream synchronisation), Lanczos mat-vecs of this iteration */
+
+/* counters and timers (the reference's TimerOutputs sections) */
+typedef struct proxsdp_stats {
+    int64_t lanczos_matvecs;     /* symmetric mat-vecs inside Lanczos (all blocks)   */
+    int64_t lanczos_restarts;
+    int64_t lanczos_calls;
+    int64_t full_eigs;           /* full_eig! calls                                  */
+    int64_t krylov_fallbacks;    /* Krylov not converged -> full_eig! fallback       */
+    int64_t linesearch_trials;
+    int64_t symv_launches;       /* == lanczos_matvecs                               */
+    int64_t symv_profiled;       /* launches bracketed by events                     */
+    double  symv_profiled_ms;    /* sum of their durations                           */
+    double  symv_bytes;          /* algorithmic bytes of all symv launches (8*N + 16*n each) */
+    double  algorithmic_bytes;   /* B_iter summed over iterations        */
+    double  init_time;           /* s: preprocess + upload ("Init")                  */
+    double  loop_time;           /* s: the PDHG loop ("CP loop")                     */
+    double  exit_time;           /* s: cache_solution                                */
+    double  t_primal, t_psd, t_linesearch, t_residual;   /* s, host wall incl. syncs */
+} proxsdp_stats;
+
+/* Result (structs.jl:60-81).  Arrays are caller-allocated with the stated
+ * lengths (NULL = not wanted); values are unscaled and in USER variable order
+ * (pdhg.jl:768-769).  objval/dual_objval are the minimisation objective; the
+ * sign/constant fix-up of MOI_wrapper.jl:336-337 stays with the caller. */
+typedef struct proxsdp_result {
+    int32_t status;                 /* PROXSDP_STATUS_*                              */
+    int32_t certificate_found;
+    int32_t primal_feasible_user_tol;
+    int32_t dual_feasible_user_tol;
+    int32_t result_count;
+    int32_t final_rank;
+    int64_t iter;
+    double  primal_residual;        /* carries equa_feasibility (sic, pdhg.jl:774)   */
+    double  dual_residual;          /* carries ineq_feasibility (sic, pdhg.jl:775)   */
+    double  objval, dual_objval, gap, time;
+    double  dual_feasibility;       /* value behind dual_feasible_user_tol           */
+    double* primal;                 /* n */
+    double* dual_cone;              /* n */
+    double* dual_eq;                /* p */
+    double* dual_in;                /* m */
+    double* slack_eq;               /* p */
+    double* slack_in;               /* m */
+    double* trace;                  /* trace_capacity x PROXSDP_TRACE_COLS, row-major */
+    int64_t trace_rows;             /* rows written                                  */
+    char    status_string[256];
+    proxsdp_stats stats;
+} proxsdp_result;
+
+/* ------------------------------------------------------------------ drop-in */
+int  proxsdp_hip_abi_version(void);
+void proxsdp_hip_default_options(proxsdp_options* opt);          /* options.jl defaults */
+/* set an option by its reference name (RawOptimizerAttribute semantics,
+ * MOI_wrapper.jl:84-93): unknown name -> PROXSDP_E_INVALID */
+int  proxsdp_hip_set_option(proxsdp_options* opt, const char* name, double value);
+int  proxsdp_hip_get_option(const proxsdp_options* opt, const char* name, double* value);
+/* replaces chambolle_pock(aff, con, opt) -- MOI_wrapper.jl:310, pdhg.jl:1-530 */
+int  proxsdp_hip_solve(const proxsdp_problem* prob, const proxsdp_options* opt,
+                       proxsdp_result* res);
+const char* proxsdp_hip_last_error(void);
+int  proxsdp_hip_device_count(void);          /* <0: PROXSDP_E_HIP */
+
+/* ------------------------------------------- kernel-level test entry points
+ * (not part of the drop-in; each is pinned against the oracle in tests/).
+ * All pointers are host pointers; data is copied to the device, the kernel(s)
+ * run, results are copied back. */
+
+/* psd_projection! of ONE block given in packed svec form
+ * (prox_operators.jl:33-66 with psd_vec_to_square/psd_square_to_vec :1-31).
+ * mode 0: Lanczos path (krylovkit_eig!, :89-109) with nev = target_rank,
+ *         falling back to full_eig! when not converged;
+ * mode 1: full_eig! (:111-126).
+ * resid: start vector (n) or NULL.  out_*: rank (current_rank), min_eig,
+ * nmatvec, converged eigenpairs, fell_back flag. */
+int proxsdp_hip_psd_project(const double* packed_in, int64_t n, int32_t target_rank,
+                            int32_t mode, const proxsdp_options* opt, const double* resid,
+                            double* packed_out, int32_t* out_rank, double* out_min_eig,
+                            int64_t* out_nmatvec, int32_t* out_converged, int32_t* out_fell_back);
+
+/* Lanczos partial eigendecomposition of smat(packed) (eigsolver.jl:798-823):
+ * vals (capacity cap), vecs (n x cap column-major); returns count in *out_count,
+ * info.converged in *out_converged. */
+int proxsdp_hip_eigsolve(const double* packed, int64_t n, int32_t nev,
+                         const proxsdp_options* opt, const double* resid, int32_t cap,
+                         double* vals, double* vecs, int32_t* out_count,
+                         int32_t* out_converged, int64_t* out_nmatvec, int32_t* out_numiter);
+
+/* y = smat(packed) * v, the Lanczos operator (dsymv('U') in the reference,
+ * eigsolver.jl:678); repeat>1 re-launches for timing, *ms = mean kernel time. */
+int proxsdp_hip_symv_packed(const double* packed, int64_t n, const double* v, double* y,
+                            int32_t repeat, double* ms);
+
+/* packed_out = svec(sum_k lambda_k z_k z_k') over lambda_k > 0
+ * (fill! + rank-1 dgemm loop, prox_operators.jl:92-106, then :17-31) */
+int proxsdp_hip_reconstruct(const double* Z, const double* lambda, int64_t n, int32_t r,
+                            double* packed_out, int32_t repeat, double* ms);
+
+/* Mx = M x (pdhg.jl:634) and Mty = M' y (pdhg.jl:556) for M given as CSC */
+int proxsdp_hip_spmv(const proxsdp_csc* M, int32_t index_base, int32_t transpose,
+                     const double* in, double* out);
+
+/* ------------------------------------------- host-only helpers (no GPU needed;
+ * exercised by the CPU test-suite) */
+/* eigen-decomposition of a small dense symmetric matrix (column-major k x k,
+ * overwritten by eigenvectors; d ascending) -- the K x K Rayleigh quotient of
+ * the thick-restart Lanczos */
+int proxsdp_host_symeig(int32_t k, double* a, double* d);
+/* the library's Lanczos start vector (init 3/2/1 as options.jl:98-103) */
+int proxsdp_host_start_vector(int64_t n, int64_t seed, int32_t init, double* out);
+/* preprocess!/norm_scaling (scaling.jl): returns the variable order, the
+ * inverse permutation and the scaled c; for layout tests */
+int proxsdp_host_preprocess(const proxsdp_problem* prob, int64_t* order, int64_t* var_ordering,
+                            double* c_scaled, double* frobenius_norm_M);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PROXSDP_HIP_H */

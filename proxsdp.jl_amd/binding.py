@@ -1,0 +1,375 @@
+"""ctypes binding of include/proxsdp_hip.h (libproxsdp_hip.so).
+
+This is the Python twin of the Julia `ccall` shim in julia/ProxSDPHip.jl: it
+marshals the standard form that `_optimize!` builds
+(/root/reference/src/MOI_wrapper.jl:229-292) into `proxsdp_problem`, calls
+`proxsdp_hip_solve` -- the replacement for `chambolle_pock(aff, con, options)`
+at MOI_wrapper.jl:310 -- and copies `proxsdp_result` out.
+
+There is no CPU fallback: a missing library raises ImportError-like
+`LibraryNotBuilt`, and every compute entry point raises `ProxSDPHipError` when
+the HIP runtime reports no device.
+"""
+import ctypes as C
+import os
+import pathlib
+import re
+
+import numpy as np
+import scipy.sparse as sp
+
+_HERE = pathlib.Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libproxsdp_hip.so"
+HEADER_PATH = _HERE.parent / "include" / "proxsdp_hip.h"
+
+TRACE_COLS = 14
+TRACE_NAMES = ("iter", "prim_obj", "dual_obj", "gap", "feas", "prim_res", "dual_res",
+               "primal_step", "beta", "theta", "target_rank", "trials", "elapsed", "matvecs")
+
+
+class LibraryNotBuilt(RuntimeError):
+    pass
+
+
+class ProxSDPHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libproxsdp_hip error {code}: {msg}")
+        self.code = code
+
+
+i32, i64, f64 = C.c_int32, C.c_int64, C.c_double
+pi64 = C.POINTER(C.c_int64)
+pf64 = C.POINTER(C.c_double)
+
+
+class CSC(C.Structure):
+    _fields_ = [("nrows", i64), ("ncols", i64), ("colptr", pi64), ("rowval", pi64), ("nzval", pf64)]
+
+
+class Problem(C.Structure):
+    _fields_ = [("n", i64), ("p", i64), ("m", i64), ("A", CSC), ("G", CSC),
+                ("b", pf64), ("h", pf64), ("c", pf64),
+                ("n_psd", i64), ("psd_ptr", pi64), ("psd_idx", pi64),
+                ("n_soc", i64), ("soc_ptr", pi64), ("soc_idx", pi64),
+                ("index_base", i32), ("reserved0", i32), ("eig_resid", pf64)]
+
+
+def _opt_fields():
+    F = []
+    a = lambda name, t: F.append((name, t))
+    a("struct_size", i64)
+    for nme in ("log_verbose", "log_freq", "timer_verbose", "timer_file", "disable_julia_logger",
+                "warn_on_limit", "extended_log", "extended_log2", "log_repeat_header", "pad0"):
+        a(nme, i32)
+    a("time_limit", f64)
+    for nme in ("tol_gap", "tol_feasibility", "tol_feasibility_dual", "tol_primal", "tol_dual",
+                "tol_psd", "tol_soc"):
+        a(nme, f64)
+    a("check_dual_feas", i32); a("check_dual_feas_freq", i32)
+    a("max_obj", f64); a("min_iter_max_obj", i32); a("pad1", i32)
+    a("min_iter_time_infeas", i32); a("pad2", i32)
+    for nme in ("infeas_gap_tol", "infeas_limit_gap_tol", "infeas_stable_gap_tol",
+                "infeas_feasibility_tol", "infeas_stable_feasibility_tol"):
+        a(nme, f64)
+    a("certificate_search", i32); a("pad3", i32)
+    a("certificate_obj_tol", f64); a("certificate_fail_tol", f64)
+    a("min_beta", f64); a("max_beta", f64); a("initial_beta", f64)
+    a("initial_adapt_level", f64); a("adapt_decay", f64); a("adapt_window", i32); a("pad4", i32)
+    a("convergence_window", i32); a("convergence_check", i32)
+    for nme in ("max_iter", "min_iter", "divergence_min_update", "max_iter_lp", "max_iter_conic",
+                "max_iter_local"):
+        a(nme, i64)
+    a("advanced_initialization", i32); a("line_search_flag", i32)
+    a("max_linsearch_steps", i32); a("pad5", i32)
+    a("delta", f64); a("initial_theta", f64); a("linsearch_decay", f64)
+    a("full_eig_decomp", i32); a("max_target_rank_krylov_eigs", i32)
+    a("min_size_krylov_eigs", i32); a("warm_start_eig", i32)
+    a("rank_increment", i32); a("rank_increment_factor", i32)
+    a("eigsolver", i32); a("eigsolver_min_lanczos", i32); a("eigsolver_resid_seed", i64)
+    a("arpack_tol", f64); a("arpack_resid_init", i32); a("arpack_reset_resid", i32); a("arpack_max_iter", i64)
+    a("krylovkit_reset_resid", i32); a("krylovkit_resid_init", i32)
+    a("krylovkit_tol", f64); a("krylovkit_max_iter", i32); a("krylovkit_eager", i32); a("krylovkit_verbose", i32)
+    a("reduce_rank", i32); a("rank_slack", i32); a("pad6", i32)
+    a("full_eig_freq", i64); a("full_eig_len", i64)
+    a("equilibration", i32); a("equilibration_iters", i32)
+    a("equilibration_lb", f64); a("equilibration_ub", f64); a("equilibration_limit", f64)
+    a("equilibration_force", i32); a("approx_norm", i32)
+    a("device_id", i32); a("trace_capacity", i32); a("profile_symv_every", i32); a("pad7", i32)
+    return F
+
+
+class Options(C.Structure):
+    _fields_ = _opt_fields()
+
+
+class Stats(C.Structure):
+    _fields_ = [("lanczos_matvecs", i64), ("lanczos_restarts", i64), ("lanczos_calls", i64),
+                ("full_eigs", i64), ("krylov_fallbacks", i64), ("linesearch_trials", i64),
+                ("symv_launches", i64), ("symv_profiled", i64), ("symv_profiled_ms", f64),
+                ("symv_bytes", f64), ("algorithmic_bytes", f64), ("init_time", f64),
+                ("loop_time", f64), ("exit_time", f64), ("t_primal", f64), ("t_psd", f64),
+                ("t_linesearch", f64), ("t_residual", f64)]
+
+
+class Result(C.Structure):
+    _fields_ = [("status", i32), ("certificate_found", i32), ("primal_feasible_user_tol", i32),
+                ("dual_feasible_user_tol", i32), ("result_count", i32), ("final_rank", i32),
+                ("iter", i64), ("primal_residual", f64), ("dual_residual", f64),
+                ("objval", f64), ("dual_objval", f64), ("gap", f64), ("time", f64),
+                ("dual_feasibility", f64),
+                ("primal", pf64), ("dual_cone", pf64), ("dual_eq", pf64), ("dual_in", pf64),
+                ("slack_eq", pf64), ("slack_in", pf64), ("trace", pf64), ("trace_rows", i64),
+                ("status_string", C.c_char * 256), ("stats", Stats)]
+
+
+_lib = None
+
+
+def header_symbols():
+    """Every function the public header declares (used by the CPU symbol test)."""
+    txt = HEADER_PATH.read_text()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(proxsdp_(?:hip|host)_\w+)\s*\(", txt)))
+
+
+def lib():
+    """Load libproxsdp_hip.so (built in-tree by __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise LibraryNotBuilt(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C proxsdp.jl_amd/csrc`).  There is no CPU fallback.")
+    L = C.CDLL(str(LIB_PATH))
+    L.proxsdp_hip_abi_version.restype = C.c_int
+    L.proxsdp_hip_last_error.restype = C.c_char_p
+    L.proxsdp_hip_default_options.argtypes = [C.POINTER(Options)]
+    L.proxsdp_hip_default_options.restype = None
+    L.proxsdp_hip_set_option.argtypes = [C.POINTER(Options), C.c_char_p, f64]
+    L.proxsdp_hip_get_option.argtypes = [C.POINTER(Options), C.c_char_p, pf64]
+    L.proxsdp_hip_solve.argtypes = [C.POINTER(Problem), C.POINTER(Options), C.POINTER(Result)]
+    L.proxsdp_hip_psd_project.argtypes = [pf64, i64, i32, i32, C.POINTER(Options), pf64, pf64,
+                                          C.POINTER(i32), pf64, pi64, C.POINTER(i32), C.POINTER(i32)]
+    L.proxsdp_hip_eigsolve.argtypes = [pf64, i64, i32, C.POINTER(Options), pf64, i32, pf64, pf64,
+                                       C.POINTER(i32), C.POINTER(i32), pi64, C.POINTER(i32)]
+    L.proxsdp_hip_symv_packed.argtypes = [pf64, i64, pf64, pf64, i32, pf64]
+    L.proxsdp_hip_reconstruct.argtypes = [pf64, pf64, i64, i32, pf64, i32, pf64]
+    L.proxsdp_hip_spmv.argtypes = [C.POINTER(CSC), i32, i32, pf64, pf64]
+    L.proxsdp_host_symeig.argtypes = [i32, pf64, pf64]
+    L.proxsdp_host_start_vector.argtypes = [i64, i64, i32, pf64]
+    L.proxsdp_host_preprocess.argtypes = [C.POINTER(Problem), pi64, pi64, pf64, pf64]
+    if L.proxsdp_hip_abi_version() != 1:
+        raise ProxSDPHipError(-1, "ABI version mismatch")
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise ProxSDPHipError(rc, lib().proxsdp_hip_last_error().decode(errors="replace"))
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _p(a, t=pf64):
+    return a.ctypes.data_as(t)
+
+
+def default_options():
+    o = Options()
+    lib().proxsdp_hip_default_options(C.byref(o))
+    return o
+
+
+def set_option(o, name, value):
+    """RawOptimizerAttribute semantics (MOI_wrapper.jl:84-93): unknown name is an error."""
+    rc = lib().proxsdp_hip_set_option(C.byref(o), name.encode(), float(value))
+    if rc != 0:
+        raise KeyError(f"No parameter matching {name}")
+
+
+def get_option(o, name):
+    v = f64()
+    rc = lib().proxsdp_hip_get_option(C.byref(o), name.encode(), C.byref(v))
+    if rc != 0:
+        raise KeyError(f"No parameter matching {name}")
+    return v.value
+
+
+def device_count():
+    return lib().proxsdp_hip_device_count()
+
+
+class _Marshalled:
+    """Keeps the numpy arrays behind a proxsdp_problem alive."""
+
+    def __init__(self, prob, eig_resid=None):
+        keep = []
+
+        def csc(M, ncols):
+            M = sp.csc_matrix(M, dtype=np.float64)
+            M.sort_indices()
+            cp, rv, nz = _i(M.indptr), _i(M.indices), _f(M.data)
+            keep.extend([cp, rv, nz])
+            return CSC(M.shape[0], ncols, _p(cp, pi64), _p(rv, pi64), _p(nz))
+
+        P = Problem()
+        P.n, P.p, P.m = prob.n, prob.A.shape[0], prob.G.shape[0]
+        P.A, P.G = csc(prob.A, prob.n), csc(prob.G, prob.n)
+        b, h, c = _f(prob.b), _f(prob.h), _f(prob.c)
+        keep.extend([b, h, c])
+        P.b, P.h, P.c = _p(b), _p(h), _p(c)
+
+        def cones(lst):
+            ptr = np.zeros(len(lst) + 1, dtype=np.int64)
+            for k, v in enumerate(lst):
+                ptr[k + 1] = ptr[k] + len(v)
+            idx = _i(np.concatenate(lst)) if lst else np.zeros(1, dtype=np.int64)
+            keep.extend([ptr, idx])
+            return len(lst), _p(ptr, pi64), _p(idx, pi64)
+
+        P.n_psd, P.psd_ptr, P.psd_idx = cones(list(prob.psd))
+        P.n_soc, P.soc_ptr, P.soc_idx = cones(list(prob.soc))
+        P.index_base = 0
+        if eig_resid is not None:
+            r = _f(np.concatenate([np.asarray(v, float).ravel() for v in eig_resid]))
+            keep.append(r)
+            P.eig_resid = _p(r)
+        self.P, self.keep = P, keep
+
+
+class SolveResult:
+    """Result (structs.jl:60-81) copied out of proxsdp_result."""
+
+    def __init__(self, R, n, p, m, arrays, trace):
+        for name, _ in Result._fields_:
+            if name in ("primal", "dual_cone", "dual_eq", "dual_in", "slack_eq", "slack_in", "trace", "stats"):
+                continue
+            v = getattr(R, name)
+            setattr(self, name, v.decode(errors="replace") if isinstance(v, bytes) else v)
+        self.primal, self.dual_cone, self.dual_eq, self.dual_in, self.slack_eq, self.slack_in = arrays
+        self.stats = {k: getattr(R.stats, k) for k, _ in Stats._fields_}
+        self.trace = trace[:R.trace_rows].copy()
+        for k in ("certificate_found", "primal_feasible_user_tol", "dual_feasible_user_tol"):
+            setattr(self, k, bool(getattr(self, k)))
+
+    def trace_dicts(self):
+        return [dict(zip(TRACE_NAMES, row)) for row in self.trace]
+
+
+def solve(prob, options=None, eig_resid=None, trace_capacity=0):
+    """proxsdp_hip_solve: replaces chambolle_pock(aff, con, options) (MOI_wrapper.jl:310).
+    Returns the minimisation objective; sign/constant fix-up is the caller's
+    (MOI_wrapper.jl:336-337), see optimizer.Optimizer."""
+    L = lib()
+    o = options if options is not None else default_options()
+    if trace_capacity:
+        o.trace_capacity = int(trace_capacity)
+    M = _Marshalled(prob, eig_resid)
+    n, p, m = M.P.n, M.P.p, M.P.m
+    arrays = [np.zeros(max(k, 1)) for k in (n, n, p, m, p, m)]
+    trace = np.zeros((max(o.trace_capacity, 1), TRACE_COLS))
+    R = Result()
+    R.primal, R.dual_cone, R.dual_eq, R.dual_in, R.slack_eq, R.slack_in = [_p(a) for a in arrays]
+    R.trace = _p(trace)
+    _check(L.proxsdp_hip_solve(C.byref(M.P), C.byref(o), C.byref(R)))
+    arrays = [a[:k] for a, k in zip(arrays, (n, n, p, m, p, m))]
+    return SolveResult(R, n, p, m, arrays, trace)
+
+
+# ----------------------------------------------------------------- kernel-level entry points
+def psd_project(packed, n, target_rank, mode=0, options=None, resid=None):
+    L = lib()
+    x = _f(packed)
+    out = np.zeros_like(x)
+    rank, conv, fell = i32(), i32(), i32()
+    mineig, nmv = f64(), i64()
+    r = _f(resid) if resid is not None else None
+    _check(L.proxsdp_hip_psd_project(_p(x), n, target_rank, mode,
+                                     C.byref(options) if options is not None else None,
+                                     _p(r) if r is not None else None, _p(out),
+                                     C.byref(rank), C.byref(mineig), C.byref(nmv), C.byref(conv), C.byref(fell)))
+    return out, dict(rank=rank.value, min_eig=mineig.value, nmatvec=nmv.value,
+                     converged=conv.value, fell_back=fell.value)
+
+
+def eigsolve(packed, n, nev, options=None, resid=None, cap=None):
+    L = lib()
+    x = _f(packed)
+    cap = cap or max(2 * nev + 2, 26)
+    vals = np.zeros(cap)
+    vecs = np.zeros((cap, n))           # row k = k-th vector (column-major n x cap on the C side)
+    cnt, conv, nit = i32(), i32(), i32()
+    nmv = i64()
+    r = _f(resid) if resid is not None else None
+    _check(L.proxsdp_hip_eigsolve(_p(x), n, nev, C.byref(options) if options is not None else None,
+                                  _p(r) if r is not None else None, cap, _p(vals), _p(vecs),
+                                  C.byref(cnt), C.byref(conv), C.byref(nmv), C.byref(nit)))
+    k = min(cnt.value, cap)
+    return vals[:k].copy(), vecs[:k].T.copy(), dict(count=cnt.value, converged=conv.value,
+                                                    nmatvec=nmv.value, numiter=nit.value)
+
+
+def symv_packed(packed, n, v, repeat=0):
+    L = lib()
+    x, vv = _f(packed), _f(v)
+    y = np.zeros(n)
+    ms = f64(0.0)
+    _check(L.proxsdp_hip_symv_packed(_p(x), n, _p(vv), _p(y), repeat, C.byref(ms)))
+    return (y, ms.value) if repeat else y
+
+
+def reconstruct(Z, lam, n, repeat=0):
+    L = lib()
+    Zc = np.asfortranarray(Z, dtype=np.float64)
+    lam = _f(lam)
+    r = len(lam)
+    out = np.zeros(n * (n + 1) // 2)
+    ms = f64(0.0)
+    _check(L.proxsdp_hip_reconstruct(Zc.ctypes.data_as(pf64), _p(lam), n, r, _p(out), repeat, C.byref(ms)))
+    return (out, ms.value) if repeat else out
+
+
+def spmv(M, x, transpose=False):
+    L = lib()
+    M = sp.csc_matrix(M, dtype=np.float64)
+    M.sort_indices()
+    cp, rv, nz = _i(M.indptr), _i(M.indices), _f(M.data)
+    S = CSC(M.shape[0], M.shape[1], _p(cp, pi64), _p(rv, pi64), _p(nz))
+    xin = _f(x)
+    out = np.zeros(M.shape[1] if transpose else M.shape[0])
+    _check(L.proxsdp_hip_spmv(C.byref(S), 0, 1 if transpose else 0, _p(xin), _p(out)))
+    return out
+
+
+# ----------------------------------------------------------------- host-only helpers (no GPU)
+def host_symeig(A):
+    L = lib()
+    a = np.asfortranarray(A, dtype=np.float64).copy(order="F")
+    k = a.shape[0]
+    d = np.zeros(k)
+    _check(L.proxsdp_host_symeig(k, a.ctypes.data_as(pf64), _p(d)))
+    return d, a
+
+
+def host_start_vector(n, seed=1234, init=3):
+    out = np.zeros(n)
+    _check(lib().proxsdp_host_start_vector(n, seed, init, _p(out)))
+    return out
+
+
+def host_preprocess(prob):
+    M = _Marshalled(prob)
+    n = prob.n
+    order, inv = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64)
+    cs = np.zeros(n)
+    fro = f64()
+    _check(lib().proxsdp_host_preprocess(C.byref(M.P), _p(order, pi64), _p(inv, pi64), _p(cs), C.byref(fro)))
+    return order, inv, cs, fro.value

@@ -1,0 +1,302 @@
+// C ABI of libproxsdp_hip.so (include/proxsdp_hip.h).  Nothing unwinds across
+// this boundary: every entry point catches, records the message in a
+// thread-local buffer and returns a negative PROXSDP_E_* code.  There is no CPU
+// fallback: without a HIP device the compute entry points fail with PROXSDP_E_HIP.
+#include <new>
+#include <string>
+
+#include "pdhg_loop.hip.hpp"
+
+namespace {
+thread_local std::string g_last_error;
+
+template <typename F>
+int guarded(F&& f) {
+    try {
+        g_last_error.clear();
+        return f();
+    } catch (const std::bad_alloc&) {
+        g_last_error = "out of memory";
+        return PROXSDP_E_NOMEM;
+    } catch (const proxsdp::HipError& e) {
+        g_last_error = e.what();
+        return PROXSDP_E_HIP;
+    } catch (const std::invalid_argument& e) {
+        g_last_error = e.what();
+        return PROXSDP_E_INVALID;
+    } catch (const std::domain_error& e) {
+        g_last_error = e.what();
+        return PROXSDP_E_UNSUPP;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return PROXSDP_E_INTERNAL;
+    } catch (...) {
+        g_last_error = "unknown error";
+        return PROXSDP_E_INTERNAL;
+    }
+}
+
+// engine-only solver for the kernel-level entry points: one block of side n
+struct Engine {
+    proxsdp_result dummy{};
+    proxsdp::Solver S;
+    Engine(const proxsdp_options* opt, int64_t n, int max_nev)
+        : S(fix(opt), dummy) {
+        if (n < 1 || n > 46340) throw std::invalid_argument("n out of range");
+        S.setup_device();
+        S.eig.resize(1);
+        S.alloc_eigwork(S.eig[0], (int)n, std::min<int>(std::max(max_nev, 2), (int)n));
+    }
+    static proxsdp_options fix(const proxsdp_options* o) {
+        proxsdp_options d;
+        proxsdp::default_options(&d);
+        if (o) {
+            if (o->struct_size != (int64_t)sizeof(proxsdp_options))
+                throw std::invalid_argument("proxsdp_options.struct_size mismatch (ABI version?)");
+            d = *o;
+        }
+        return d;
+    }
+    void set_resid(const double* resid) {
+        proxsdp::EigWork& W = S.eig[0];
+        W.resid_host.assign(W.npad, 0.0);
+        if (resid) std::copy(resid, resid + W.n, W.resid_host.begin());
+        else proxsdp::start_vector(W.n, (uint64_t)S.opt.eigsolver_resid_seed,
+                                   S.opt.eigsolver == 1 ? S.opt.arpack_resid_init : S.opt.krylovkit_resid_init,
+                                   W.resid_host.data());
+        double nr = proxsdp::norm2(W.resid_host.data(), W.n);
+        if (!(nr > 0.0)) throw std::invalid_argument("Lanczos start vector has zero norm");
+        for (int i = 0; i < W.n; ++i) W.resid_host[i] /= nr;
+        W.resid.upload(W.resid_host.data(), W.npad, S.stream);
+        PX_HIP(hipStreamSynchronize(S.stream));
+    }
+};
+}  // namespace
+
+extern "C" {
+
+int proxsdp_hip_abi_version(void) { return PROXSDP_HIP_ABI_VERSION; }
+
+void proxsdp_hip_default_options(proxsdp_options* opt) {
+    if (opt) proxsdp::default_options(opt);
+}
+
+int proxsdp_hip_set_option(proxsdp_options* opt, const char* name, double value) {
+    if (!opt || !name) { g_last_error = "NULL argument"; return PROXSDP_E_INVALID; }
+    int rc = proxsdp::set_option(opt, name, value);
+    if (rc != 0) g_last_error = std::string("No parameter matching ") + name;
+    return rc;
+}
+
+int proxsdp_hip_get_option(const proxsdp_options* opt, const char* name, double* value) {
+    if (!opt || !name || !value) { g_last_error = "NULL argument"; return PROXSDP_E_INVALID; }
+    int rc = proxsdp::get_option(opt, name, value);
+    if (rc != 0) g_last_error = std::string("No parameter matching ") + name;
+    return rc;
+}
+
+const char* proxsdp_hip_last_error(void) { return g_last_error.c_str(); }
+
+int proxsdp_hip_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        g_last_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(e);
+        return PROXSDP_E_HIP;
+    }
+    return n;
+}
+
+int proxsdp_hip_solve(const proxsdp_problem* prob, const proxsdp_options* opt, proxsdp_result* res) {
+    return guarded([&]() -> int {
+        if (!prob || !res) throw std::invalid_argument("NULL problem or result");
+        proxsdp_options o = Engine::fix(opt);
+        res->status = PROXSDP_STATUS_NOT_CALLED;
+        res->trace_rows = 0;
+        res->result_count = 0;
+        res->certificate_found = 0;
+        res->status_string[0] = 0;
+        if (o.trace_capacity > 0 && !res->trace) o.trace_capacity = 0;
+        proxsdp::Solver S(*prob, o, *res);
+        S.run();
+        return 0;
+    });
+}
+
+int proxsdp_hip_psd_project(const double* packed_in, int64_t n, int32_t target_rank, int32_t mode,
+                            const proxsdp_options* opt, const double* resid, double* packed_out,
+                            int32_t* out_rank, double* out_min_eig, int64_t* out_nmatvec,
+                            int32_t* out_converged, int32_t* out_fell_back) {
+    return guarded([&]() -> int {
+        if (!packed_in || !packed_out) throw std::invalid_argument("NULL buffer");
+        if (target_rank < 1) throw std::invalid_argument("target_rank < 1");
+        proxsdp_options o = Engine::fix(opt);
+        if (mode == 1) o.full_eig_decomp = 1;
+        // the test entry point takes the Krylov branch whenever mode == 0
+        if (mode == 0) { o.min_size_krylov_eigs = 0; o.max_target_rank_krylov_eigs = std::max(o.max_target_rank_krylov_eigs, target_rank); }
+        Engine E(&o, n, target_rank);
+        E.set_resid(resid);
+        proxsdp::Solver& S = E.S;
+        const int64_t N = n * (n + 1) / 2;
+        proxsdp::DevBuf<double> x(N);
+        x.upload(packed_in, N, S.stream);
+        S.P.blocks.push_back({(int)n, N, 0});
+        S.test_project(0, x.p, target_rank);
+        x.download(packed_out, N, S.stream);
+        PX_HIP(hipStreamSynchronize(S.stream));
+        if (out_rank) *out_rank = (int32_t)S.test_rank();
+        if (out_min_eig) *out_min_eig = S.test_min_eig();
+        if (out_nmatvec) *out_nmatvec = S.st.lanczos_matvecs;
+        if (out_converged) *out_converged = S.eig[0].converged_eigs;
+        if (out_fell_back) *out_fell_back = (int32_t)S.st.krylov_fallbacks;
+        return 0;
+    });
+}
+
+int proxsdp_hip_eigsolve(const double* packed, int64_t n, int32_t nev, const proxsdp_options* opt,
+                         const double* resid, int32_t cap, double* vals, double* vecs,
+                         int32_t* out_count, int32_t* out_converged, int64_t* out_nmatvec,
+                         int32_t* out_numiter) {
+    return guarded([&]() -> int {
+        if (!packed || !vals || !vecs) throw std::invalid_argument("NULL buffer");
+        if (nev < 1) throw std::invalid_argument("nev < 1");
+        Engine E(opt, n, nev);
+        E.set_resid(resid);
+        proxsdp::Solver& S = E.S;
+        proxsdp::EigWork& W = S.eig[0];
+        const int64_t N = n * (n + 1) / 2;
+        proxsdp::DevBuf<double> x(N);
+        x.upload(packed, N, S.stream);
+        S.lanczos(W, x.p, nev);
+        PX_HIP(hipStreamSynchronize(S.stream));
+        const int cnt = std::min<int>(W.count, cap);
+        for (int i = 0; i < cnt; ++i) vals[i] = W.vals[i];
+        if (cnt > 0)
+            PX_HIP(hipMemcpy2D(vecs, (size_t)n * 8, W.Z.p, (size_t)W.npad * 8, (size_t)n * 8, cnt,
+                               hipMemcpyDeviceToHost));
+        if (out_count) *out_count = W.count;
+        if (out_converged) *out_converged = W.converged_eigs;
+        if (out_nmatvec) *out_nmatvec = S.st.lanczos_matvecs;
+        if (out_numiter) *out_numiter = W.numiter;
+        return 0;
+    });
+}
+
+int proxsdp_hip_symv_packed(const double* packed, int64_t n, const double* v, double* y,
+                            int32_t repeat, double* ms) {
+    return guarded([&]() -> int {
+        if (!packed || !v || !y) throw std::invalid_argument("NULL buffer");
+        Engine E(nullptr, n, 2);
+        proxsdp::Solver& S = E.S;
+        proxsdp::EigWork& W = S.eig[0];
+        const int64_t N = n * (n + 1) / 2;
+        proxsdp::DevBuf<double> x(N), vd(W.npad);
+        x.upload(packed, N, S.stream);
+        vd.zero(S.stream);
+        vd.upload(v, n, S.stream);
+        PX_HIP(hipMemsetAsync(W.ctl.p, 0, sizeof(proxsdp::dev::LanczosCtl), S.stream));
+        // y = (sum of partials)/sqrt2 through the first Lanczos kernel with an empty basis (k = -1)
+        S.launch_symv(W, x.p, vd.p, false);
+        hipLaunchKernelGGL(proxsdp::dev::k_lz_dots1, dim3(W.nwg), dim3(proxsdp::dev::TPB), 0, S.stream,
+                           W.Ppart.p, W.nt, W.n, W.npad, W.V.p, W.npad, -1, W.w.p, W.hpart1.p, W.ctl.p);
+        W.w.download(y, n, S.stream);
+        PX_HIP(hipStreamSynchronize(S.stream));
+        if (repeat > 0 && ms) {
+            hipEvent_t a, b;
+            PX_HIP(hipEventCreate(&a)); PX_HIP(hipEventCreate(&b));
+            for (int i = 0; i < 3; ++i) S.launch_symv(W, x.p, vd.p, false);
+            PX_HIP(hipEventRecord(a, S.stream));
+            for (int i = 0; i < repeat; ++i) S.launch_symv(W, x.p, vd.p, false);
+            PX_HIP(hipEventRecord(b, S.stream));
+            PX_HIP(hipEventSynchronize(b));
+            float t = 0.f;
+            PX_HIP(hipEventElapsedTime(&t, a, b));
+            *ms = (double)t / repeat;
+            (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+        }
+        return 0;
+    });
+}
+
+int proxsdp_hip_reconstruct(const double* Z, const double* lambda, int64_t n, int32_t r,
+                            double* packed_out, int32_t repeat, double* ms) {
+    return guarded([&]() -> int {
+        if ((r > 0 && (!Z || !lambda)) || !packed_out) throw std::invalid_argument("NULL buffer");
+        if (r < 0) throw std::invalid_argument("r < 0");
+        Engine E(nullptr, n, 2);
+        proxsdp::Solver& S = E.S;
+        proxsdp::EigWork& W = S.eig[0];
+        const int64_t N = n * (n + 1) / 2;
+        proxsdp::DevBuf<double> x(N), Zd((size_t)std::max<int64_t>(1, n * r)), ld(std::max(1, r));
+        Zd.upload(Z, (size_t)n * r, S.stream);
+        ld.upload(lambda, r, S.stream);
+        S.launch_reconstruct(W, Zd.p, (int)n, ld.p, r, x.p);
+        x.download(packed_out, N, S.stream);
+        PX_HIP(hipStreamSynchronize(S.stream));
+        if (repeat > 0 && ms) {
+            hipEvent_t a, b;
+            PX_HIP(hipEventCreate(&a)); PX_HIP(hipEventCreate(&b));
+            PX_HIP(hipEventRecord(a, S.stream));
+            for (int i = 0; i < repeat; ++i) S.launch_reconstruct(W, Zd.p, (int)n, ld.p, r, x.p);
+            PX_HIP(hipEventRecord(b, S.stream));
+            PX_HIP(hipEventSynchronize(b));
+            float t = 0.f;
+            PX_HIP(hipEventElapsedTime(&t, a, b));
+            *ms = (double)t / repeat;
+            (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+        }
+        return 0;
+    });
+}
+
+int proxsdp_hip_spmv(const proxsdp_csc* M, int32_t index_base, int32_t transpose,
+                     const double* in, double* out) {
+    return guarded([&]() -> int {
+        if (!M || !in || !out) throw std::invalid_argument("NULL argument");
+        // run through the same preparation + kernels as the solver
+        proxsdp_problem pr{};
+        pr.n = M->ncols; pr.p = M->nrows; pr.m = 0;
+        pr.A = *M;
+        std::vector<int64_t> zc((size_t)M->ncols + 1, index_base);
+        pr.G.nrows = 0; pr.G.ncols = M->ncols; pr.G.colptr = zc.data();
+        std::vector<double> zb((size_t)std::max<int64_t>(M->nrows, 1), 0.0), zcv((size_t)std::max<int64_t>(M->ncols, 1), 0.0);
+        pr.b = zb.data(); pr.h = zb.data(); pr.c = zcv.data();
+        pr.index_base = index_base;
+        proxsdp_options o;
+        proxsdp::default_options(&o);
+        proxsdp_result dummy{};
+        proxsdp::Solver S(pr, o, dummy);
+        S.test_spmv(transpose != 0, in, out);
+        return 0;
+    });
+}
+
+int proxsdp_host_symeig(int32_t k, double* a, double* d) {
+    if (k < 0 || !a || !d) { g_last_error = "invalid argument"; return PROXSDP_E_INVALID; }
+    int rc = proxsdp::symeig_dense(k, a, d);
+    if (rc != 0) { g_last_error = "QL iteration did not converge"; return PROXSDP_E_INTERNAL; }
+    return 0;
+}
+
+int proxsdp_host_start_vector(int64_t n, int64_t seed, int32_t init, double* out) {
+    if (n < 0 || !out) { g_last_error = "invalid argument"; return PROXSDP_E_INVALID; }
+    proxsdp::start_vector(n, (uint64_t)seed, init, out);
+    return 0;
+}
+
+int proxsdp_host_preprocess(const proxsdp_problem* prob, int64_t* order, int64_t* var_ordering,
+                            double* c_scaled, double* frobenius_norm_M) {
+    return guarded([&]() -> int {
+        if (!prob) throw std::invalid_argument("NULL problem");
+        proxsdp::Prep R = proxsdp::prepare(*prob);
+        for (int64_t i = 0; i < R.n; ++i) {
+            if (order) order[i] = R.ord[i];
+            if (var_ordering) var_ordering[i] = R.inv[i];
+            if (c_scaled) c_scaled[i] = R.c[i];
+        }
+        if (frobenius_norm_M) *frobenius_norm_M = R.frob;
+        return 0;
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,288 @@
+// Host-only helpers of libproxsdp_hip (no HIP calls in this header).
+//
+//  * start_vector     : replacement for eigsolver_update_resid!
+//                       (/root/reference/src/eigsolver.jl:397-411); Julia's
+//                       MersenneTwister stream cannot be reproduced outside Julia,
+//                       so library and oracle (oracle/eig.py:start_vector) share a
+//                       counter-based generator, bit-identical on both sides.
+//  * symeig_dense     : eigen-decomposition of the K x K Rayleigh quotient of the
+//                       thick-restart Lanczos (KrylovKit does this with LAPACK on
+//                       the host as well): Householder tridiagonalisation followed
+//                       by implicit-shift QL.
+//  * option table     : name -> field map for RawOptimizerAttribute semantics
+//                       (/root/reference/src/MOI_wrapper.jl:84-103).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <cstddef>
+#include <vector>
+#include <algorithm>
+#include "../../include/proxsdp_hip.h"
+
+namespace proxsdp {
+
+// ------------------------------------------------------------------ start vector
+inline uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+inline double uniform53(uint64_t seed, uint64_t counter) {
+    uint64_t key = seed ^ ((counter + 1ull) * 0xD1342543DE82EF95ull);
+    return (double)(splitmix64(key) >> 11) * (1.0 / 9007199254740992.0);
+}
+// init 3: normalised Irwin-Hall(12)-6 "normal"; 2: uniform; 1: ones; else zeros
+inline void start_vector(int64_t n, uint64_t seed, int init, double* out) {
+    if (init == 3) {
+        double ss = 0.0;
+        for (int64_t i = 0; i < n; ++i) {
+            double z = 0.0;
+            for (int k = 0; k < 12; ++k) z = z + uniform53(seed, (uint64_t)i * 12ull + (uint64_t)k);
+            z = z - 6.0;
+            out[i] = z;
+            ss = ss + z * z;                 // sequential, as np.cumsum in the oracle
+        }
+        double nrm = std::sqrt(ss);
+        for (int64_t i = 0; i < n; ++i) out[i] = out[i] / nrm;
+    } else if (init == 2) {
+        for (int64_t i = 0; i < n; ++i) out[i] = uniform53(seed, (uint64_t)i * 12ull);
+    } else if (init == 1) {
+        for (int64_t i = 0; i < n; ++i) out[i] = 1.0;
+    } else {
+        for (int64_t i = 0; i < n; ++i) out[i] = 0.0;
+    }
+}
+
+// ------------------------------------------------------------------ small symmetric eig
+// a: column-major n x n symmetric (full storage); on exit columns are orthonormal
+// eigenvectors, d ascending eigenvalues.  Returns 0, or 1 if QL failed to converge.
+inline int symeig_dense(int n, double* a, double* d) {
+    if (n <= 0) return 0;
+    if (n == 1) { d[0] = a[0]; a[0] = 1.0; return 0; }
+    std::vector<double> e(n, 0.0);
+    auto V = [&](int i, int j) -> double& { return a[(size_t)j * n + i]; };
+    // ---- Householder reduction to tridiagonal form (accumulating the transform)
+    for (int j = 0; j < n; ++j) d[j] = V(n - 1, j);
+    for (int i = n - 1; i > 0; --i) {
+        double scale = 0.0, h = 0.0;
+        for (int k = 0; k < i; ++k) scale += std::fabs(d[k]);
+        if (scale == 0.0) {
+            e[i] = d[i - 1];
+            for (int j = 0; j < i; ++j) { d[j] = V(i - 1, j); V(i, j) = 0.0; V(j, i) = 0.0; }
+        } else {
+            for (int k = 0; k < i; ++k) { d[k] /= scale; h += d[k] * d[k]; }
+            double f = d[i - 1];
+            double g = std::sqrt(h);
+            if (f > 0) g = -g;
+            e[i] = scale * g;
+            h -= f * g;
+            d[i - 1] = f - g;
+            for (int j = 0; j < i; ++j) e[j] = 0.0;
+            for (int j = 0; j < i; ++j) {
+                f = d[j];
+                V(j, i) = f;
+                g = e[j] + V(j, j) * f;
+                for (int k = j + 1; k <= i - 1; ++k) { g += V(k, j) * d[k]; e[k] += V(k, j) * f; }
+                e[j] = g;
+            }
+            f = 0.0;
+            for (int j = 0; j < i; ++j) { e[j] /= h; f += e[j] * d[j]; }
+            double hh = f / (h + h);
+            for (int j = 0; j < i; ++j) e[j] -= hh * d[j];
+            for (int j = 0; j < i; ++j) {
+                f = d[j]; g = e[j];
+                for (int k = j; k <= i - 1; ++k) V(k, j) -= (f * e[k] + g * d[k]);
+                d[j] = V(i - 1, j);
+                V(i, j) = 0.0;
+            }
+        }
+        d[i] = h;
+    }
+    for (int i = 0; i < n - 1; ++i) {
+        V(n - 1, i) = V(i, i);
+        V(i, i) = 1.0;
+        double h = d[i + 1];
+        if (h != 0.0) {
+            for (int k = 0; k <= i; ++k) d[k] = V(k, i + 1) / h;
+            for (int j = 0; j <= i; ++j) {
+                double g = 0.0;
+                for (int k = 0; k <= i; ++k) g += V(k, i + 1) * V(k, j);
+                for (int k = 0; k <= i; ++k) V(k, j) -= g * d[k];
+            }
+        }
+        for (int k = 0; k <= i; ++k) V(k, i + 1) = 0.0;
+    }
+    for (int j = 0; j < n; ++j) { d[j] = V(n - 1, j); V(n - 1, j) = 0.0; }
+    V(n - 1, n - 1) = 1.0;
+    e[0] = 0.0;
+    // ---- implicit-shift QL on the tridiagonal (d, e), accumulating into V
+    for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+    e[n - 1] = 0.0;
+    double f = 0.0, tst1 = 0.0;
+    const double eps = 2.220446049250313e-16;
+    int rc = 0;
+    for (int l = 0; l < n; ++l) {
+        tst1 = std::max(tst1, std::fabs(d[l]) + std::fabs(e[l]));
+        int m = l;
+        while (m < n) { if (std::fabs(e[m]) <= eps * tst1) break; ++m; }
+        if (m >= n) m = n - 1;
+        if (m > l) {
+            int iter = 0;
+            do {
+                if (++iter > 200) { rc = 1; break; }
+                double g = d[l];
+                double p = (d[l + 1] - g) / (2.0 * e[l]);
+                double r = std::hypot(p, 1.0);
+                if (p < 0) r = -r;
+                d[l] = e[l] / (p + r);
+                d[l + 1] = e[l] * (p + r);
+                double dl1 = d[l + 1];
+                double h = g - d[l];
+                for (int i = l + 2; i < n; ++i) d[i] -= h;
+                f += h;
+                p = d[m];
+                double c = 1.0, c2 = c, c3 = c, el1 = e[l + 1], s = 0.0, s2 = 0.0;
+                for (int i = m - 1; i >= l; --i) {
+                    c3 = c2; c2 = c; s2 = s;
+                    g = c * e[i];
+                    h = c * p;
+                    r = std::hypot(p, e[i]);
+                    e[i + 1] = s * r;
+                    s = e[i] / r;
+                    c = p / r;
+                    p = c * d[i] - s * g;
+                    d[i + 1] = h + s * (c * g + s * d[i]);
+                    for (int k = 0; k < n; ++k) {
+                        h = V(k, i + 1);
+                        V(k, i + 1) = s * V(k, i) + c * h;
+                        V(k, i) = c * V(k, i) - s * h;
+                    }
+                }
+                p = -s * s2 * c3 * el1 * e[l] / dl1;
+                e[l] = s * p;
+                d[l] = c * p;
+            } while (std::fabs(e[l]) > eps * tst1);
+        }
+        d[l] = d[l] + f;
+        e[l] = 0.0;
+    }
+    // ---- sort ascending
+    for (int i = 0; i < n - 1; ++i) {
+        int k = i; double p = d[i];
+        for (int j = i + 1; j < n; ++j) if (d[j] < p) { k = j; p = d[j]; }
+        if (k != i) {
+            d[k] = d[i]; d[i] = p;
+            for (int j = 0; j < n; ++j) std::swap(V(j, i), V(j, k));
+        }
+    }
+    return rc;
+}
+
+// ------------------------------------------------------------------ options
+enum OptType { OT_I32, OT_I64, OT_F64 };
+struct OptEntry { const char* name; OptType type; size_t offset; };
+
+#define PX_OPT(name, type) { #name, type, offsetof(proxsdp_options, name) }
+inline const std::vector<OptEntry>& option_table() {
+    static const std::vector<OptEntry> t = {
+        PX_OPT(log_verbose, OT_I32), PX_OPT(log_freq, OT_I32), PX_OPT(timer_verbose, OT_I32),
+        PX_OPT(timer_file, OT_I32), PX_OPT(disable_julia_logger, OT_I32), PX_OPT(warn_on_limit, OT_I32),
+        PX_OPT(extended_log, OT_I32), PX_OPT(extended_log2, OT_I32), PX_OPT(log_repeat_header, OT_I32),
+        PX_OPT(time_limit, OT_F64),
+        PX_OPT(tol_gap, OT_F64), PX_OPT(tol_feasibility, OT_F64), PX_OPT(tol_feasibility_dual, OT_F64),
+        PX_OPT(tol_primal, OT_F64), PX_OPT(tol_dual, OT_F64), PX_OPT(tol_psd, OT_F64), PX_OPT(tol_soc, OT_F64),
+        PX_OPT(check_dual_feas, OT_I32), PX_OPT(check_dual_feas_freq, OT_I32),
+        PX_OPT(max_obj, OT_F64), PX_OPT(min_iter_max_obj, OT_I32),
+        PX_OPT(min_iter_time_infeas, OT_I32), PX_OPT(infeas_gap_tol, OT_F64),
+        PX_OPT(infeas_limit_gap_tol, OT_F64), PX_OPT(infeas_stable_gap_tol, OT_F64),
+        PX_OPT(infeas_feasibility_tol, OT_F64), PX_OPT(infeas_stable_feasibility_tol, OT_F64),
+        PX_OPT(certificate_search, OT_I32), PX_OPT(certificate_obj_tol, OT_F64), PX_OPT(certificate_fail_tol, OT_F64),
+        PX_OPT(min_beta, OT_F64), PX_OPT(max_beta, OT_F64), PX_OPT(initial_beta, OT_F64),
+        PX_OPT(initial_adapt_level, OT_F64), PX_OPT(adapt_decay, OT_F64), PX_OPT(adapt_window, OT_I32),
+        PX_OPT(convergence_window, OT_I32), PX_OPT(convergence_check, OT_I32),
+        PX_OPT(max_iter, OT_I64), PX_OPT(min_iter, OT_I64), PX_OPT(divergence_min_update, OT_I64),
+        PX_OPT(max_iter_lp, OT_I64), PX_OPT(max_iter_conic, OT_I64), PX_OPT(max_iter_local, OT_I64),
+        PX_OPT(advanced_initialization, OT_I32), PX_OPT(line_search_flag, OT_I32),
+        PX_OPT(max_linsearch_steps, OT_I32), PX_OPT(delta, OT_F64), PX_OPT(initial_theta, OT_F64),
+        PX_OPT(linsearch_decay, OT_F64),
+        PX_OPT(full_eig_decomp, OT_I32), PX_OPT(max_target_rank_krylov_eigs, OT_I32),
+        PX_OPT(min_size_krylov_eigs, OT_I32), PX_OPT(warm_start_eig, OT_I32),
+        PX_OPT(rank_increment, OT_I32), PX_OPT(rank_increment_factor, OT_I32),
+        PX_OPT(eigsolver, OT_I32), PX_OPT(eigsolver_min_lanczos, OT_I32), PX_OPT(eigsolver_resid_seed, OT_I64),
+        PX_OPT(arpack_tol, OT_F64), PX_OPT(arpack_resid_init, OT_I32), PX_OPT(arpack_reset_resid, OT_I32),
+        PX_OPT(arpack_max_iter, OT_I64),
+        PX_OPT(krylovkit_reset_resid, OT_I32), PX_OPT(krylovkit_resid_init, OT_I32),
+        PX_OPT(krylovkit_tol, OT_F64), PX_OPT(krylovkit_max_iter, OT_I32), PX_OPT(krylovkit_eager, OT_I32),
+        PX_OPT(krylovkit_verbose, OT_I32),
+        PX_OPT(reduce_rank, OT_I32), PX_OPT(rank_slack, OT_I32),
+        PX_OPT(full_eig_freq, OT_I64), PX_OPT(full_eig_len, OT_I64),
+        PX_OPT(equilibration, OT_I32), PX_OPT(equilibration_iters, OT_I32),
+        PX_OPT(equilibration_lb, OT_F64), PX_OPT(equilibration_ub, OT_F64), PX_OPT(equilibration_limit, OT_F64),
+        PX_OPT(equilibration_force, OT_I32), PX_OPT(approx_norm, OT_I32),
+        PX_OPT(device_id, OT_I32), PX_OPT(trace_capacity, OT_I32), PX_OPT(profile_symv_every, OT_I32),
+    };
+    return t;
+}
+#undef PX_OPT
+
+inline void default_options(proxsdp_options* o) {      // options.jl:1-132
+    std::memset(o, 0, sizeof(*o));
+    o->struct_size = (int64_t)sizeof(*o);
+    o->log_verbose = 0; o->log_freq = 1000; o->disable_julia_logger = 1;
+    o->time_limit = 360000.0;
+    o->tol_gap = 1e-4; o->tol_feasibility = 1e-4; o->tol_feasibility_dual = 1e-4;
+    o->tol_primal = 1e-4; o->tol_dual = 1e-4; o->tol_psd = 1e-7; o->tol_soc = 1e-7;
+    o->check_dual_feas = 0; o->check_dual_feas_freq = 1000;
+    o->max_obj = 1e20; o->min_iter_max_obj = 10;
+    o->min_iter_time_infeas = 1000; o->infeas_gap_tol = 1e-4; o->infeas_limit_gap_tol = 1e-1;
+    o->infeas_stable_gap_tol = 1e-4; o->infeas_feasibility_tol = 1e-4;
+    o->infeas_stable_feasibility_tol = 1e-8;
+    o->certificate_search = 1; o->certificate_obj_tol = 1e-1; o->certificate_fail_tol = 1e-8;
+    o->min_beta = 1e-5; o->max_beta = 1e5; o->initial_beta = 1.0;
+    o->initial_adapt_level = 0.9; o->adapt_decay = 0.8; o->adapt_window = 50;
+    o->convergence_window = 200; o->convergence_check = 50;
+    o->max_iter = 0; o->min_iter = 40; o->divergence_min_update = 50;
+    o->max_iter_lp = 10000000; o->max_iter_conic = 1000000; o->max_iter_local = 0;
+    o->advanced_initialization = 1; o->line_search_flag = 1; o->max_linsearch_steps = 5000;
+    o->delta = 0.9999; o->initial_theta = 1.0; o->linsearch_decay = 0.75;
+    o->full_eig_decomp = 0; o->max_target_rank_krylov_eigs = 16; o->min_size_krylov_eigs = 100;
+    o->warm_start_eig = 1; o->rank_increment = 1; o->rank_increment_factor = 1;
+    o->eigsolver = 2; o->eigsolver_min_lanczos = 25; o->eigsolver_resid_seed = 1234;
+    o->arpack_tol = 1e-10; o->arpack_resid_init = 3; o->arpack_reset_resid = 1; o->arpack_max_iter = 10000;
+    o->krylovkit_reset_resid = 0; o->krylovkit_resid_init = 3; o->krylovkit_tol = 1e-12;
+    o->krylovkit_max_iter = 100; o->krylovkit_eager = 0; o->krylovkit_verbose = 0;
+    o->reduce_rank = 0; o->rank_slack = 3; o->full_eig_freq = 10000000; o->full_eig_len = 0;
+    o->equilibration = 0; o->equilibration_iters = 1000; o->equilibration_lb = -10.0;
+    o->equilibration_ub = 10.0; o->equilibration_limit = 0.9; o->equilibration_force = 0;
+    o->approx_norm = 1;
+    o->device_id = 0; o->trace_capacity = 0; o->profile_symv_every = 0;
+}
+
+inline int set_option(proxsdp_options* o, const char* name, double v) {
+    for (const auto& e : option_table()) {
+        if (std::strcmp(e.name, name) == 0) {
+            char* base = reinterpret_cast<char*>(o) + e.offset;
+            if (e.type == OT_I32) *reinterpret_cast<int32_t*>(base) = (int32_t)std::llround(v);
+            else if (e.type == OT_I64) *reinterpret_cast<int64_t*>(base) = (int64_t)std::llround(v);
+            else *reinterpret_cast<double*>(base) = v;
+            return 0;
+        }
+    }
+    return PROXSDP_E_INVALID;
+}
+inline int get_option(const proxsdp_options* o, const char* name, double* v) {
+    for (const auto& e : option_table()) {
+        if (std::strcmp(e.name, name) == 0) {
+            const char* base = reinterpret_cast<const char*>(o) + e.offset;
+            if (e.type == OT_I32) *v = (double)*reinterpret_cast<const int32_t*>(base);
+            else if (e.type == OT_I64) *v = (double)*reinterpret_cast<const int64_t*>(base);
+            else *v = *reinterpret_cast<const double*>(base);
+            return 0;
+        }
+    }
+    return PROXSDP_E_INVALID;
+}
+
+}  // namespace proxsdp

@@ -1,0 +1,597 @@
+// Hand-written gfx950 kernels of the PDHG hot path.  fp64 throughout; wave = 64.
+//
+// Data layout in HBM:
+//   * the primal iterate x keeps the reference's order (scaling.jl:2-26): PSD
+//     blocks first, each as the column-major upper triangle ("packed svec",
+//     entry (i<=j) at j(j+1)/2+i, off-diagonals carrying the sqrt(2) factor),
+//     then SOC variables, then free variables;
+//   * there is NO dense n x n copy of a PSD block on the Lanczos path: the
+//     symmetric mat-vec reads the packed triangle of x directly (8*N bytes per
+//     mat-vec -- exactly what dsymv('U') reads in the reference, half of a GEMV)
+//     and the projection is written back in packed form by the rank-r
+//     reconstruction kernel.  psd_vec_to_square / psd_square_to_vec
+//     (prox_operators.jl:1-31) therefore have no kernel of their own.
+//
+// All reductions are deterministic: fixed-shape shuffle trees inside a wave,
+// LDS across waves, per-workgroup partials combined in a fixed order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace proxsdp {
+namespace dev {
+
+constexpr int WAVE = 64;
+constexpr int TILE = 64;            // symv / reconstruct tile side (rows = lanes)
+constexpr int TPB = 256;            // threads per workgroup everywhere
+constexpr int NWAVE = TPB / WAVE;
+constexpr int CPW = TILE / NWAVE;   // tile columns per wave (16)
+constexpr double INV_SQRT2 = 0.70710678118654752440;
+constexpr double SQRT2 = 1.41421356237309504880;
+
+struct LanczosCtl {                 // device-resident control block of one PSD block
+    int stop;                       // set when beta <= tol (invariant subspace)
+    int kstop;                      // basis size at which it stopped
+    int pad[2];
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
+    return v;                       // valid in lane 0
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, WAVE));
+    return v;
+}
+// block-wide sum; result valid in thread 0.  `sm` needs NWAVE doubles.
+__device__ __forceinline__ double block_sum(double v, double* sm) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NWAVE; ++i) r += sm[i];
+    }
+    return r;
+}
+__device__ __forceinline__ double block_max(double v, double* sm) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm[w] = v;
+    __syncthreads();
+    double r = sm[0];
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 1; i < NWAVE; ++i) r = fmax(r, sm[i]);
+    }
+    return r;
+}
+
+// linear tile id (column-major over the upper block-triangle) -> (I <= J)
+__device__ __forceinline__ void tile_coords(int t, int& I, int& J) {
+    int j = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((long long)(j + 1) * (j + 2) / 2 <= t) ++j;
+    while ((long long)j * (j + 1) / 2 > t) --j;
+    J = j;
+    I = t - (int)((long long)j * (j + 1) / 2);
+}
+
+// ---------------------------------------------------------------------------
+// Symmetric mat-vec on the packed triangle:  u = P~ v  with P~ the symmetric
+// fill of the raw packed values, diagonal pre-multiplied by sqrt(2), so that
+// smat(xp) v = u / sqrt(2)  (the off-diagonals of xp carry a sqrt(2) factor,
+// prox_operators.jl:5-13).  Replaces dsymv('U') (eigsolver.jl:678 / KrylovKit).
+//
+// One workgroup per 64x64 tile (I<=J) of the upper block-triangle.  Lane = row,
+// each wave owns 16 tile columns, so every global load instruction of a wave
+// reads 512 contiguous bytes of one packed column.  The tile contributes
+//   rows of block I :  sum_c T[r,c] v[J*64+c]      (row sums,   slot J)
+//   rows of block J :  sum_r T[r,c] v[I*64+r]      (column sums, slot I)
+// written to Ppart[slot][row]; every (slot,row) is written exactly once per
+// mat-vec, so no zero-fill and no atomics -- the consumer sums the nt slots in
+// a fixed order (deterministic).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(TPB)
+k_symv_packed(const double* __restrict__ xp, int n, int nt, int npad,
+              const double* __restrict__ v, double* __restrict__ Ppart,
+              const LanczosCtl* __restrict__ ctl) {
+    if (ctl != nullptr && ctl->stop) return;
+    __shared__ double s_vI[TILE], s_vJ[TILE];
+    __shared__ double s_prod[TILE][TILE + 1];   // [col][row], padded
+    __shared__ double s_row[NWAVE][TILE];
+    int I, J;
+    tile_coords(blockIdx.x, I, J);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x < TILE) {
+        int gi = I * TILE + threadIdx.x;
+        s_vI[threadIdx.x] = gi < n ? v[gi] : 0.0;
+    } else if (threadIdx.x < 2 * TILE) {
+        int gj = J * TILE + threadIdx.x - TILE;
+        s_vJ[threadIdx.x - TILE] = gj < n ? v[gj] : 0.0;
+    }
+    const int gi = I * TILE + lane;
+    double t[CPW];
+    const bool diag = (I == J);
+#pragma unroll
+    for (int k = 0; k < CPW; ++k) {
+        const int c = w * CPW + k;
+        const int gj = J * TILE + c;
+        double val = 0.0;
+        if (gj < n && gi < n && gi <= gj) {
+            val = xp[(long long)gj * (gj + 1) / 2 + gi];
+            if (diag && gi == gj) val *= SQRT2;
+        }
+        t[k] = val;
+    }
+    __syncthreads();
+    const double vi = s_vI[lane];
+    double rowacc = 0.0;
+#pragma unroll
+    for (int k = 0; k < CPW; ++k) {
+        const int c = w * CPW + k;
+        rowacc += t[k] * s_vJ[c];
+        // column-sum contribution; on a diagonal tile the diagonal entry itself
+        // must be counted once only (it is in the row sum)
+        double pc = t[k] * vi;
+        if (diag && lane == c) pc = 0.0;
+        s_prod[c][lane] = pc;
+    }
+    s_row[w][lane] = rowacc;
+    __syncthreads();
+    if (threadIdx.x < TILE) {
+        const int r = threadIdx.x;
+        double rs = (s_row[0][r] + s_row[1][r]) + (s_row[2][r] + s_row[3][r]);
+        double cs = 0.0;
+#pragma unroll 8
+        for (int l = 0; l < TILE; ++l) cs += s_prod[r][l];   // column r of the tile
+        if (diag) {
+            const int g = I * TILE + r;
+            if (g < npad) Ppart[(long long)I * npad + g] = rs + cs;
+        } else {
+            const int grow = I * TILE + r;     // rows of block I, slot J
+            if (grow < npad) Ppart[(long long)J * npad + grow] = rs;
+            const int gcol = J * TILE + r;     // rows of block J, slot I
+            if (gcol < npad) Ppart[(long long)I * npad + gcol] = cs;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Lanczos recurrence with full re-orthogonalisation (two classical Gram-Schmidt
+// passes against the whole basis), scalars kept on the device: replaces the
+// BLAS-1 work inside KrylovKit's LanczosIterator (call site eigsolver.jl:802).
+//   dots1      : w = (sum of symv partials)/sqrt2 ; hpart = V[:,0..k]' w
+//   apply_dots : w -= V h ; hpart2 = V' w
+//   apply_norm : w -= V h2 ; nrmpart = |w|^2
+//   finish     : alpha_k = h[k]+h2[k]; beta_k = |w|; V[:,k+1] = w/beta_k, or stop
+// Grid = ceil(n/256) workgroups, one row per thread.
+// ---------------------------------------------------------------------------
+constexpr int MAXK = 160;           // capacity of the Krylov basis (krylovdim+1 <= MAXK)
+
+__device__ __forceinline__ void dots_against_basis(const double* __restrict__ V, int ldv, int kk,
+                                                   int i, bool valid, double wi,
+                                                   double* __restrict__ hpart_wg, double (*s_h)[NWAVE]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int j = 0; j < kk; ++j) {
+        double p = valid ? V[(long long)j * ldv + i] * wi : 0.0;
+        p = wave_sum(p);
+        if (lane == 0) s_h[j][w] = p;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < kk; j += TPB)
+        hpart_wg[j] = (s_h[j][0] + s_h[j][1]) + (s_h[j][2] + s_h[j][3]);
+}
+
+__global__ void __launch_bounds__(TPB)
+k_lz_dots1(const double* __restrict__ Ppart, int nt, int n, int npad,
+           const double* __restrict__ V, int ldv, int k,
+           double* __restrict__ wbuf, double* __restrict__ hpart, const LanczosCtl* __restrict__ ctl) {
+    if (ctl->stop) return;
+    __shared__ double s_h[MAXK][NWAVE];
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    const bool valid = i < n;
+    double wi = 0.0;
+    if (valid) {
+        for (int s = 0; s < nt; ++s) wi += Ppart[(long long)s * npad + i];
+        wi *= INV_SQRT2;
+        wbuf[i] = wi;
+    }
+    dots_against_basis(V, ldv, k + 1, i, valid, wi, hpart + (long long)blockIdx.x * MAXK, s_h);
+}
+
+// mode 0: apply + second dots; mode 1: apply + squared norm
+template <int MODE>
+__global__ void __launch_bounds__(TPB)
+k_lz_apply(double* __restrict__ wbuf, int n, const double* __restrict__ V, int ldv, int k,
+           const double* __restrict__ hpart_in, int nwg, double* __restrict__ hsum_out,
+           double* __restrict__ part_out, const LanczosCtl* __restrict__ ctl) {
+    if (ctl->stop) return;
+    __shared__ double s_hsum[MAXK];
+    __shared__ double s_h[MAXK][NWAVE];
+    __shared__ double s_red[NWAVE];
+    const int kk = k + 1;
+    for (int j = threadIdx.x; j < kk; j += TPB) {
+        double h = 0.0;
+        for (int g = 0; g < nwg; ++g) h += hpart_in[(long long)g * MAXK + j];
+        s_hsum[j] = h;
+        if (blockIdx.x == 0) hsum_out[j] = h;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    const bool valid = i < n;
+    double wi = 0.0;
+    if (valid) {
+        wi = wbuf[i];
+        for (int j = 0; j < kk; ++j) wi -= V[(long long)j * ldv + i] * s_hsum[j];
+        wbuf[i] = wi;
+    }
+    if (MODE == 0) {
+        dots_against_basis(V, ldv, kk, i, valid, wi, part_out + (long long)blockIdx.x * MAXK, s_h);
+    } else {
+        double r = block_sum(valid ? wi * wi : 0.0, s_red);
+        if (threadIdx.x == 0) part_out[blockIdx.x] = r;
+    }
+}
+
+__global__ void __launch_bounds__(TPB)
+k_lz_finish(const double* __restrict__ wbuf, int n, const double* __restrict__ nrmpart, int nwg,
+            double* __restrict__ V, int ldv, int k, const double* __restrict__ h1, const double* __restrict__ h2,
+            double* __restrict__ alphas, double* __restrict__ betas, LanczosCtl* __restrict__ ctl, double tol) {
+    if (ctl->stop) return;
+    double ss = 0.0;
+    for (int g = 0; g < nwg; ++g) ss += nrmpart[g];
+    const double beta = sqrt(ss);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        alphas[k] = h1[k] + h2[k];
+        betas[k] = beta;
+    }
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (beta <= tol) {
+        // every workgroup sees the same beta; the flag is only READ by later
+        // launches (stream order), so a plain store by one thread is enough
+        if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->kstop = k + 1; ctl->stop = 1; }
+        return;
+    }
+    if (i < n) V[(long long)(k + 1) * ldv + i] = wbuf[i] / beta;
+}
+
+// out[:, c] = sum_j V[:, j] U[j, c]  (basis rotation at a thick restart and the
+// final Ritz vectors B*v, KrylovKit eigsolve); optional extra column copy.
+__global__ void __launch_bounds__(TPB)
+k_lz_rotate(const double* __restrict__ V, int ldv, int n, int K, const double* __restrict__ U, int ldu,
+            int ncols, double* __restrict__ out, int ldo, int copy_src, int copy_dst) {
+    extern __shared__ double s_U[];           // K x ncols
+    for (int t = threadIdx.x; t < K * ncols; t += TPB) {
+        int j = t % K, c = t / K;
+        s_U[t] = U[(long long)c * ldu + j];
+    }
+    __syncthreads();
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    for (int c0 = 0; c0 < ncols; c0 += 8) {
+        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int cn = min(8, ncols - c0);
+        for (int j = 0; j < K; ++j) {
+            const double vij = V[(long long)j * ldv + i];
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (c < cn) acc[c] += vij * s_U[(c0 + c) * K + j];
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c < cn) out[(long long)(c0 + c) * ldo + i] = acc[c];
+    }
+    if (copy_src >= 0) out[(long long)copy_dst * ldo + i] = V[(long long)copy_src * ldv + i];
+}
+
+// ---------------------------------------------------------------------------
+// Rank-r reconstruction written directly in packed form:
+//   xp[(i,j)] = s_ij * sum_k lambda_k Z[i,k] Z[j,k],  s = sqrt2 off-diagonal, 1 on it
+// replaces fill! + r dense rank-1 dgemm updates of the full square +
+// psd_square_to_vec (prox_operators.jl:92-106, 115-124, 17-31): one 8*N-byte
+// write instead of (r+1) passes over 8*n^2 bytes.  Same tiling as the mat-vec.
+// ---------------------------------------------------------------------------
+constexpr int RCHUNK = 16;
+__global__ void __launch_bounds__(TPB)
+k_reconstruct_packed(const double* __restrict__ Z, int ldz, const double* __restrict__ lam, int r,
+                     int n, double* __restrict__ xp) {
+    __shared__ double s_ZI[RCHUNK][TILE];      // [k][row]
+    __shared__ double s_ZJ[RCHUNK][TILE];      // [k][col], pre-multiplied by lambda
+    int I, J;
+    tile_coords(blockIdx.x, I, J);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double acc[CPW];
+#pragma unroll
+    for (int k = 0; k < CPW; ++k) acc[k] = 0.0;
+    for (int k0 = 0; k0 < r; k0 += RCHUNK) {
+        const int kc = min(RCHUNK, r - k0);
+        __syncthreads();
+        for (int t = threadIdx.x; t < RCHUNK * TILE; t += TPB) {
+            const int kk = t / TILE, rr = t % TILE;
+            double zi = 0.0, zj = 0.0;
+            if (kk < kc) {
+                const int gi = I * TILE + rr, gj = J * TILE + rr;
+                if (gi < n) zi = Z[(long long)(k0 + kk) * ldz + gi];
+                if (gj < n) zj = Z[(long long)(k0 + kk) * ldz + gj] * lam[k0 + kk];
+            }
+            s_ZI[kk][rr] = zi;
+            s_ZJ[kk][rr] = zj;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < RCHUNK; ++kk) {
+            const double zi = s_ZI[kk][lane];
+#pragma unroll
+            for (int k = 0; k < CPW; ++k) acc[k] += zi * s_ZJ[kk][w * CPW + k];
+        }
+    }
+    const int gi = I * TILE + lane;
+#pragma unroll
+    for (int k = 0; k < CPW; ++k) {
+        const int gj = J * TILE + w * CPW + k;
+        if (gj < n && gi <= gj) {
+            const double s = (gi == gj) ? 1.0 : SQRT2;
+            xp[(long long)gj * (gj + 1) / 2 + gi] = s * acc[k];
+        }
+    }
+}
+
+// packed svec -> dense column-major upper triangle (only for the full-eig
+// fallback, which hands the matrix to rocSOLVER): psd_vec_to_square :1-16
+__global__ void __launch_bounds__(TPB)
+k_unpack_upper(const double* __restrict__ xp, int n, double* __restrict__ A, int lda, double offscale) {
+    int I, J;
+    tile_coords(blockIdx.x, I, J);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int gi = I * TILE + lane;
+#pragma unroll
+    for (int k = 0; k < CPW; ++k) {
+        const int gj = J * TILE + w * CPW + k;
+        if (gj < n && gi <= gj) {
+            double v = xp[(long long)gj * (gj + 1) / 2 + gi];
+            A[(long long)gj * lda + gi] = (gi == gj) ? v : v * offscale;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// PDHG vector kernels (pdhg.jl:532-637, residuals.jl) -- fused passes.
+// Floating-point contraction is OFF for the element-wise expressions below:
+// Julia's broadcasts round every product and sum separately, and the solver's
+// discrete decisions depend on it (at k = 1 the reference gets x = tau*c -
+// tau*(0 + c) = exactly 0; an FMA leaves 1 ulp of tau*c behind, which flips the
+// first 0 <= 0 linesearch acceptance and changes the whole trajectory).  These
+// kernels are HBM-bound, so the extra rounding steps cost nothing.
+// ---------------------------------------------------------------------------
+#pragma clang fp contract(off)
+// x_out = x_in - tau*(Mty + c)                                   pdhg.jl:622
+__global__ void __launch_bounds__(TPB)
+k_primal_update(double* __restrict__ xo, const double* __restrict__ xi, const double* __restrict__ Mty,
+                const double* __restrict__ c, double tau, long long N) {
+    long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+    const long long stride = (long long)gridDim.x * TPB;
+    for (; i < N; i += stride) xo[i] = xi[i] - tau * (Mty[i] + c[i]);
+}
+
+// 1x1 PSD blocks: x = max(0,x); min_eig = x                      prox_operators.jl:43-45
+__global__ void k_clamp_scalars(double* __restrict__ x, const long long* __restrict__ offs, int cnt,
+                                double* __restrict__ mineig) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < cnt) { double v = fmax(0.0, x[offs[t]]); x[offs[t]] = v; mineig[t] = v; }
+}
+
+// second-order cone projection, one workgroup per cone           prox_operators.jl:138-158
+__global__ void __launch_bounds__(TPB)
+k_soc_project(double* __restrict__ x, const long long* __restrict__ soc_off, const int* __restrict__ soc_len) {
+    __shared__ double sm[NWAVE];
+    __shared__ double s_nv;
+    const long long off = soc_off[blockIdx.x];
+    const int len = soc_len[blockIdx.x];
+    double ss = 0.0;
+    for (int i = 1 + threadIdx.x; i < len; i += TPB) { double v = x[off + i]; ss += v * v; }
+    double tot = block_sum(ss, sm);
+    if (threadIdx.x == 0) s_nv = sqrt(tot);
+    __syncthreads();
+    const double nv = s_nv, s = x[off];
+    __syncthreads();
+    if (nv <= -s) {
+        for (int i = threadIdx.x; i < len; i += TPB) x[off + i] = 0.0;
+    } else if (nv <= s) {
+        // inside the cone
+    } else {
+        const double val = 0.5 * (1.0 + s / nv);
+        for (int i = 1 + threadIdx.x; i < len; i += TPB) x[off + i] *= val;
+        if (threadIdx.x == 0) x[off] = val * nv;
+    }
+}
+// soc_gap = |v| - s  per cone (residuals.jl:73-86); out[cone]
+__global__ void __launch_bounds__(TPB)
+k_soc_gap(const double* __restrict__ x, const long long* __restrict__ soc_off, const int* __restrict__ soc_len,
+          double* __restrict__ out) {
+    __shared__ double sm[NWAVE];
+    const long long off = soc_off[blockIdx.x];
+    const int len = soc_len[blockIdx.x];
+    double ss = 0.0;
+    for (int i = 1 + threadIdx.x; i < len; i += TPB) { double v = x[off + i]; ss += v * v; }
+    double tot = block_sum(ss, sm);
+    if (threadIdx.x == 0) out[blockIdx.x] = sqrt(tot) - x[off];
+}
+
+// Mx = M x, M in CSR.  Thread-per-row (short rows) and wave-per-row (long rows)
+// variants; pdhg.jl:634 (the reference does a CSC scatter in pure Julia).
+__global__ void __launch_bounds__(TPB)
+k_spmv_csr_thread(const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val,
+                  const double* __restrict__ x, double* __restrict__ y, int nrows) {
+    int r = blockIdx.x * TPB + threadIdx.x;
+    if (r >= nrows) return;
+    double acc = 0.0;
+    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) acc += val[k] * x[col[k]];
+    y[r] = acc;
+}
+__global__ void __launch_bounds__(TPB)
+k_spmv_csr_wave(const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val,
+                const double* __restrict__ x, double* __restrict__ y, int nrows) {
+    const int lane = threadIdx.x & 63;
+    int r = blockIdx.x * NWAVE + (threadIdx.x >> 6);
+    if (r >= nrows) return;
+    double acc = 0.0;
+    for (int k = rowptr[r] + lane; k < rowptr[r + 1]; k += WAVE) acc += val[k] * x[col[k]];
+    acc = wave_sum(acc);
+    if (lane == 0) y[r] = acc;
+}
+
+// y+ = ybar - bt*box(ybar/bt),  ybar = y + bt((1+theta)Mx - theta Mx_old)
+// pdhg.jl:547-553 + box_projection! (prox_operators.jl:160-170), fused with the
+// partial of |y+ - y_old|^2 (pdhg.jl:561-562; y_old == y at this point).
+__global__ void __launch_bounds__(TPB)
+k_dual_trial(const double* __restrict__ y, const double* __restrict__ Mx, const double* __restrict__ Mx_old,
+             const double* __restrict__ bh, int p, int Q, double bt, double theta,
+             double* __restrict__ yout, double* __restrict__ part) {
+    __shared__ double sm[NWAVE];
+    double ss = 0.0;
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < Q; i += gridDim.x * TPB) {
+        const double yi = y[i];
+        const double ybar = yi + bt * ((1.0 + theta) * Mx[i] - theta * Mx_old[i]);
+        const double proj = (i < p) ? bh[i] : fmin(ybar / bt, bh[i]);
+        const double yn = ybar - bt * proj;
+        yout[i] = yn;
+        const double d = yn - yi;
+        ss += d * d;
+    }
+    double tot = block_sum(ss, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+// no-linesearch variant (dual_step!, pdhg.jl:584-609): ybar = y + sigma(2Mx - Mx_old)
+// is the same kernel with theta = 1, bt = sigma.
+
+// Mty = M' y (M in CSC: one dot per column) fused with |Mty - Mty_old|^2
+// pdhg.jl:556-563.  Thread per column; columns are mostly empty or short.
+__global__ void __launch_bounds__(TPB)
+k_spmv_csc_norm(const int* __restrict__ colptr, const int* __restrict__ row, const double* __restrict__ val,
+                const double* __restrict__ y, double* __restrict__ Mty, const double* __restrict__ Mty_old,
+                long long ncols, double* __restrict__ part) {
+    __shared__ double sm[NWAVE];
+    double ss = 0.0;
+    long long j = (long long)blockIdx.x * TPB + threadIdx.x;
+    const long long stride = (long long)gridDim.x * TPB;
+    for (; j < ncols; j += stride) {
+        double acc = 0.0;
+        const int k0 = colptr[j], k1 = colptr[j + 1];
+        for (int k = k0; k < k1; ++k) acc += val[k] * y[row[k]];
+        Mty[j] = acc;
+        const double d = acc - Mty_old[j];
+        ss += d * d;
+    }
+    double tot = block_sum(ss, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+// plain transposed product (test entry point)
+__global__ void __launch_bounds__(TPB)
+k_spmv_csc(const int* __restrict__ colptr, const int* __restrict__ row, const double* __restrict__ val,
+           const double* __restrict__ y, double* __restrict__ out, long long ncols) {
+    long long j = (long long)blockIdx.x * TPB + threadIdx.x;
+    const long long stride = (long long)gridDim.x * TPB;
+    for (; j < ncols; j += stride) {
+        double acc = 0.0;
+        for (int k = colptr[j]; k < colptr[j + 1]; ++k) acc += val[k] * y[row[k]];
+        out[j] = acc;
+    }
+}
+
+// compute_residual! (x part, residuals.jl:41-48) + prim_obj = c.x (residuals.jl:22)
+// in ONE pass over (x, x_old, Mty, Mty_old, c).  part layout: [3][grid]:
+//   0: max |(x - tau Mty) - (x_old - tau Mty_old)|   1: max |x_old - tau Mty_old|   2: sum c*x
+__global__ void __launch_bounds__(TPB)
+k_residual_x(const double* __restrict__ x, const double* __restrict__ xold, double xold_coef,
+             const double* __restrict__ Mty, const double* __restrict__ Mty_old, const double* __restrict__ c,
+             double tau, long long N, double* __restrict__ part) {
+    __shared__ double sm[NWAVE];
+    double m0 = 0.0, m1 = 0.0, s2 = 0.0;
+    long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+    const long long stride = (long long)gridDim.x * TPB;
+    for (; i < N; i += stride) {
+        const double xi = x[i];
+        const double pold = xold_coef * xold[i] - tau * Mty_old[i];
+        const double pnew = xi - tau * Mty[i];
+        m0 = fmax(m0, fabs(pnew - pold));
+        m1 = fmax(m1, fabs(pold));
+        s2 += c[i] * xi;
+    }
+    double r0 = block_max(m0, sm);
+    double r1 = block_max(m1, sm);
+    double r2 = block_sum(s2, sm);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = r0;
+        part[gridDim.x + blockIdx.x] = r1;
+        part[2 * gridDim.x + blockIdx.x] = r2;
+    }
+}
+// y part of compute_residual! (residuals.jl:51-58) + compute_gap! (residuals.jl:2-35)
+// part layout [6][grid]: 0 max|dPy| 1 max|Py_old| 2 max|Mx-b| (eq) 3 max(Mx-h) (ineq, >=0)
+//                        4 sum b*y_eq 5 sum h*y_in
+__global__ void __launch_bounds__(TPB)
+k_residual_y(const double* __restrict__ y, const double* __restrict__ yold,
+             const double* __restrict__ Mx, const double* __restrict__ Mx_old,
+             const double* __restrict__ bh, int p, int Q, double sigma, double* __restrict__ part) {
+    __shared__ double sm[NWAVE];
+    double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0, s4 = 0.0, s5 = 0.0;
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < Q; i += gridDim.x * TPB) {
+        const double yi = y[i], mx = Mx[i], rhs = bh[i];
+        const double pold = yold[i] - sigma * Mx_old[i];
+        const double pnew = yi - sigma * mx;
+        m0 = fmax(m0, fabs(pnew - pold));
+        m1 = fmax(m1, fabs(pold));
+        if (i < p) { m2 = fmax(m2, fabs(mx - rhs)); s4 += rhs * yi; }
+        else       { m3 = fmax(m3, mx - rhs);       s5 += rhs * yi; }
+    }
+    double r0 = block_max(m0, sm), r1 = block_max(m1, sm), r2 = block_max(m2, sm), r3 = block_max(m3, sm);
+    double r4 = block_sum(s4, sm), r5 = block_sum(s5, sm);
+    if (threadIdx.x == 0) {
+        const int g = gridDim.x, b = blockIdx.x;
+        part[b] = r0; part[g + b] = r1; part[2 * g + b] = r2; part[3 * g + b] = r3;
+        part[4 * g + b] = r4; part[5 * g + b] = r5;
+    }
+}
+
+#pragma clang fp contract(fast)
+// final fixed-order combine of per-workgroup partials: out[q] = sum or max over
+// part[q*stride .. q*stride+cnt).  One workgroup; ismax bit q selects max.
+__global__ void __launch_bounds__(TPB)
+k_combine(const double* __restrict__ part, int stride, int cnt, int nq, unsigned ismax, double* __restrict__ out) {
+    __shared__ double sm[NWAVE];
+    for (int q = 0; q < nq; ++q) {
+        const bool mx = (ismax >> q) & 1u;
+        double a = 0.0;
+        for (int i = threadIdx.x; i < cnt; i += TPB) {
+            const double v = part[(long long)q * stride + i];
+            a = mx ? fmax(a, v) : a + v;
+        }
+        double r = mx ? block_max(a, sm) : block_sum(a, sm);
+        if (threadIdx.x == 0) out[q] = r;
+        __syncthreads();
+    }
+}
+
+// v[offdiag] *= s over all PSD blocks (fix_diag_scaling, pdhg.jl:734-743) -- used
+// on the exit path and when a certificate search snapshots the solution.
+__global__ void __launch_bounds__(TPB)
+k_scale_offdiag(double* __restrict__ xp, int n, double s) {
+    int I, J;
+    tile_coords(blockIdx.x, I, J);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int gi = I * TILE + lane;
+#pragma unroll
+    for (int k = 0; k < CPW; ++k) {
+        const int gj = J * TILE + w * CPW + k;
+        if (gj < n && gi < gj) xp[(long long)gj * (gj + 1) / 2 + gi] *= s;
+    }
+}
+
+}  // namespace dev
+}  // namespace proxsdp

@@ -1,0 +1,660 @@
+// The PDHG loop itself: primal_step!, linesearch!/dual_step!, compute_residual!,
+// compute_gap!, the stop / rank-update / adaptive-step logic and the exit path.
+// Each function cites the reference lines it replaces.
+#pragma once
+#include "solver.hip.hpp"
+
+namespace proxsdp {
+
+constexpr int PSTRIDE = 2048;       // stride of one quantity in the partials buffer
+constexpr int NQ = 16;
+
+// pdhg.jl:634 (Mx = M x)
+inline void Solver::spmv(const double* x, double* y) {
+    if (P.Q == 0) return;
+    if (csr_wave)
+        hipLaunchKernelGGL(dev::k_spmv_csr_wave, dim3(ceil_div(P.Q, dev::NWAVE)), dim3(dev::TPB), 0, stream,
+                           csr_ptr.p, csr_col.p, csr_val.p, x, y, (int)P.Q);
+    else
+        hipLaunchKernelGGL(dev::k_spmv_csr_thread, dim3(ceil_div(P.Q, dev::TPB)), dim3(dev::TPB), 0, stream,
+                           csr_ptr.p, csr_col.p, csr_val.p, x, y, (int)P.Q);
+}
+
+// psd_projection! (prox_operators.jl:33-66), one block
+inline void Solver::project_block(int idx, double* x) {
+    EigWork& W = eig[idx];
+    double* xp = x + P.blocks[idx].off;
+    current_rank[idx] = 0;
+    const bool krylov = !opt.full_eig_decomp && target_rank[idx] <= opt.max_target_rank_krylov_eigs &&
+                        W.n > opt.min_size_krylov_eigs && (iter % opt.full_eig_freq) > opt.full_eig_len;
+    if (!krylov) { full_eig_project(idx, xp); return; }
+    const int nev = (int)target_rank[idx];
+    lanczos(W, xp, nev);
+    if (!W.converged) {                       // prox_operators.jl:55-57
+        st.krylov_fallbacks++;
+        full_eig_project(idx, xp);
+        return;
+    }
+    double mn = W.vals[0];
+    for (double v : W.vals) mn = std::min(mn, v);
+    min_eig[idx] = mn;                        // prox_operators.jl:95 / :74
+    int first = 0, npos = 0;
+    if (opt.eigsolver == 1) {                 // ascending arc.d, all nev used (prox_operators.jl:78-85)
+        for (int i = 0; i < nev; ++i) if (W.vals[i] > 0.0) ++npos;
+        first = nev - npos;
+    } else {                                  // descending, min(target_rank, converged) used (:99-106)
+        const int k = std::min(nev, W.converged_eigs);
+        for (int i = 0; i < k; ++i) if (W.vals[i] > 0.0) ++npos;
+    }
+    current_rank[idx] += npos;
+    if (npos > 0) W.lam.upload(W.vals.data() + first, npos, stream);
+    launch_reconstruct(W, W.Z.p + (size_t)first * W.npad, W.npad, W.lam.p, npos, xp);
+    recon_r_iter += npos;
+}
+
+inline void Solver::psd_projection(double* x) {
+    std::fill(min_eig.begin(), min_eig.end(), 0.0);
+    if (!one_blocks.empty()) {
+        hipLaunchKernelGGL(dev::k_clamp_scalars, dim3(ceil_div(one_blocks.size(), 256)), dim3(256), 0, stream,
+                           x, one_off.p, (int)one_blocks.size(), one_min.p);
+        for (int idx : one_blocks) current_rank[idx] = 0;
+    }
+    for (size_t idx = 0; idx < P.blocks.size(); ++idx)
+        if (P.blocks[idx].n > 1) project_block((int)idx, x);
+}
+
+// primal_step! (pdhg.jl:611-637)
+inline void Solver::primal_step_dev() {
+    const double* xi = xbuf[xc].p;
+    double* xo = xbuf[1 - xc].p;
+    hipLaunchKernelGGL(dev::k_primal_update, dim3(grid_for(P.n)), dim3(dev::TPB), 0, stream,
+                       xo, xi, Mtybuf[mtyc].p, c_d.p, primal_step, (long long)P.n);
+    if (!P.blocks.empty()) {
+        double t0 = now_s();
+        psd_projection(xo);
+        st.t_psd += now_s() - t0;
+    }
+    if (!P.socs.empty())
+        hipLaunchKernelGGL(dev::k_soc_project, dim3((int)P.socs.size()), dim3(dev::TPB), 0, stream,
+                           xo, soc_off.p, soc_len.p);
+    spmv(xo, Mxbuf[1 - mxc].p);
+}
+
+// linesearch! (pdhg.jl:532-582)
+inline int Solver::linesearch() {
+    primal_step = primal_step * std::sqrt(1.0 + theta);
+    const int gq = std::min(PSTRIDE, grid_for(std::max<int64_t>(P.Q, 1)));
+    const int gx = std::min(PSTRIDE, grid_for(P.n));
+    int trials = 0;
+    for (int i = 0; i < opt.max_linsearch_steps; ++i) {
+        ++trials;
+        theta = primal_step / primal_step_old;
+        const double bt = beta * primal_step;
+        hipLaunchKernelGGL(dev::k_dual_trial, dim3(gq), dim3(dev::TPB), 0, stream,
+                           ybuf[yc].p, Mxbuf[1 - mxc].p, Mxbuf[mxc].p, bh_d.p, (int)P.p, (int)P.Q, bt, theta,
+                           ybuf[1 - yc].p, part.p);
+        hipLaunchKernelGGL(dev::k_spmv_csc_norm, dim3(gx), dim3(dev::TPB), 0, stream,
+                           csc_ptr.p, csc_row.p, csc_val.p, ybuf[1 - yc].p, Mtybuf[1 - mtyc].p, Mtybuf[mtyc].p,
+                           (long long)P.n, part.p + PSTRIDE);
+        hipLaunchKernelGGL(dev::k_combine, dim3(1), dim3(dev::TPB), 0, stream,
+                           part.p, PSTRIDE, PSTRIDE, 2, 0u, scal.p);
+        scal.download(hscal.data(), 2, stream);
+        PX_HIP(hipStreamSynchronize(stream));
+        const double y_norm = std::sqrt(hscal[0]), Mty_norm = std::sqrt(hscal[1]);
+        if (debug && iter <= 5 && trials <= 6)
+            std::fprintf(stderr, "[dbg] it %lld trial %d tau %.6e theta %.6e y_norm %.6e Mty_norm %.6e\n",
+                         iter, trials, primal_step, theta, y_norm, Mty_norm);
+        if (std::sqrt(beta) * primal_step * Mty_norm <= opt.delta * y_norm) break;
+        primal_step *= opt.linsearch_decay;
+    }
+    primal_step_old = primal_step;
+    dual_step = beta * primal_step;
+    st.linesearch_trials += trials;
+    return trials;
+}
+
+// dual_step! (pdhg.jl:584-609): the same kernels with theta = 1, bt = dual_step
+inline void Solver::dual_step_plain() {
+    const int gq = std::min(PSTRIDE, grid_for(std::max<int64_t>(P.Q, 1)));
+    const int gx = std::min(PSTRIDE, grid_for(P.n));
+    hipLaunchKernelGGL(dev::k_dual_trial, dim3(gq), dim3(dev::TPB), 0, stream,
+                       ybuf[yc].p, Mxbuf[1 - mxc].p, Mxbuf[mxc].p, bh_d.p, (int)P.p, (int)P.Q, dual_step, 1.0,
+                       ybuf[1 - yc].p, part.p);
+    hipLaunchKernelGGL(dev::k_spmv_csc_norm, dim3(gx), dim3(dev::TPB), 0, stream,
+                       csc_ptr.p, csc_row.p, csc_val.p, ybuf[1 - yc].p, Mtybuf[1 - mtyc].p, Mtybuf[mtyc].p,
+                       (long long)P.n, part.p + PSTRIDE);
+    primal_step_old = primal_step;
+    st.linesearch_trials += 1;
+}
+
+// compute_residual! + compute_gap! (residuals.jl:2-71), then the *_old rotation
+// (:65-68) as index flips instead of four vector copies
+inline void Solver::residual_and_gap() {
+    const int gq = std::min(PSTRIDE, grid_for(std::max<int64_t>(P.Q, 1)));
+    const int gx = std::min(PSTRIDE, grid_for(P.n));
+    const double xold_coef = (iter == 1 && opt.advanced_initialization) ? 0.0 : 1.0;   // x_old = 0 at k = 1
+    hipLaunchKernelGGL(dev::k_residual_x, dim3(gx), dim3(dev::TPB), 0, stream,
+                       xbuf[1 - xc].p, xbuf[xc].p, xold_coef, Mtybuf[1 - mtyc].p, Mtybuf[mtyc].p, c_d.p,
+                       primal_step, (long long)P.n, part.p + 2 * PSTRIDE);
+    // k_residual_x writes 3 quantities with stride gridDim; re-stride into the common layout
+    // by launching with exactly PSTRIDE-strided output: handled by passing gridDim == gx and
+    // combining with stride gx (see k_combine call below).
+    hipLaunchKernelGGL(dev::k_residual_y, dim3(gq), dim3(dev::TPB), 0, stream,
+                       ybuf[1 - yc].p, ybuf[yc].p, Mxbuf[1 - mxc].p, Mxbuf[mxc].p, bh_d.p, (int)P.p, (int)P.Q,
+                       dual_step, part.p + 5 * PSTRIDE);
+    hipLaunchKernelGGL(dev::k_combine, dim3(1), dim3(dev::TPB), 0, stream,
+                       part.p + 2 * PSTRIDE, gx, gx, 3, 0x3u, scal.p + 2);
+    hipLaunchKernelGGL(dev::k_combine, dim3(1), dim3(dev::TPB), 0, stream,
+                       part.p + 5 * PSTRIDE, gq, gq, 6, 0xFu, scal.p + 5);
+    PX_HIP(hipMemcpyAsync(hscal.data() + 2, scal.p + 2, 9 * sizeof(double), hipMemcpyDeviceToHost, stream));
+    PX_HIP(hipStreamSynchronize(stream));
+    const double* s = hscal.data() + 2;
+    if (debug && iter <= 5)
+        std::fprintf(stderr, "[dbg] it %lld res: %.6e %.6e cx %.6e | %.6e %.6e eq %.6e in %.6e by %.6e hy %.6e\n",
+                     iter, s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], s[8]);
+    const double pres = std::sqrt((double)P.n) * s[0] / std::max({s[1], P.norm_b, P.norm_h, 1.0});
+    const double dres = std::sqrt((double)P.Q) * s[3] / std::max({s[4], P.norm_c, 1.0});
+    h_pres.at(iter) = pres;
+    h_dres.at(iter) = dres;
+    h_comb.at(iter) = std::max(pres, dres);
+    if (P.p > 0) equa_feasibility = s[5] / (1.0 + P.norm_b);
+    if (P.m > 0) ineq_feasibility = s[6] / (1.0 + P.norm_h);
+    h_feas.at(iter) = std::max(equa_feasibility, ineq_feasibility);
+    const double po = s[2];
+    double d_o = 0.0;
+    if (P.p > 0) d_o -= s[7];
+    if (P.m > 0) d_o -= s[8];
+    h_pobj.at(iter) = po;
+    h_dobj.at(iter) = d_o;
+    h_gap.at(iter) = std::fabs(po - d_o) / (1.0 + std::fabs(po) + std::fabs(d_o));
+    xc = 1 - xc; mtyc = 1 - mtyc; yc = 1 - yc; mxc = 1 - mxc;
+}
+
+// convergedrank (residuals.jl:88-101)
+inline bool Solver::convergedrank() const {
+    for (size_t idx = 0; idx < P.blocks.size(); ++idx) {
+        if (!(P.blocks[idx].n < opt.min_size_krylov_eigs ||
+              target_rank[idx] > opt.max_target_rank_krylov_eigs || min_eig[idx] < opt.tol_psd))
+            return false;
+    }
+    return true;
+}
+
+// soc_convergence (residuals.jl:73-86)
+inline bool Solver::soc_convergence() {
+    if (P.socs.empty()) return true;
+    hipLaunchKernelGGL(dev::k_soc_gap, dim3((int)P.socs.size()), dim3(dev::TPB), 0, stream,
+                       xbuf[xc].p, soc_off.p, soc_len.p, soc_gap_d.p);
+    std::vector<double> g(P.socs.size());
+    soc_gap_d.download(g.data(), g.size(), stream);
+    PX_HIP(hipStreamSynchronize(stream));
+    for (double v : g) if (v >= opt.tol_soc) return false;
+    return true;
+}
+
+// certificate_parameters (pdhg.jl:670-676)
+inline void Solver::certificate_parameters() {
+    certificate_search_min_iter = iter + 2 * opt.convergence_window + iter / 5 + 1000;
+    certificate_search = true;
+    time_limit *= 1.1;
+    max_iter_local = max_iter_local + max_iter_local / 10;
+}
+
+// the rank-update rule shared by pdhg.jl:270-280 and :294-301
+inline void Solver::bump_rank(int idx) {
+    if (current_rank[idx] + opt.rank_slack >= target_rank[idx]) {
+        if (min_eig[idx] > opt.tol_psd) {
+            long long side = P.blocks[idx].n;
+            if (opt.rank_increment == 0)
+                target_rank[idx] = std::min<long long>(opt.rank_increment_factor * target_rank[idx], side);
+            else
+                target_rank[idx] = std::min<long long>(opt.rank_increment_factor + target_rank[idx], side);
+        }
+    }
+}
+
+// get_duals + dual_feas + cone_feas (pdhg.jl:678-732) on host vectors; the
+// dual-cone eigenvalues come from the device (rocSOLVER, values only).
+inline double Solver::dual_feas_host(const std::vector<double>& y, const std::vector<double>& cvec,
+                                     std::vector<double>* dual_eq, std::vector<double>* dual_in,
+                                     std::vector<double>* dual_cone_out) {
+    std::vector<double> dc(cvec);
+    for (int64_t k = 0; k < P.n; ++k) {
+        double acc = 0.0;
+        for (int64_t q = P.colptr[k]; q < P.colptr[k + 1]; ++q) acc += P.val_orig[q] * y[P.rowidx[q]];
+        dc[k] += acc;
+        if (P.offdiag[k]) dc[k] /= 2.0;                       // fix_diag_scaling(dual_cone, cones, 2.0)
+    }
+    double ineq_viol = 0.0;
+    if (P.m > 0) {
+        double mn = y[P.p];
+        for (int64_t i = 0; i < P.m; ++i) mn = std::min(mn, y[P.p + i]);
+        ineq_viol = -std::min(0.0, mn);
+    }
+    double sdp_viol = 0.0;
+    for (size_t idx = 0; idx < P.blocks.size(); ++idx) {
+        const BlockInfo& B = P.blocks[idx];
+        if (B.n == 1) {
+            sdp_viol = std::max(sdp_viol, -std::min(0.0, dc[B.off]));
+        } else {
+            EigWork& W = eig[idx];
+            // psd_vec_to_square(v, a, cones, sqrt(2)): off-diagonals / sqrt(2)
+            DevBuf<double> tmp(B.N);
+            tmp.upload(dc.data() + B.off, B.N, stream);
+            std::vector<double> D;
+            full_eig_values(W, tmp.p, dev::INV_SQRT2, false, D);
+            double mn = D[0];
+            for (double v : D) mn = std::min(mn, v);
+            sdp_viol = std::max(sdp_viol, -std::min(0.0, mn));
+        }
+    }
+    for (const SocInfo& S : P.socs) {
+        double ss = 0.0;
+        for (int i = 1; i < S.len; ++i) ss += dc[S.off + i] * dc[S.off + i];
+        sdp_viol = std::max(sdp_viol, -std::min(0.0, dc[S.off] - std::sqrt(ss)));
+    }
+    double zero_viol = 0.0;
+    for (int64_t k = P.conelen; k < P.n; ++k) zero_viol = std::max(zero_viol, std::fabs(dc[k]));
+    if (dual_eq) dual_eq->assign(y.begin(), y.begin() + P.p);
+    if (dual_in) dual_in->assign(y.begin() + P.p, y.end());
+    if (dual_cone_out) *dual_cone_out = std::move(dc);
+    return std::max({sdp_viol, ineq_viol, zero_viol});
+}
+
+// cache_solution (pdhg.jl:745-787).  NB the reference rescales pair.x IN PLACE
+// (fix_diag_scaling on pair.x, :749); when a certificate search continues after
+// this snapshot the iterate stays rescaled -- reproduced here on the device.
+inline void Solver::cache_solution(const std::vector<double>& cvec) {
+    double t0 = now_s();
+    const double inv = 1.0 / std::sqrt(2.0);
+    for (size_t idx = 0; idx < P.blocks.size(); ++idx) {
+        const BlockInfo& B = P.blocks[idx];
+        if (B.n < 2) continue;
+        const int nt = ceil_div(B.n, dev::TILE);
+        hipLaunchKernelGGL(dev::k_scale_offdiag, dim3(nt * (nt + 1) / 2), dim3(dev::TPB), 0, stream,
+                           xbuf[xc].p + B.off, B.n, inv);
+    }
+    std::vector<double> x(P.n), y(P.Q);
+    xbuf[xc].download(x.data(), P.n, stream);
+    ybuf[yc].download(y.data(), P.Q, stream);
+    PX_HIP(hipStreamSynchronize(stream));
+    std::vector<double> slack(P.Q, 0.0);
+    for (int64_t k = 0; k < P.n; ++k) {
+        const double xk = x[k];
+        for (int64_t q = P.colptr[k]; q < P.colptr[k + 1]; ++q) slack[P.rowidx[q]] += P.val_orig[q] * xk;
+    }
+    std::vector<double> deq, din, dcone;
+    const double dfeas = dual_feas_host(y, cvec, &deq, &din, &dcone);
+    res.status = stop_reason;
+    std::snprintf(res.status_string, sizeof(res.status_string), "%s", stop_reason_string.c_str());
+    if (res.primal)    for (int64_t i = 0; i < P.n; ++i) res.primal[i] = x[P.inv[i]];
+    if (res.dual_cone) for (int64_t i = 0; i < P.n; ++i) res.dual_cone[i] = dcone[P.inv[i]];
+    if (res.dual_eq)   for (int64_t i = 0; i < P.p; ++i) res.dual_eq[i] = deq[i];
+    if (res.dual_in)   for (int64_t i = 0; i < P.m; ++i) res.dual_in[i] = din[i];
+    if (res.slack_eq)  for (int64_t i = 0; i < P.p; ++i) res.slack_eq[i] = slack[i] - P.b[i];
+    if (res.slack_in)  for (int64_t i = 0; i < P.m; ++i) res.slack_in[i] = slack[P.p + i] - P.h[i];
+    res.primal_residual = equa_feasibility;
+    res.dual_residual = ineq_feasibility;
+    res.objval = h_pobj.at(iter);
+    res.dual_objval = h_dobj.at(iter);
+    res.gap = h_gap.at(iter);
+    res.iter = iter;
+    long long fr = 0;
+    for (long long r : current_rank) fr += r;
+    res.final_rank = (int32_t)fr;
+    res.primal_feasible_user_tol = h_feas.at(iter) <= opt.tol_feasibility;
+    res.dual_feasible_user_tol = dfeas <= opt.tol_feasibility_dual;
+    res.dual_feasibility = dfeas;
+    res.certificate_found = certificate_found;
+    res.result_count = 1;
+    res.time = now_s() - time0;
+    have_snapshot = true;
+    st.exit_time += now_s() - t0;
+}
+
+// ---- hooks for the kernel-level test entry points
+inline void Solver::test_project(int idx, double* xp, int tr) {
+    target_rank.assign(1, tr); current_rank.assign(1, 0); min_eig.assign(1, 0.0);
+    iter = 1;
+    project_block(idx, xp - P.blocks[idx].off);
+}
+inline void Solver::test_spmv(bool transpose, const double* in, double* out) {
+    setup_device();
+    std::vector<int> rp(P.Q + 1), cp(P.n + 1);
+    for (int64_t i = 0; i <= P.Q; ++i) rp[i] = (int)P.rowptr[i];
+    for (int64_t i = 0; i <= P.n; ++i) cp[i] = (int)P.colptr[i];
+    const int64_t nz = std::max<int64_t>(P.nnz, 1);
+    csr_ptr.alloc(P.Q + 1); csr_col.alloc(nz); csr_val.alloc(nz);
+    csc_ptr.alloc(P.n + 1); csc_row.alloc(nz); csc_val.alloc(nz);
+    csr_ptr.upload(rp.data(), P.Q + 1, stream); csc_ptr.upload(cp.data(), P.n + 1, stream);
+    csr_col.upload(P.colidx.data(), P.nnz, stream); csr_val.upload(P.rval.data(), P.nnz, stream);
+    csc_row.upload(P.rowidx.data(), P.nnz, stream); csc_val.upload(P.val.data(), P.nnz, stream);
+    csr_wave = P.Q > 0 && (double)P.nnz / (double)P.Q > 8.0;
+    DevBuf<double> xin(std::max<int64_t>(transpose ? P.Q : P.n, 1)), xout(std::max<int64_t>(transpose ? P.n : P.Q, 1));
+    xin.upload(in, transpose ? P.Q : P.n, stream);
+    if (transpose)
+        hipLaunchKernelGGL(dev::k_spmv_csc, dim3(grid_for(P.n)), dim3(dev::TPB), 0, stream,
+                           csc_ptr.p, csc_row.p, csc_val.p, xin.p, xout.p, (long long)P.n);
+    else
+        spmv(xin.p, xout.p);
+    xout.download(out, transpose ? P.n : P.Q, stream);
+    PX_HIP(hipStreamSynchronize(stream));
+}
+
+// chambolle_pock (pdhg.jl:1-530)
+inline void Solver::run() {
+    const double t_init0 = now_s();
+    if (opt.equilibration || opt.equilibration_force)
+        throw std::domain_error("equilibration is not implemented (off by default in the reference)");
+    if (!opt.approx_norm) throw std::domain_error("approx_norm=false (svds) is not implemented");
+    if (P.n <= 0) throw std::invalid_argument("problem has no variables");
+    if (opt.convergence_window <= 0) throw std::invalid_argument("convergence_window must be positive");
+    theta = opt.initial_theta; adapt_level = opt.initial_adapt_level; beta = opt.initial_beta;
+    const int window = opt.convergence_window;
+    const size_t nb = P.blocks.size();
+    target_rank.assign(nb, 2); current_rank.assign(nb, 2); min_eig.assign(nb, 0.0);
+    time_limit = opt.time_limit;
+    if (opt.max_iter <= 0) max_iter_local = (nb > 0 || !P.socs.empty()) ? opt.max_iter_conic : opt.max_iter_lp;
+    else max_iter_local = opt.max_iter;
+    int ada_count = 0;
+    h_gap.init(2 * window); h_pobj.init(2 * window); h_dobj.init(2 * window); h_feas.init(2 * window);
+    h_pres.init(2 * window); h_dres.init(2 * window); h_comb.init(2 * window);
+    b_host = P.b; h_host = P.h; c_host = P.c;
+
+    // ---- device state ("Init", pdhg.jl:54-142)
+    setup_device();
+    for (int k = 0; k < 2; ++k) {
+        xbuf[k].alloc(P.n); Mtybuf[k].alloc(P.n);
+        ybuf[k].alloc(std::max<int64_t>(P.Q, 1)); Mxbuf[k].alloc(std::max<int64_t>(P.Q, 1));
+        xbuf[k].zero(stream); Mtybuf[k].zero(stream); ybuf[k].zero(stream); Mxbuf[k].zero(stream);
+    }
+    c_d.alloc(P.n); c_d.upload(P.c.data(), P.n, stream);
+    bh_d.alloc(std::max<int64_t>(P.Q, 1));
+    {
+        std::vector<double> bh(P.Q);
+        std::copy(P.b.begin(), P.b.end(), bh.begin());
+        std::copy(P.h.begin(), P.h.end(), bh.begin() + P.p);
+        bh_d.upload(bh.data(), P.Q, stream);
+        PX_HIP(hipStreamSynchronize(stream));
+    }
+    part.alloc((size_t)NQ * PSTRIDE); part.zero(stream);
+    scal.alloc(NQ); scal.zero(stream);
+    hscal.assign(NQ, 0.0);
+    {   // sparse operator, both orientations, int32 indices
+        std::vector<int> rp(P.Q + 1), cp(P.n + 1);
+        for (int64_t i = 0; i <= P.Q; ++i) rp[i] = (int)P.rowptr[i];
+        for (int64_t i = 0; i <= P.n; ++i) cp[i] = (int)P.colptr[i];
+        csr_ptr.alloc(P.Q + 1); csr_col.alloc(std::max<int64_t>(P.nnz, 1)); csr_val.alloc(std::max<int64_t>(P.nnz, 1));
+        csc_ptr.alloc(P.n + 1); csc_row.alloc(std::max<int64_t>(P.nnz, 1)); csc_val.alloc(std::max<int64_t>(P.nnz, 1));
+        csr_ptr.upload(rp.data(), P.Q + 1, stream); csc_ptr.upload(cp.data(), P.n + 1, stream);
+        csr_col.upload(P.colidx.data(), P.nnz, stream); csr_val.upload(P.rval.data(), P.nnz, stream);
+        csc_row.upload(P.rowidx.data(), P.nnz, stream); csc_val.upload(P.val.data(), P.nnz, stream);
+        PX_HIP(hipStreamSynchronize(stream));
+        csr_wave = P.Q > 0 && (double)P.nnz / (double)P.Q > 8.0;
+    }
+    eig.resize(nb);
+    {
+        std::vector<long long> offs;
+        const double* ur = user_resid;
+        for (size_t idx = 0; idx < nb; ++idx) {
+            const BlockInfo& B = P.blocks[idx];
+            if (B.n == 1) { one_blocks.push_back((int)idx); offs.push_back(B.off); if (ur) ur += 1; continue; }
+            EigWork& W = eig[idx];
+            const int max_nev = std::min<int>(std::max<int>(opt.max_target_rank_krylov_eigs, 2), B.n);
+            alloc_eigwork(W, B.n, max_nev);
+            W.resid_host.resize(W.npad, 0.0);
+            if (ur) { std::copy(ur, ur + B.n, W.resid_host.begin()); ur += B.n; }
+            else start_vector(B.n, (uint64_t)opt.eigsolver_resid_seed,
+                              opt.eigsolver == 1 ? opt.arpack_resid_init : opt.krylovkit_resid_init,
+                              W.resid_host.data());
+            double nr = norm2(W.resid_host.data(), B.n);        // KrylovKit: v = x0 / norm(x0)
+            if (!(nr > 0.0)) throw std::invalid_argument("Lanczos start vector has zero norm");
+            for (int i = 0; i < B.n; ++i) W.resid_host[i] /= nr;
+            W.resid.upload(W.resid_host.data(), W.npad, stream);
+        }
+        if (!offs.empty()) {
+            one_off.alloc(offs.size()); one_min.alloc(offs.size());
+            one_off.upload(offs.data(), offs.size(), stream);
+            PX_HIP(hipStreamSynchronize(stream));
+        }
+    }
+    if (!P.socs.empty()) {
+        std::vector<long long> so; std::vector<int> sl;
+        for (const SocInfo& S : P.socs) { so.push_back(S.off); sl.push_back(S.len); }
+        soc_off.alloc(so.size()); soc_len.alloc(sl.size()); soc_gap_d.alloc(so.size());
+        soc_off.upload(so.data(), so.size(), stream); soc_len.upload(sl.data(), sl.size(), stream);
+        PX_HIP(hipStreamSynchronize(stream));
+    }
+    double spectral_norm = P.frob;                       // LinearAlgebra.norm(M), pdhg.jl:121
+    if (spectral_norm < 1e-10) spectral_norm = 1.0;
+    primal_step = 1.0 / spectral_norm;
+    primal_step_old = primal_step;
+    dual_step = primal_step;
+    if (opt.advanced_initialization) {                   // x = tau*c (pdhg.jl:138-142)
+        std::vector<double> x0(P.n);
+        for (int64_t i = 0; i < P.n; ++i) x0[i] = primal_step * P.c[i];
+        xbuf[xc].upload(x0.data(), P.n, stream);
+        PX_HIP(hipStreamSynchronize(stream));
+    }
+    PX_HIP(hipStreamSynchronize(stream));
+    st.init_time = now_s() - t_init0;
+
+    auto snapshot = [&]() { cache_solution(P.c_orig); };
+    auto cert_infeas = [&]() {                           // certificate_infeasibility (pdhg.jl:655-668)
+        std::fill(c_host.begin(), c_host.end(), 0.0);
+        c_d.zero(stream);
+        certificate_parameters();
+    };
+    auto cert_dual_infeas = [&]() {                      // certificate_dual_infeasibility (pdhg.jl:639-653)
+        std::fill(b_host.begin(), b_host.end(), 0.0);
+        std::fill(h_host.begin(), h_host.end(), 0.0);
+        bh_d.zero(stream);
+        certificate_parameters();
+    };
+    int n_snap = 0;
+
+    // ---- "CP loop" (pdhg.jl:145-484)
+    const double t_loop0 = now_s();
+    const long long kmax = 2 * max_iter_local;
+    for (long long k = 1; k <= kmax; ++k) {
+        iter = k;
+        lz_matvec_iter = 0; recon_r_iter = 0;
+        primal_step_dev();
+        if (opt.line_search_flag) last_trials = linesearch();
+        else { dual_step_plain(); last_trials = 1; }
+        residual_and_gap();
+        {   // algorithmic bytes of this iteration
+            const double t = (double)last_trials;
+            double bb = 8.0 * (double)P.n * (11.0 + 3.0 * t) + 12.0 * (double)P.nnz * (1.0 + t) +
+                        8.0 * (double)P.Q * (8.0 + 6.0 * t);
+            for (size_t idx = 0; idx < nb; ++idx) {
+                if (P.blocks[idx].n < 2) continue;
+                // per-block L and r are accumulated over blocks in lz_matvec_iter / recon_r_iter;
+                // single-block instances (all BASELINE configs) make this exact
+                (void)idx;
+            }
+            if (nb > 0) {
+                const BlockInfo& B0 = P.blocks[0];
+                bb += (8.0 * (double)B0.N + 16.0 * (double)B0.n) * (double)lz_matvec_iter +
+                      8.0 * (double)B0.n * (double)recon_r_iter;
+            }
+            st.algorithmic_bytes += bb;
+        }
+        if (res.trace && res.trace_rows < opt.trace_capacity) {
+            double* row = res.trace + (size_t)res.trace_rows * PROXSDP_TRACE_COLS;
+            row[0] = (double)k; row[1] = h_pobj.at(k); row[2] = h_dobj.at(k); row[3] = h_gap.at(k);
+            row[4] = h_feas.at(k); row[5] = h_pres.at(k); row[6] = h_dres.at(k); row[7] = primal_step;
+            row[8] = beta; row[9] = theta; row[10] = nb ? (double)target_rank[0] : 0.0; row[11] = (double)last_trials;
+            row[12] = now_s() - t_loop0; row[13] = (double)lz_matvec_iter;
+            res.trace_rows++;
+        }
+        if (opt.check_dual_feas && k % opt.check_dual_feas_freq == 0) {
+            std::vector<double> y(P.Q);
+            ybuf[yc].download(y.data(), P.Q, stream);
+            PX_HIP(hipStreamSynchronize(stream));
+            std::vector<double> cc(P.c_orig);
+            if (stop_reason == 6) std::fill(cc.begin(), cc.end(), 0.0);
+            dual_feasibility = dual_feas_host(y, cc, nullptr, nullptr, nullptr);
+        }
+        if (opt.log_verbose && opt.log_freq > 0 && k % opt.log_freq == 0)
+            std::printf("|%9lld| %+.4e %+.4e %.2e %.2e %.2e %.2e %4lld %8.2f\n", k, h_pobj.at(k), h_dobj.at(k),
+                        h_gap.at(k), h_feas.at(k), h_pres.at(k), h_dres.at(k), nb ? target_rank[0] : 0,
+                        now_s() - time0);
+        if (iter < certificate_search_min_iter) continue;
+
+        if (opt.certificate_search && certificate_search) {          // pdhg.jl:184-244
+            if (stop_reason == 6) {
+                if (h_dobj.at(k) > opt.certificate_obj_tol) {
+                    std::vector<double> y(P.Q);
+                    ybuf[yc].download(y.data(), P.Q, stream);
+                    PX_HIP(hipStreamSynchronize(stream));
+                    std::vector<double> zc(P.n, 0.0);
+                    dual_feasibility = dual_feas_host(y, zc, nullptr, nullptr, nullptr);
+                    if (dual_feasibility < opt.tol_feasibility_dual) {
+                        certificate_found = true;
+                        stop_reason_string += " [Dual ray found]";
+                        break;
+                    }
+                }
+            } else {
+                if (h_pobj.at(k) < -opt.certificate_obj_tol && h_feas.at(iter) < opt.tol_feasibility) {
+                    certificate_found = true;
+                    stop_reason_string += " [Primal ray found]";
+                    break;
+                }
+            }
+            if ((h_pobj.at(k) < -opt.certificate_fail_tol && h_dobj.at(k) < -opt.certificate_fail_tol &&
+                 h_feas.at(iter) < -opt.certificate_fail_tol) || std::isnan(h_comb.at(k))) {
+                stop_reason_string += " [Failed to find certificate]";
+                break;
+            }
+        }
+
+        // ---- convergence / rank update / divergence / adaptive steps (pdhg.jl:246-332)
+        rank_update += 1;
+        if (h_gap.at(iter) <= opt.tol_gap && h_feas.at(iter) <= opt.tol_feasibility &&
+            (!opt.check_dual_feas || dual_feasibility < opt.tol_feasibility_dual)) {
+            if (convergedrank() && soc_convergence() && iter > opt.min_iter) {
+                if (!certificate_search) {
+                    stop_reason = 1;
+                    stop_reason_string = "Optimal solution found";
+                } else {
+                    stop_reason_string += " [Failed to find certificate - type 2]";
+                }
+                break;
+            } else if (rank_update > window) {
+                update_cont += 1;
+                if (update_cont > 0) {
+                    for (size_t idx = 0; idx < nb; ++idx) bump_rank((int)idx);
+                    rank_update = 0; update_cont = 0;
+                }
+            }
+        } else if (k > window && h_comb.at(k - window) < h_comb.at(k) && rank_update > window) {
+            update_cont += 1;
+            if (update_cont > opt.divergence_min_update) {
+                for (size_t idx = 0; idx < nb; ++idx) {
+                    if (target_rank[idx] < P.blocks[idx].n) { rank_update = 0; update_cont = 0; }
+                    bump_rank((int)idx);
+                }
+            }
+        } else if (h_pres.at(k) > opt.tol_primal && h_dres.at(k) < opt.tol_dual && k > window) {
+            if (++ada_count > opt.adapt_window) {
+                ada_count = 0;
+                if (opt.line_search_flag) { beta *= (1.0 - adapt_level); primal_step /= std::sqrt(1.0 - adapt_level); }
+                else { primal_step /= (1.0 - adapt_level); dual_step *= (1.0 - adapt_level); }
+                adapt_level *= opt.adapt_decay;
+            }
+        } else if (h_pres.at(k) < opt.tol_primal && h_dres.at(k) > opt.tol_dual && k > window) {
+            if (++ada_count > opt.adapt_window) {
+                ada_count = 0;
+                if (opt.line_search_flag) { beta /= (1.0 - adapt_level); primal_step *= std::sqrt(1.0 - adapt_level); }
+                else { primal_step *= (1.0 - adapt_level); dual_step /= (1.0 - adapt_level); }
+                adapt_level *= opt.adapt_decay;
+            }
+        }
+
+        // ---- iteration / time limits (pdhg.jl:334-382)
+        if (iter >= max_iter_local || now_s() - time0 >= time_limit) {
+            if (iter > opt.min_iter_time_infeas && h_gap.max_abs_diff() < opt.infeas_stable_gap_tol &&
+                h_gap.at(k) > opt.infeas_limit_gap_tol) {
+                if (h_feas.at(iter) <= opt.tol_feasibility / 100) {
+                    stop_reason = 5;
+                    stop_reason_string = "Problem declared unbounded due to lack of improvement";
+                    if (opt.certificate_search && !certificate_search) { cert_dual_infeas(); snapshot(); ++n_snap; }
+                    else if (opt.certificate_search && certificate_search) {}
+                    else break;
+                } else if (h_feas.at(iter) > opt.infeas_feasibility_tol) {
+                    stop_reason = 6;
+                    stop_reason_string = "Problem declared infeasible due to lack of improvement";
+                    if (opt.certificate_search && !certificate_search) { cert_infeas(); snapshot(); ++n_snap; }
+                    else if (opt.certificate_search && certificate_search) {}
+                    else break;
+                }
+            } else if (iter >= max_iter_local) {
+                stop_reason = 3;
+                stop_reason_string = "Iteration limit of " + std::to_string(max_iter_local) + " was hit";
+            } else {
+                stop_reason = 2;
+                stop_reason_string = "Time limit hit, limit: " + std::to_string(time_limit) +
+                                     " time: " + std::to_string(now_s() - time0);
+            }
+            if (iter >= max_iter_local || now_s() - time0 >= time_limit) break;
+        }
+        if (opt.certificate_search && certificate_search) continue;
+
+        // ---- objective blow-up / stalls (pdhg.jl:389-483)
+        if ((iter > opt.min_iter_max_obj && h_dobj.at(k) > opt.max_obj) || std::isnan(h_dobj.at(k))) {
+            stop_reason = 6;
+            stop_reason_string = "Infeasible: |Dual objective| = " + std::to_string(h_dobj.at(k)) +
+                                 " > maximum allowed = " + std::to_string(opt.max_obj);
+            if (opt.certificate_search && !certificate_search) { cert_infeas(); snapshot(); ++n_snap; }
+            else break;
+        }
+        if ((iter > opt.min_iter_max_obj && h_pobj.at(k) < -opt.max_obj) || std::isnan(h_pobj.at(k))) {
+            stop_reason = 5;
+            stop_reason_string = "Unbounded: |Primal objective| = " + std::to_string(h_pobj.at(k)) +
+                                 " > maximum allowed = " + std::to_string(opt.max_obj);
+            if (opt.certificate_search && !certificate_search) { cert_dual_infeas(); snapshot(); ++n_snap; }
+            else break;
+        }
+        if (iter > opt.min_iter_max_obj && h_gap.at(k) > opt.infeas_limit_gap_tol &&
+            h_feas.at(iter) > opt.infeas_feasibility_tol &&
+            h_feas.max_abs_diff() < opt.infeas_stable_feasibility_tol) {
+            stop_reason = 6;
+            stop_reason_string = "Infeasible: feasibility stalled at " + std::to_string(h_feas.at(iter));
+            if (opt.certificate_search && !certificate_search) { cert_infeas(); snapshot(); ++n_snap; }
+            else break;
+        }
+        if (iter > opt.min_iter_max_obj && h_gap.at(k) > 1 - opt.infeas_gap_tol &&
+            h_gap.max_abs_diff() < opt.infeas_stable_gap_tol) {
+            if (std::fabs(h_dobj.at(k)) > std::fabs(h_pobj.at(k)) && h_feas.at(iter) > opt.infeas_feasibility_tol) {
+                stop_reason = 6;
+                stop_reason_string = "Infeasible: duality gap stalled at 100 % with |Dual objective| >> |Primal objective|";
+                if (opt.certificate_search && !certificate_search) { cert_infeas(); snapshot(); ++n_snap; }
+                else break;
+            } else if (std::fabs(h_pobj.at(k)) > std::fabs(h_dobj.at(k)) && h_feas.at(iter) <= opt.tol_feasibility) {
+                stop_reason = 5;
+                stop_reason_string = "Unbounded: duality gap stalled at 100 % with |Dual objective| << |Primal objective|";
+                if (opt.certificate_search && !certificate_search) { cert_dual_infeas(); snapshot(); ++n_snap; }
+                else break;
+            }
+        }
+    }
+    PX_HIP(hipStreamSynchronize(stream));
+    st.loop_time = now_s() - t_loop0;
+
+    // ---- results (pdhg.jl:486-529)
+    if (opt.certificate_search && certificate_search) {
+        if (certificate_found) {
+            std::vector<double> cc(P.c_orig);
+            if (stop_reason == 6) std::fill(cc.begin(), cc.end(), 0.0);
+            cache_solution(cc);
+        }
+    } else {
+        cache_solution(P.c_orig);
+    }
+    (void)n_snap;
+    res.stats = st;
+}
+
+}  // namespace proxsdp

@@ -1,0 +1,179 @@
+// Host-side one-shot preparation of a solve (no HIP calls here):
+//   validate + copy the borrowed problem, preprocess! (variable order, cones
+//   first -- /root/reference/src/scaling.jl:2-26), norm_scaling (x sqrt(2)/2 on
+//   off-diagonal PSD columns of A, G and on c -- scaling.jl:28-58), M = vcat(A,G)
+//   (pdhg.jl:104) in both orientations, ||M||_F (pdhg.jl:121), data norms
+//   (pdhg.jl:14-16), cone layout (util.jl:2-16).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/proxsdp_hip.h"
+
+namespace proxsdp {
+
+struct BlockInfo { int n; int64_t N; int64_t off; };
+struct SocInfo { int64_t off; int len; };
+
+struct Prep {
+    int64_t n = 0, p = 0, m = 0, Q = 0, nnz = 0;
+    std::vector<int64_t> ord;          // new position k holds original variable ord[k]
+    std::vector<int64_t> inv;          // sortperm(ord): original variable i sits at inv[i]
+    // M = [A;G] with reordered columns, CSC, scaled (val) and unscaled (val_orig)
+    std::vector<int64_t> colptr;       // n+1
+    std::vector<int32_t> rowidx;       // nnz, rows of G offset by p
+    std::vector<double> val, val_orig;
+    // CSR of the scaled M
+    std::vector<int64_t> rowptr;       // Q+1
+    std::vector<int32_t> colidx;
+    std::vector<double> rval;
+    std::vector<double> b, h, c, c_orig;   // c: reordered+scaled; c_orig: reordered, unscaled
+    std::vector<uint8_t> offdiag;          // per new position: 1 if off-diagonal PSD entry
+    std::vector<BlockInfo> blocks;
+    std::vector<SocInfo> socs;
+    int64_t sdplen = 0, conelen = 0;
+    double norm_b = 0, norm_h = 0, norm_c = 0, frob = 0;
+};
+
+inline double norm2(const double* v, int64_t n) {
+    double s = 0.0;
+    for (int64_t i = 0; i < n; ++i) s += v[i] * v[i];
+    return std::sqrt(s);
+}
+
+inline void check_csc(const proxsdp_csc& M, int64_t rows, int64_t cols, int base, const char* name) {
+    if (M.nrows != rows || M.ncols != cols)
+        throw std::invalid_argument(std::string(name) + ": shape mismatch");
+    if (cols > 0 && M.colptr == nullptr) throw std::invalid_argument(std::string(name) + ": colptr is NULL");
+    if (cols == 0) return;
+    if (M.colptr[0] != base) throw std::invalid_argument(std::string(name) + ": colptr[0] != index_base");
+    for (int64_t j = 0; j < cols; ++j)
+        if (M.colptr[j + 1] < M.colptr[j]) throw std::invalid_argument(std::string(name) + ": colptr not monotone");
+    int64_t nnz = M.colptr[cols] - base;
+    if (nnz > 0 && (M.rowval == nullptr || M.nzval == nullptr))
+        throw std::invalid_argument(std::string(name) + ": rowval/nzval is NULL");
+    for (int64_t k = 0; k < nnz; ++k) {
+        int64_t r = M.rowval[k] - base;
+        if (r < 0 || r >= rows) throw std::invalid_argument(std::string(name) + ": row index out of range");
+    }
+}
+
+inline Prep prepare(const proxsdp_problem& P) {
+    Prep R;
+    const int base = P.index_base;
+    if (base != 0 && base != 1) throw std::invalid_argument("index_base must be 0 or 1");
+    if (P.n < 0 || P.p < 0 || P.m < 0) throw std::invalid_argument("negative dimension");
+    if (P.n >= (int64_t)1 << 31) throw std::invalid_argument("n >= 2^31 not supported");
+    R.n = P.n; R.p = P.p; R.m = P.m; R.Q = P.p + P.m;
+    check_csc(P.A, P.p, P.n, base, "A");
+    check_csc(P.G, P.m, P.n, base, "G");
+    if ((P.p > 0 && !P.b) || (P.m > 0 && !P.h) || (P.n > 0 && !P.c))
+        throw std::invalid_argument("b, h or c is NULL");
+    if (P.n_psd < 0 || P.n_soc < 0) throw std::invalid_argument("negative cone count");
+    if (P.n_psd > 0 && (!P.psd_ptr || !P.psd_idx)) throw std::invalid_argument("psd_ptr/psd_idx is NULL");
+    if (P.n_soc > 0 && (!P.soc_ptr || !P.soc_idx)) throw std::invalid_argument("soc_ptr/soc_idx is NULL");
+
+    // ---- preprocess!: cones first (PSD blocks in cone order, then SOC), then the rest sorted
+    std::vector<uint8_t> used(P.n, 0);
+    R.ord.reserve(P.n);
+    R.offdiag.assign(P.n, 0);
+    int64_t pos = 0;
+    for (int64_t k = 0; k < P.n_psd; ++k) {
+        int64_t len = P.psd_ptr[k + 1] - P.psd_ptr[k];
+        if (len <= 0) throw std::invalid_argument("empty PSD cone");
+        int64_t side = (int64_t)((std::sqrt(8.0 * (double)len + 1.0) - 1.0) / 2.0);
+        while (side * (side + 1) / 2 < len) ++side;
+        while (side * (side + 1) / 2 > len) --side;
+        if (side * (side + 1) / 2 != len) throw std::invalid_argument("PSD cone length is not triangular");
+        if (side > 46340) throw std::invalid_argument("PSD side too large");
+        R.blocks.push_back({(int)side, len, pos});
+        int64_t q = P.psd_ptr[k];
+        for (int64_t j = 0; j < side; ++j)
+            for (int64_t i = 0; i <= j; ++i, ++q) {
+                int64_t v = P.psd_idx[q] - base;
+                if (v < 0 || v >= P.n || used[v]) throw std::invalid_argument("PSD cone variable out of range or repeated");
+                used[v] = 1;
+                R.ord.push_back(v);
+                R.offdiag[pos++] = (i != j);
+            }
+    }
+    R.sdplen = pos;
+    for (int64_t k = 0; k < P.n_soc; ++k) {
+        int64_t len = P.soc_ptr[k + 1] - P.soc_ptr[k];
+        if (len <= 0) throw std::invalid_argument("empty SOC cone");
+        R.socs.push_back({pos, (int)len});
+        for (int64_t q = P.soc_ptr[k]; q < P.soc_ptr[k + 1]; ++q) {
+            int64_t v = P.soc_idx[q] - base;
+            if (v < 0 || v >= P.n || used[v]) throw std::invalid_argument("SOC variable out of range or repeated");
+            used[v] = 1;
+            R.ord.push_back(v);
+            ++pos;
+        }
+    }
+    R.conelen = pos;
+    for (int64_t v = 0; v < P.n; ++v)
+        if (!used[v]) R.ord.push_back(v);
+    R.inv.assign(P.n, 0);
+    for (int64_t k = 0; k < P.n; ++k) R.inv[R.ord[k]] = k;
+
+    // ---- vectors
+    R.b.assign(P.b, P.b + P.p);
+    R.h.assign(P.h, P.h + P.m);
+    R.norm_b = norm2(P.b, P.p);
+    R.norm_h = norm2(P.h, P.m);
+    R.norm_c = norm2(P.c, P.n);
+    const double cte = std::sqrt(2.0) / 2.0;
+    R.c.resize(P.n); R.c_orig.resize(P.n);
+    for (int64_t k = 0; k < P.n; ++k) {
+        double v = P.c[R.ord[k]];
+        R.c_orig[k] = v;
+        R.c[k] = R.offdiag[k] ? v * cte : v;
+    }
+
+    // ---- M = vcat(A, G) with reordered columns
+    int64_t nnzA = P.n > 0 ? P.A.colptr[P.n] - base : 0;
+    int64_t nnzG = P.n > 0 ? P.G.colptr[P.n] - base : 0;
+    R.nnz = nnzA + nnzG;
+    if (R.nnz >= ((int64_t)1 << 31) - 1) throw std::invalid_argument("nnz(M) >= 2^31 not supported by the sparse path");
+    R.colptr.assign(P.n + 1, 0);
+    R.rowidx.resize(R.nnz); R.val.resize(R.nnz); R.val_orig.resize(R.nnz);
+    int64_t w = 0;
+    double ss = 0.0;
+    for (int64_t k = 0; k < P.n; ++k) {
+        const int64_t j = R.ord[k];
+        const double sc = R.offdiag[k] ? cte : 1.0;
+        R.colptr[k] = w;
+        for (int64_t q = P.A.colptr[j] - base; q < P.A.colptr[j + 1] - base; ++q, ++w) {
+            R.rowidx[w] = (int32_t)(P.A.rowval[q] - base);
+            R.val_orig[w] = P.A.nzval[q];
+            R.val[w] = P.A.nzval[q] * sc;
+            ss += R.val[w] * R.val[w];
+        }
+        for (int64_t q = P.G.colptr[j] - base; q < P.G.colptr[j + 1] - base; ++q, ++w) {
+            R.rowidx[w] = (int32_t)(P.G.rowval[q] - base + P.p);
+            R.val_orig[w] = P.G.nzval[q];
+            R.val[w] = P.G.nzval[q] * sc;
+            ss += R.val[w] * R.val[w];
+        }
+    }
+    R.colptr[P.n] = w;
+    R.frob = std::sqrt(ss);
+
+    // ---- CSR of the scaled M (counting sort; column order inside a row ascending)
+    R.rowptr.assign(R.Q + 1, 0);
+    for (int64_t q = 0; q < R.nnz; ++q) R.rowptr[R.rowidx[q] + 1]++;
+    for (int64_t r = 0; r < R.Q; ++r) R.rowptr[r + 1] += R.rowptr[r];
+    R.colidx.resize(R.nnz); R.rval.resize(R.nnz);
+    std::vector<int64_t> cur(R.rowptr.begin(), R.rowptr.end() - 1);
+    for (int64_t k = 0; k < P.n; ++k)
+        for (int64_t q = R.colptr[k]; q < R.colptr[k + 1]; ++q) {
+            int64_t d = cur[R.rowidx[q]]++;
+            R.colidx[d] = (int32_t)k;
+            R.rval[d] = R.val[q];
+        }
+    return R;
+}
+
+}  // namespace proxsdp

@@ -1,0 +1,475 @@
+// Device-resident PDHG solve: the replacement for chambolle_pock
+// (/root/reference/src/pdhg.jl:1-530) and everything below it.
+//
+// Host role: the scalar control logic of pdhg.jl:166-483 (a few dozen flops per
+// iteration), the K x K Rayleigh-quotient eigenproblem of the thick-restart
+// Lanczos, and kernel launches.  Every vector of length Nx or Q, the sparse
+// operator in both orientations and the Lanczos basis live in HBM for the whole
+// solve; per iteration the host reads back a handful of scalars.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "host_util.hpp"
+#include "kernels.hip.hpp"
+#include "prep.hpp"
+
+namespace proxsdp {
+
+struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+#define PX_HIP(call)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            throw ::proxsdp::HipError(std::string(#call) + ": " + hipGetErrorString(e_) + " (" +       \
+                           __FILE__ + ":" + std::to_string(__LINE__) + ")");                \
+    } while (0)
+#define PX_ROC(call)                                                                         \
+    do {                                                                                     \
+        rocblas_status s_ = (call);                                                          \
+        if (s_ != rocblas_status_success)                                                    \
+            throw ::proxsdp::HipError(std::string(#call) + ": rocblas status " + std::to_string((int)s_)); \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    explicit DevBuf(size_t count) { alloc(count); }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void alloc(size_t count) {
+        release();
+        n = count;
+        if (count == 0) return;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+        if (e != hipSuccess) { p = nullptr; throw std::bad_alloc(); }
+    }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; } n = 0; }
+    void zero(hipStream_t s) { if (n) PX_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
+    void upload(const T* h, size_t count, hipStream_t s) {
+        if (count) PX_HIP(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, s));
+    }
+    void download(T* h, size_t count, hipStream_t s) const {
+        if (count) PX_HIP(hipMemcpyAsync(h, p, count * sizeof(T), hipMemcpyDeviceToHost, s));
+    }
+};
+
+static inline double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+static inline int grid_for(long long n) {          // memory-bound passes: cap the grid, grid-stride the rest
+    long long g = (n + dev::TPB - 1) / dev::TPB;
+    return (int)std::max<long long>(1, std::min<long long>(g, 2048));
+}
+
+// structs.jl:2-30
+struct CircularVector {
+    std::vector<double> v;
+    int l = 0;
+    void init(int len) { v.assign(len, 0.0); l = len; }
+    double& at(long long i) { return v[(size_t)(((i - 1) % l + l) % l)]; }
+    double max_abs_diff() const {
+        double val = 0.0;
+        for (int i = 0; i < l; ++i) val = std::max(val, std::fabs(v[i] - v[(i + l - 1) % l]));
+        return val;
+    }
+};
+
+// ------------------------------------------------------------------ per-block Lanczos workspace
+struct EigWork {
+    int n = 0, nt = 0, npad = 0, nwg = 0, cap = 0;   // cap = columns of V (krylovdim_max + 1)
+    int64_t N = 0;
+    DevBuf<double> V, Z;            // npad x cap each (V: Krylov basis, Z: rotation target / Ritz vectors)
+    DevBuf<double> w, Ppart, hpart1, hpart2, nrmpart, hsum1, hsum2, alphas, betas, U, lam, resid;
+    DevBuf<dev::LanczosCtl> ctl;
+    // full-eig fallback
+    DevBuf<double> A, D, E;
+    DevBuf<rocblas_int> info;
+    std::vector<double> resid_host;
+    // results of the last call
+    std::vector<double> vals;
+    int count = 0, converged_eigs = 0, numiter = 0;
+    bool converged = false;
+};
+
+struct EigEvents {                  // optional profiling of the dominant kernel
+    std::vector<hipEvent_t> e0, e1;
+    size_t used = 0;
+};
+
+class Solver {
+public:
+    Solver(const proxsdp_problem& prob, const proxsdp_options& opt_in, proxsdp_result& res_out)
+        : opt(opt_in), res(res_out), P(prepare(prob)) {
+        time0 = now_s();
+        user_resid = prob.eig_resid;
+    }
+    // engine-only instance for the kernel-level test entry points (no problem data)
+    Solver(const proxsdp_options& opt_in, proxsdp_result& res_out) : opt(opt_in), res(res_out) {
+        time0 = now_s();
+    }
+    ~Solver() {
+        for (auto e : ev.e0) (void)hipEventDestroy(e);
+        for (auto e : ev.e1) (void)hipEventDestroy(e);
+        if (blas) (void)rocblas_destroy_handle(blas);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+    void run();
+
+    // pieces also used by the kernel-level test entry points
+    void setup_device();
+    void alloc_eigwork(EigWork& W, int n, int max_nev);
+    void lanczos(EigWork& W, const double* xp, int nev);
+    void full_eig_values(EigWork& W, const double* xp, double offscale, bool vectors, std::vector<double>& Dhost);
+    void launch_symv(EigWork& W, const double* xp, const double* v, bool use_ctl);
+    void launch_reconstruct(EigWork& W, const double* Z, int ldz, const double* lam, int r, double* xp_out);
+    void rotate(EigWork& W, int K, const std::vector<double>& U, int ldu, int ncols, double* out, int copy_src, int copy_dst);
+
+    // test hooks (capi.hip)
+    void test_project(int idx, double* xp, int tr);
+    long long test_rank() const { return current_rank.empty() ? 0 : current_rank[0]; }
+    double test_min_eig() const { return min_eig.empty() ? 0.0 : min_eig[0]; }
+    void test_spmv(bool transpose, const double* in, double* out);
+
+    proxsdp_options opt;
+    proxsdp_result& res;
+    Prep P;
+    hipStream_t stream = nullptr;
+    rocblas_handle blas = nullptr;
+    std::vector<EigWork> eig;
+    EigEvents ev;
+    proxsdp_stats st{};
+    double time0 = 0;
+    const double* user_resid = nullptr;
+
+private:
+    // device state
+    DevBuf<double> xbuf[2], Mtybuf[2], ybuf[2], Mxbuf[2], c_d, bh_d, part, scal;
+    DevBuf<int> csr_ptr, csr_col, csc_ptr, csc_row;
+    DevBuf<double> csr_val, csc_val;
+    DevBuf<long long> one_off, soc_off;
+    DevBuf<int> soc_len;
+    DevBuf<double> one_min, soc_gap_d;
+    int xc = 0, mtyc = 0, yc = 0, mxc = 0;     // index of the "current" buffer of each ping-pong pair
+    std::vector<int> one_blocks;               // indices of 1x1 PSD blocks
+    std::vector<double> hscal;
+    bool csr_wave = false;
+
+    // scalar state (Params, structs.jl:159-192)
+    double theta = 1, beta = 1, adapt_level = 0.9, primal_step = 0, primal_step_old = 0, dual_step = 0;
+    long long iter = 0;
+    int rank_update = 0, update_cont = 0, stop_reason = 0;
+    std::string stop_reason_string = "Not optimized";
+    std::vector<long long> target_rank, current_rank;
+    std::vector<double> min_eig;
+    double dual_feasibility = -1.0;
+    bool certificate_search = false, certificate_found = false;
+    long long certificate_search_min_iter = 0;
+    long long max_iter_local = 0;
+    double time_limit = 0;
+    int last_trials = 0;
+    long long lz_matvec_iter = 0; long long recon_r_iter = 0;
+    // histories (Residuals, structs.jl:100-125)
+    CircularVector h_gap, h_pobj, h_dobj, h_feas, h_pres, h_dres, h_comb;
+    double equa_feasibility = 0, ineq_feasibility = 0;
+
+    void primal_step_dev();
+    void psd_projection(double* x);
+    void project_block(int idx, double* x);
+    void full_eig_project(int idx, double* xp);
+    void spmv(const double* x, double* y);
+    int  linesearch();
+    void dual_step_plain();
+    void residual_and_gap();
+    bool convergedrank() const;
+    bool soc_convergence();
+    double dual_feas_host(const std::vector<double>& y, const std::vector<double>& cvec,
+                          std::vector<double>* dual_eq, std::vector<double>* dual_in, std::vector<double>* dual_cone);
+    void cache_solution(const std::vector<double>& cvec);
+    void certificate_parameters();
+    void bump_rank(int idx);
+    std::vector<double> b_host, h_host, c_host;   // current (possibly zeroed by a certificate search)
+    bool have_snapshot = false;
+    bool debug = std::getenv("PROXSDP_HIP_DEBUG") != nullptr;
+};
+
+// ------------------------------------------------------------------ setup
+inline void Solver::alloc_eigwork(EigWork& W, int n, int max_nev) {
+    W.n = n;
+    W.N = (int64_t)n * (n + 1) / 2;
+    W.nt = ceil_div(n, dev::TILE);
+    W.npad = W.nt * dev::TILE;
+    W.nwg = ceil_div(n, dev::TPB);
+    int kd = std::max(2 * max_nev + 1, (int)opt.eigsolver_min_lanczos);
+    W.cap = kd + 1;
+    if (W.cap > dev::MAXK)
+        throw std::invalid_argument("krylov dimension exceeds the library limit (raise dev::MAXK)");
+    W.V.alloc((size_t)W.npad * W.cap);
+    W.Z.alloc((size_t)W.npad * W.cap);
+    W.w.alloc(W.npad);
+    W.Ppart.alloc((size_t)W.nt * W.npad);
+    W.hpart1.alloc((size_t)W.nwg * dev::MAXK);
+    W.hpart2.alloc((size_t)W.nwg * dev::MAXK);
+    W.nrmpart.alloc(W.nwg);
+    W.hsum1.alloc(dev::MAXK); W.hsum2.alloc(dev::MAXK);
+    W.alphas.alloc(dev::MAXK); W.betas.alloc(dev::MAXK);
+    W.U.alloc((size_t)dev::MAXK * dev::MAXK);
+    W.lam.alloc(std::max(n, dev::MAXK));
+    W.resid.alloc(W.npad);
+    W.ctl.alloc(1);
+    W.V.zero(stream); W.Z.zero(stream); W.w.zero(stream);
+    W.hsum1.zero(stream); W.hsum2.zero(stream); W.alphas.zero(stream); W.betas.zero(stream);
+    W.resid.zero(stream);
+}
+
+inline void Solver::setup_device() {
+    int ndev = 0;
+    PX_HIP(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) throw HipError("no HIP device available");
+    if (opt.device_id < 0 || opt.device_id >= ndev) throw std::invalid_argument("device_id out of range");
+    PX_HIP(hipSetDevice(opt.device_id));
+    PX_HIP(hipStreamCreate(&stream));
+    PX_ROC(rocblas_create_handle(&blas));
+    PX_ROC(rocblas_set_stream(blas, stream));
+}
+
+// ------------------------------------------------------------------ kernels launch helpers
+inline void Solver::launch_symv(EigWork& W, const double* xp, const double* v, bool use_ctl) {
+    const int ntile = W.nt * (W.nt + 1) / 2;
+    bool prof = opt.profile_symv_every > 0 && (st.symv_launches % opt.profile_symv_every) == 0;
+    size_t slot = 0;
+    if (prof) {
+        if (ev.used == ev.e0.size()) {
+            hipEvent_t a, b;
+            PX_HIP(hipEventCreate(&a)); PX_HIP(hipEventCreate(&b));
+            ev.e0.push_back(a); ev.e1.push_back(b);
+        }
+        slot = ev.used++;
+        PX_HIP(hipEventRecord(ev.e0[slot], stream));
+    }
+    hipLaunchKernelGGL(dev::k_symv_packed, dim3(ntile), dim3(dev::TPB), 0, stream,
+                       xp, W.n, W.nt, W.npad, v, W.Ppart.p, use_ctl ? W.ctl.p : nullptr);
+    if (prof) PX_HIP(hipEventRecord(ev.e1[slot], stream));
+    st.symv_launches++;
+    st.symv_bytes += 8.0 * (double)W.N + 16.0 * (double)W.n;
+}
+
+inline void Solver::launch_reconstruct(EigWork& W, const double* Z, int ldz, const double* lam, int r, double* xp_out) {
+    const int ntile = W.nt * (W.nt + 1) / 2;
+    hipLaunchKernelGGL(dev::k_reconstruct_packed, dim3(ntile), dim3(dev::TPB), 0, stream,
+                       Z, ldz, lam, r, W.n, xp_out);
+}
+
+inline void Solver::rotate(EigWork& W, int K, const std::vector<double>& U, int ldu, int ncols,
+                           double* out, int copy_src, int copy_dst) {
+    // U: host column-major (ldu x >=ncols); upload the K x ncols part compactly
+    std::vector<double> tmp((size_t)K * std::max(ncols, 1));
+    for (int c = 0; c < ncols; ++c)
+        for (int j = 0; j < K; ++j) tmp[(size_t)c * K + j] = U[(size_t)c * ldu + j];
+    W.U.upload(tmp.data(), (size_t)K * ncols, stream);
+    PX_HIP(hipStreamSynchronize(stream));          // tmp is stack-scoped host memory
+    const int maxcols = std::max(1, (int)(40 * 1024 / (8 * K)));   // keep dynamic LDS <= 40 KiB
+    int c0 = 0;
+    do {
+        const int cn = std::max(0, std::min(maxcols, ncols - c0));
+        const bool last = (c0 + cn >= ncols);
+        if (cn > 0 || (last && copy_src >= 0))
+            hipLaunchKernelGGL(dev::k_lz_rotate, dim3(W.nwg), dim3(dev::TPB), (size_t)K * cn * 8, stream,
+                               W.V.p, W.npad, W.n, K, W.U.p + (size_t)c0 * K, K, cn,
+                               out + (size_t)c0 * W.npad, W.npad, last ? copy_src : -1, copy_dst - c0);
+        c0 += std::max(cn, 1);
+    } while (c0 < ncols);
+}
+
+// ------------------------------------------------------------------ Lanczos (KrylovKit eigsolve)
+// eigsolver.jl:798-823 -> KrylovKit.eigsolve(A, resid, nev, :LR, Lanczos(orth, krylovdim, maxiter, tol))
+// with A = Symmetric(smat(xp)).  eigsolver == 1 selects ARPACK's acceptance rule
+// (dsaupd: |resid_i| <= tol*max(eps^(2/3), |theta_i|) for all nev wanted values,
+// eigsolver.jl:668-746) on the same thick-restart engine.
+inline void Solver::lanczos(EigWork& W, const double* xp, int nev) {
+    const bool arpack = (opt.eigsolver == 1);
+    const int krylovdim = std::max(2 * nev + 1, (int)opt.eigsolver_min_lanczos);
+    if (krylovdim + 1 > W.cap) throw std::invalid_argument("Lanczos workspace too small for the requested rank");
+    const double tol = arpack ? opt.arpack_tol : opt.krylovkit_tol;
+    const long long maxiter = arpack ? (long long)opt.arpack_max_iter : (long long)opt.krylovkit_max_iter;
+    if (!arpack && opt.krylovkit_eager) throw std::invalid_argument("krylovkit_eager=true is not implemented");
+    W.converged = false; W.count = 0; W.converged_eigs = 0; W.numiter = 0; W.vals.clear();
+    st.lanczos_calls++;
+    if (arpack && (!(0 < nev && nev < W.n) || krylovdim > W.n)) return;   // dsaupd info=-1/-3 -> error -> fallback
+
+    const double step_tol = arpack ? 0.0 : tol;       // invariant-subspace test inside the recurrence
+    PX_HIP(hipMemsetAsync(W.ctl.p, 0, sizeof(dev::LanczosCtl), stream));
+    PX_HIP(hipMemcpyAsync(W.V.p, W.resid.p, (size_t)W.npad * 8, hipMemcpyDeviceToDevice, stream));
+
+    const int ld = krylovdim + 1;
+    std::vector<double> T((size_t)ld * ld, 0.0), Tw, D(ld), U, f(ld), al(ld), be(ld);
+    int howmany = nev, numiter = 1, converged = 0, K = 0, kfirst = 0;
+    double betaK = 0.0;
+    dev::LanczosCtl hctl{};
+    while (true) {
+        for (int k = kfirst; k < krylovdim; ++k) {
+            launch_symv(W, xp, W.V.p + (size_t)k * W.npad, true);
+            hipLaunchKernelGGL(dev::k_lz_dots1, dim3(W.nwg), dim3(dev::TPB), 0, stream,
+                               W.Ppart.p, W.nt, W.n, W.npad, W.V.p, W.npad, k, W.w.p, W.hpart1.p, W.ctl.p);
+            hipLaunchKernelGGL(dev::k_lz_apply<0>, dim3(W.nwg), dim3(dev::TPB), 0, stream,
+                               W.w.p, W.n, W.V.p, W.npad, k, W.hpart1.p, W.nwg, W.hsum1.p, W.hpart2.p, W.ctl.p);
+            hipLaunchKernelGGL(dev::k_lz_apply<1>, dim3(W.nwg), dim3(dev::TPB), 0, stream,
+                               W.w.p, W.n, W.V.p, W.npad, k, W.hpart2.p, W.nwg, W.hsum2.p, W.nrmpart.p, W.ctl.p);
+            hipLaunchKernelGGL(dev::k_lz_finish, dim3(W.nwg), dim3(dev::TPB), 0, stream,
+                               W.w.p, W.n, W.nrmpart.p, W.nwg, W.V.p, W.npad, k, W.hsum1.p, W.hsum2.p,
+                               W.alphas.p, W.betas.p, W.ctl.p, step_tol);
+        }
+        W.alphas.download(al.data(), krylovdim, stream);
+        W.betas.download(be.data(), krylovdim, stream);
+        PX_HIP(hipMemcpyAsync(&hctl, W.ctl.p, sizeof(hctl), hipMemcpyDeviceToHost, stream));
+        PX_HIP(hipStreamSynchronize(stream));
+        if (ev.used) {                                   // harvest profiled symv launches
+            for (size_t s = 0; s < ev.used; ++s) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, ev.e0[s], ev.e1[s]) == hipSuccess) {
+                    st.symv_profiled_ms += ms; st.symv_profiled++;
+                }
+            }
+            ev.used = 0;
+        }
+        const int Kend = hctl.stop ? hctl.kstop : krylovdim;
+        // launches after the stop flag are no-ops; count the mat-vecs that did work
+        {
+            long long skipped = (long long)(krylovdim - Kend);
+            st.lanczos_matvecs += (Kend - kfirst);
+            st.symv_launches -= skipped;
+            st.symv_bytes -= skipped * (8.0 * (double)W.N + 16.0 * (double)W.n);
+            lz_matvec_iter += (Kend - kfirst);
+        }
+        for (int k = kfirst; k < Kend; ++k) {
+            T[(size_t)k * ld + k] = al[k];
+            if (k + 1 < Kend) { T[(size_t)k * ld + k + 1] = be[k]; T[(size_t)(k + 1) * ld + k] = be[k]; }
+        }
+        K = Kend;
+        betaK = be[K - 1];
+        if (!(betaK == betaK)) {                         // NaN guard: treat as not converged
+            W.converged = false; W.numiter = numiter; return;
+        }
+        if (betaK <= tol && K < howmany && !arpack) howmany = K;
+        if (K == 1) {
+            D[0] = T[0]; U.assign(1, 1.0); f[0] = betaK;
+        } else {
+            Tw.assign((size_t)K * K, 0.0);
+            for (int c = 0; c < K; ++c)
+                for (int r = 0; r < K; ++r) Tw[(size_t)c * K + r] = T[(size_t)c * ld + r];
+            std::vector<double> Dasc(K);
+            symeig_dense(K, Tw.data(), Dasc.data());
+            U.assign((size_t)K * K, 0.0);
+            for (int c = 0; c < K; ++c) {                // :LR -> descending
+                D[c] = Dasc[K - 1 - c];
+                for (int r = 0; r < K; ++r) U[(size_t)c * K + r] = Tw[(size_t)(K - 1 - c) * K + r];
+                f[c] = betaK * U[(size_t)c * K + (K - 1)];
+            }
+        }
+        converged = 0;
+        if (!arpack) {
+            while (converged < K && std::fabs(f[converged]) <= tol) ++converged;
+        } else {
+            const double eps23 = std::pow(2.220446049250313e-16 / 2.0, 2.0 / 3.0);
+            int want = std::min(nev, K);
+            for (int i = 0; i < want; ++i)
+                if (std::fabs(f[i]) <= tol * std::max(eps23, std::fabs(D[i]))) ++converged;
+        }
+        if (converged >= howmany) break;
+        if (K < krylovdim) break;                        // invariant subspace without convergence (arpack rule)
+        if (numiter == maxiter) break;
+        const int keep = arpack ? std::min(krylovdim - 1, nev + std::max(1, (krylovdim - nev) / 2))
+                                : (3 * krylovdim + 2 * converged) / 5;
+        rotate(W, K, U, K, keep, W.Z.p, K, keep);        // Z[:, :keep] = V U[:, :keep]; Z[:, keep] = V[:, K]
+        std::swap(W.V.p, W.Z.p);
+        std::fill(T.begin(), T.end(), 0.0);
+        for (int j = 0; j < keep; ++j) {
+            T[(size_t)j * ld + j] = D[j];
+            T[(size_t)j * ld + keep] = f[j];
+            T[(size_t)keep * ld + j] = f[j];
+        }
+        kfirst = keep;
+        ++numiter;
+        st.lanczos_restarts++;
+    }
+    W.numiter = numiter;
+    if (arpack) {
+        // _saupd!/_seupd! (eigsolver.jl:668-746): converged only when all nev pairs are
+        W.converged_eigs = converged;
+        if (converged < nev) { W.converged = false; return; }
+        W.count = nev;
+        W.vals.assign(D.begin(), D.begin() + nev);
+        std::reverse(W.vals.begin(), W.vals.end());      // arc.d is ascending
+        std::vector<double> Ur((size_t)K * nev);
+        for (int c = 0; c < nev; ++c)
+            for (int r = 0; r < K; ++r) Ur[(size_t)c * K + r] = U[(size_t)(nev - 1 - c) * K + r];
+        rotate(W, K, Ur, K, nev, W.Z.p, -1, 0);
+        W.converged = true;
+        return;
+    }
+    if (converged > howmany) howmany = converged;
+    W.count = howmany;
+    W.vals.assign(D.begin(), D.begin() + howmany);
+    W.converged_eigs = converged;
+    W.converged = (converged != 0);                      // eigsolver.jl:816-818
+    rotate(W, K, U, K, howmany, W.Z.p, -1, 0);            // Ritz vectors B*v
+}
+
+// eigen!(Symmetric(smat(xp))) through rocSOLVER dsyevd (ascending), the dense
+// fallback (prox_operators.jl:113, pdhg.jl:685)
+inline void Solver::full_eig_values(EigWork& W, const double* xp, double offscale, bool vectors,
+                                    std::vector<double>& Dhost) {
+    const int n = W.n;
+    if (W.A.n < (size_t)n * n) {
+        W.A.alloc((size_t)n * n); W.D.alloc(n); W.E.alloc(n); W.info.alloc(1);
+    }
+    const int ntile = W.nt * (W.nt + 1) / 2;
+    hipLaunchKernelGGL(dev::k_unpack_upper, dim3(ntile), dim3(dev::TPB), 0, stream, xp, n, W.A.p, n, offscale);
+    PX_ROC(rocsolver_dsyevd(blas, vectors ? rocblas_evect_original : rocblas_evect_none, rocblas_fill_upper,
+                            n, W.A.p, n, W.D.p, W.E.p, W.info.p));
+    Dhost.resize(n);
+    rocblas_int info = 0;
+    W.D.download(Dhost.data(), n, stream);
+    PX_HIP(hipMemcpyAsync(&info, W.info.p, sizeof(info), hipMemcpyDeviceToHost, stream));
+    PX_HIP(hipStreamSynchronize(stream));
+    if (info != 0) throw HipError("rocsolver_dsyevd did not converge (info=" + std::to_string(info) + ")");
+}
+
+// full_eig! (prox_operators.jl:111-126)
+inline void Solver::full_eig_project(int idx, double* xp) {
+    EigWork& W = eig[idx];
+    std::vector<double> D;
+    full_eig_values(W, xp, dev::INV_SQRT2, true, D);
+    st.full_eigs++;
+    const int n = W.n;
+    int npos = 0, rank = 0;
+    for (int i = 0; i < n; ++i) { if (D[i] > 0.0) ++npos; if (D[i] > opt.tol_psd) ++rank; }
+    current_rank[idx] = rank;
+    min_eig[idx] = 0.0;
+    // ascending order: the positive eigenpairs are the trailing npos columns
+    launch_reconstruct(W, W.A.p + (size_t)(n - npos) * n, n, W.D.p + (n - npos), npos, xp);
+    recon_r_iter += npos;
+}
+
+}  // namespace proxsdp

@@ -1,0 +1,331 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, the
+committed golden fixtures, the reference's known answers, and -- at full size --
+size-independent properties.  Tolerances: fp64 kernels, deterministic
+reductions; kernel-level results agree to ~1e-12 relative, eigenpairs to the
+solvers' 1e-12/1e-10 residual tolerance, solves to the solver's own
+tol_gap/tol_feasibility (BASELINE.json north_star)."""
+import json
+import math
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import oracle
+from oracle import Options, eig as oeig
+from proxsdp_jl_amd import binding as B
+from proxsdp_jl_amd import problems as P
+from proxsdp_jl_amd.optimizer import Optimizer
+
+from helpers import PROJ_CASES, oracle_project, planted_packed, smat, svec
+from kat_problems import KATS, sdp_wiki, simple_lp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert B.device_count() > 0, "no HIP device: the product path has no CPU fallback"
+
+
+def _rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(1e-300, np.linalg.norm(b))
+
+
+# ----------------------------------------------------------------- kernels
+@pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 65, 127, 128, 200, 513, 1000])
+def test_symv_packed_matches_dense(n):
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n * (n + 1) // 2)
+    v = rng.standard_normal(n)
+    y = B.symv_packed(x, n, v)
+    ref = smat(x, n) @ v
+    assert _rel(y, ref) < 1e-13
+
+
+def test_symv_is_symmetric_and_linear_at_full_size():
+    """n = 4000 (the metric's size): u'(Xv) == v'(Xu), X(av+bu) == aXv+bXu, and
+    agreement with the packed arithmetic done on the CPU for a few rows."""
+    n = 4000
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(n * (n + 1) // 2)
+    u, v = rng.standard_normal(n), rng.standard_normal(n)
+    Xu, Xv = B.symv_packed(x, n, u), B.symv_packed(x, n, v)
+    assert abs(v @ Xu - u @ Xv) <= 1e-11 * np.linalg.norm(Xu) * np.linalg.norm(v)
+    Xc = B.symv_packed(x, n, 2.0 * u - 3.0 * v)
+    assert _rel(Xc, 2.0 * Xu - 3.0 * Xv) < 1e-12
+    for i in (0, 1, 63, 64, 2047, 3999):
+        col = np.arange(n)
+        lo, hi = np.minimum(i, col), np.maximum(i, col)
+        vals = x[hi * (hi + 1) // 2 + lo]
+        vals = np.where(col == i, vals, vals / math.sqrt(2))
+        assert abs(vals @ u - Xu[i]) <= 1e-11 * np.linalg.norm(vals) * np.linalg.norm(u)
+
+
+@pytest.mark.parametrize("n,r", [(5, 0), (5, 1), (64, 3), (65, 16), (200, 17), (257, 40), (513, 2)])
+def test_reconstruct_matches_dense(n, r):
+    rng = np.random.default_rng(n + r)
+    Z = rng.standard_normal((n, r))
+    lam = rng.uniform(0.1, 5.0, r)
+    out = B.reconstruct(Z, lam, n)
+    ref = svec((Z * lam) @ Z.T) if r else np.zeros(n * (n + 1) // 2)
+    assert np.allclose(out, ref, rtol=1e-13, atol=1e-13 * max(1.0, np.abs(ref).max()))
+
+
+def test_spmv_both_orientations():
+    rng = np.random.default_rng(1)
+    for (rows, cols, dens) in [(50, 400, 0.05), (300, 40, 0.3), (7, 5000, 0.9), (1000, 1000, 0.002)]:
+        M = sp.random(rows, cols, density=dens, random_state=rng, format="csc")
+        x, y = rng.standard_normal(cols), rng.standard_normal(rows)
+        assert _rel(B.spmv(M, x), M @ x) < 1e-13
+        assert _rel(B.spmv(M, y, transpose=True), M.T @ y) < 1e-13
+    # one very long row (gpp500-1's all-ones constraint) and empty rows/columns
+    M = sp.lil_matrix((4, 20000))
+    M[1, :] = 1.0
+    M[3, 5] = 2.0
+    M = M.tocsc()
+    x = rng.standard_normal(20000)
+    assert _rel(B.spmv(M, x), M @ x) < 1e-13
+
+
+# ----------------------------------------------------------------- eigen layer
+@pytest.mark.parametrize("n,nev,top", [
+    (101, 2, [40.0, 25.0, 9.0, 4.0]),
+    (257, 4, [90.0, 60.0, 33.0, 12.0, 5.0]),
+    (300, 12, [50, 40, 30, 20, 10, 9, 8, 7, 6.5, 6, 5.5, 5.2]),
+    (1000, 3, [500.0, 20.0, 19.5, 19.0]),
+])
+def test_lanczos_matches_oracle_and_dense(n, nev, top):
+    x = planted_packed(n, 11, top, bulk=(-5.0, 1.0))
+    X = smat(x, n)
+    vals, vecs, info = B.eigsolve(x, n, nev)
+    ncv = max(2 * nev + 1, 25)
+    ovals, ovecs, oconv, onumiter, onumops = oeig.krylovkit_eigsolve(
+        lambda v: X @ v, oeig.start_vector(n), nev, ncv, 100, 1e-12)
+    ref = np.sort(np.linalg.eigvalsh(X))[::-1]
+    scale = abs(ref[0])
+    assert info["converged"] >= nev and len(vals) >= nev
+    assert np.allclose(vals[:nev], ref[:nev], rtol=0, atol=1e-11 * scale)
+    assert np.allclose(vals[:nev], ovals[:nev], rtol=0, atol=1e-11 * scale)
+    resid = np.linalg.norm(X @ vecs - vecs * vals, axis=0)
+    assert np.all(resid[:nev] < 1e-9 * scale)
+    assert np.allclose(vecs.T @ vecs, np.eye(vecs.shape[1]), atol=1e-10)
+    # same algorithm, same start vector: same number of restarts / mat-vecs
+    assert info["numiter"] == onumiter and info["nmatvec"] == onumops
+
+
+def test_lanczos_edge_cases():
+    # zero matrix: invariant subspace at K = 1, howmany reduced (first PDHG iteration: x - tau*(0+c) with x = tau*c)
+    vals, vecs, info = B.eigsolve(np.zeros(101 * 102 // 2), 101, 2)
+    assert list(vals) == [0.0] and info["converged"] == 1 and info["nmatvec"] == 1
+    # tiny matrix, krylovdim > n
+    X3 = np.array([[1, -0.15, 0.0], [-0.15, 1, 0.45], [0.0, 0.45, 1.0]])
+    vals, vecs, info = B.eigsolve(svec(X3), 3, 2)
+    assert info["converged"] == 3 and info["nmatvec"] == 3
+    assert np.allclose(vals, np.sort(np.linalg.eigvalsh(X3))[::-1], atol=1e-13)
+    # explicit start vector
+    rng = np.random.default_rng(5)
+    x = planted_packed(150, 2, [30.0, 10.0])
+    r = rng.standard_normal(150)
+    v1, _, i1 = B.eigsolve(x, 150, 2, resid=r)
+    v2, _, i2 = B.eigsolve(x, 150, 2, resid=3.0 * r)          # normalised inside, as KrylovKit does
+    assert np.allclose(v1[:2], v2[:2], atol=1e-12) and i1["nmatvec"] == i2["nmatvec"]
+
+
+@pytest.mark.parametrize("case", PROJ_CASES, ids=[c[0] for c in PROJ_CASES])
+def test_psd_projection_matches_golden_and_oracle(case, golden_dir):
+    name, n, seed, top, tr, full = case
+    gold = np.load(golden_dir / "psd_projection.npz")
+    x = planted_packed(n, seed, top)
+    out, info = B.psd_project(x, n, tr, mode=1 if full else 0)
+    g_out, meta = gold[name + "__out"], gold[name + "__meta"]
+    scale = np.abs(x).max()
+    assert np.allclose(out, g_out, rtol=0, atol=2e-9 * scale), np.abs(out - g_out).max()
+    assert info["rank"] == int(meta[4])
+    assert abs(info["min_eig"] - meta[5]) <= 1e-9 * scale
+    if not full:
+        assert info["fell_back"] == 0
+        assert info["nmatvec"] == int(meta[6])
+    # and live against the oracle
+    o_out, o_rank, o_min, _ = oracle_project(x, n, tr, full)
+    assert np.allclose(out, o_out, rtol=0, atol=2e-9 * scale)
+
+
+def test_projection_properties_at_full_size():
+    """n = 4000: a planted rank-3 PSD matrix is a fixed point of the rank-4
+    projection; projecting X and -X splits X (Moreau) on the captured subspace."""
+    n, r = 4000, 3
+    rng = np.random.default_rng(3)
+    Z, _ = np.linalg.qr(rng.standard_normal((n, r)))
+    lam = np.array([300.0, 120.0, 45.0])
+    ii = np.concatenate([np.arange(j + 1) for j in range(n)])
+    jj = np.repeat(np.arange(n), np.arange(1, n + 1))
+    W = Z * lam
+    x = np.einsum("ik,ik->i", W[ii], Z[jj]) * np.where(ii == jj, 1.0, math.sqrt(2.0))
+    out, info = B.psd_project(x, n, 4)
+    # the 4th Ritz value is 0 up to rounding; `val > 0` (prox_operators.jl:101) may count it
+    assert info["rank"] in (3, 4) and info["fell_back"] == 0
+    assert np.abs(out - x).max() <= 1e-9 * np.abs(x).max()
+    out2, _ = B.psd_project(out, n, 4)                         # idempotence
+    assert np.abs(out2 - out).max() <= 1e-9 * np.abs(x).max()
+    neg, info_neg = B.psd_project(-x, n, 4)                    # -X has no positive part
+    assert np.abs(neg).max() <= 1e-9 * np.abs(x).max()
+
+
+# ----------------------------------------------------------------- solves
+def _gopt(**kw):
+    o = Optimizer(tol_gap=1e-6, tol_feasibility=1e-6, time_limit=30.0)
+    for k, v in kw.items():
+        o.set_attribute(k, v)
+    return o
+
+
+@pytest.mark.parametrize("name", list(KATS))
+def test_known_answers_and_golden_results(name, golden_dir):
+    """The reference's KATs (test/moi_proxsdp_unit.jl) on the HIP path, and the
+    oracle's committed final Result for the same problem."""
+    build, expected, atol, xexp = KATS[name]
+    gold = json.loads((golden_dir / "kat_results.json").read_text())[name]
+    opt = _gopt()
+    sol = opt.optimize(build())
+    assert opt.termination_status() == "OPTIMAL"
+    assert opt.primal_status() == "FEASIBLE_POINT" and opt.dual_status() == "FEASIBLE_POINT"
+    assert abs(opt.objective_value() - expected) <= atol
+    if xexp is not None:
+        assert np.allclose(opt.variable_primal(), xexp, atol=atol)
+    # against the oracle: identical algorithm in fp64 -> same iteration count, same numbers
+    assert sol.iter == gold["iter"] and sol.final_rank == gold["final_rank"]
+    assert abs(sol.objval - gold["objval"]) <= 1e-9 * (1 + abs(gold["objval"]))
+    assert abs(sol.dual_objval - gold["dual_objval"]) <= 1e-9 * (1 + abs(gold["dual_objval"]))
+    for key in ("primal", "dual_cone", "dual_eq", "dual_in", "slack_eq", "slack_in"):
+        assert np.allclose(getattr(sol, key), gold[key], rtol=0, atol=1e-8), key
+
+
+@pytest.mark.parametrize("settings", [
+    dict(eigsolver=1, min_size_krylov_eigs=1),
+    dict(eigsolver=2, min_size_krylov_eigs=1),
+    dict(full_eig_decomp=1),
+])
+def test_sdp_wiki_all_eig_paths(settings):
+    """moi_proxsdp_unit.jl:358-370."""
+    for mx, exp in ((False, -0.978), (True, 0.872)):
+        opt = _gopt(**settings)
+        sol = opt.optimize(sdp_wiki(mx))
+        assert opt.termination_status() == "OPTIMAL" and abs(opt.objective_value() - exp) <= 1e-2
+        if settings.get("eigsolver") == 2:
+            assert sol.stats["lanczos_matvecs"] > 0 and sol.stats["full_eigs"] == 0
+        if settings.get("eigsolver") == 1:
+            assert sol.stats["krylov_fallbacks"] == sol.iter      # ncv > n -> ARPACK error -> full_eig!
+
+
+def test_termination_statuses():
+    """test_terminationstatus.jl:40-73."""
+    opt = Optimizer()
+    opt.optimize(simple_lp())
+    assert opt.termination_status() == "OPTIMAL"
+    opt = Optimizer(max_iter=1)
+    opt.optimize(simple_lp())
+    assert opt.termination_status() == "ITERATION_LIMIT" and opt.pdhg_iterations() >= 0
+    opt = Optimizer(tol_gap=1e-16, tol_feasibility=1e-16, tol_primal=1e-16, tol_dual=1e-16,
+                    tol_feasibility_dual=1e-16, tol_psd=1e-16, time_limit=0.0)
+    opt.optimize(simple_lp())
+    assert opt.termination_status() == "TIME_LIMIT"
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 5])
+def test_mimo_property(n):
+    """moi_mimo.jl:71-75."""
+    opt = _gopt()
+    sol = opt.optimize(P.mimo(n, seed=123))
+    X = P.unpack_psd(sol.primal, n + 1)
+    assert opt.termination_status() == "OPTIMAL"
+    assert np.all(np.abs(X) > 0.99) and np.all(np.abs(X) < 1.01)
+
+
+@pytest.mark.parametrize("name", ["maxcut_readme_n4", "sdplib_mcp124-1", "maxcut_er_n200_s0"])
+def test_iteration_traces_match_golden(name, golden_dir):
+    """Per-iteration parity with the oracle's committed traces (fp64 both sides)."""
+    gold = json.loads((golden_dir / "traces.json").read_text())[name]
+    if name == "maxcut_readme_n4":
+        pr, iters = P.maxcut_readme(), 200
+    elif name == "sdplib_mcp124-1":
+        pr, iters = P.sdplib(golden_dir / "sdplib" / "mcp124-1.dat-s"), 120
+    else:
+        pr, iters = P.maxcut(200, seed=0), 120
+    opt = Optimizer(max_iter=iters)
+    sol = opt.optimize(pr, trace_capacity=iters)
+    rows = np.array(gold["rows"])
+    assert sol.status == gold["status"] and sol.iter == gold["iter"]
+    k = min(len(rows), len(sol.trace))
+    assert k == len(rows)
+    G, T = rows[:k], sol.trace[:k]
+    assert np.array_equal(T[:, 0], G[:, 0])                       # iter
+    assert np.array_equal(T[:, 10], G[:, 10])                     # target_rank schedule
+    assert np.array_equal(T[:, 11], G[:, 11])                     # linesearch trials
+    # Tight window: until the Lanczos first needs a restart (more than krylovdim = 25
+    # mat-vecs) both sides are the same fp64 computation up to summation order.  After
+    # that the rank-2 truncation sits on near-degenerate eigenvalues and the projection is
+    # ill-conditioned (measured drift ~1e-5 relative on mcp124-1, bounded); SURVEY.md
+    # section 8d: "looser after rank changes".
+    mv = T[:, 13]
+    tight = int(np.argmax(mv > 25)) if np.any(mv > 25) else k
+    tight = max(tight, 3)
+    for col, nm in ((1, "prim_obj"), (2, "dual_obj"), (7, "primal_step"), (8, "beta"), (9, "theta")):
+        assert np.allclose(T[:tight, col], G[:tight, col], rtol=1e-9, atol=1e-12), nm
+        assert np.allclose(T[:, col], G[:, col], rtol=1e-3, atol=1e-9), nm
+    for col, nm in ((3, "gap"), (4, "feas"), (5, "prim_res"), (6, "dual_res")):
+        assert np.allclose(T[:tight, col], G[:tight, col], rtol=1e-7, atol=1e-12), nm
+        assert np.allclose(T[:, col], G[:, col], rtol=5e-2, atol=1e-6), nm
+
+
+@pytest.mark.parametrize("fname,lit,tol", [("mcp124-1", -141.99, 1e-3), ("gpp124-2", 46.8623, 1e-3),
+                                           ("mcp124-1", -141.99, 1e-4)])
+def test_sdplib_against_oracle(fname, lit, tol, golden_dir):
+    """moitest.jl:119-143 on the HIP path, side by side with the oracle run on this
+    box's CPU: same status, both within the solver's own tolerances, objectives within
+    tol_gap*(1+|po|+|do|) of each other (the solver's own gap measure), lambda_min >= -1e-4."""
+    pr = P.sdplib(golden_dir / "sdplib" / f"{fname}.dat-s")
+    opt = Optimizer(tol_gap=tol, tol_feasibility=tol)
+    sol = opt.optimize(pr)
+    o = Options()
+    o.tol_gap = o.tol_feasibility = tol
+    ref = oracle.solve(pr, o)
+    X = P.unpack_psd(sol.primal, pr.psd_sides()[0])
+    assert sol.status == ref.status == 1
+    assert np.linalg.eigvalsh(X).min() >= -1e-4
+    diff = abs(opt.objective_value() - ref.objval)
+    print(f"{fname} tol={tol}: gpu obj {opt.objective_value():.8f} it {sol.iter}  oracle obj {ref.objval:.8f} "
+          f"it {ref.iter}  |diff| {diff:.3e}")
+    assert diff <= tol * (1 + abs(ref.objval) + abs(ref.dual_objval))
+    assert abs(opt.objective_value() - lit) <= 5 * tol * (1 + abs(lit))
+    assert sol.gap <= tol and sol.primal_feasible_user_tol
+    assert sol.stats["lanczos_matvecs"] > 0 and sol.stats["full_eigs"] == 0
+    assert abs(sol.iter - ref.iter) <= 0.25 * ref.iter
+
+
+def test_block_diagonal_model_two_blocks():
+    """Two independent MIMO instances in one block-diagonal model (the shape of the
+    'MIMO x 8 blocks' config) against the oracle."""
+    pr = P.block_diag_problems([P.mimo(6, seed=1), P.mimo(7, seed=2)])
+    opt = _gopt()
+    sol = opt.optimize(pr)
+    o = Options()
+    o.tol_gap = o.tol_feasibility = 1e-6
+    ref = oracle.solve(pr, o)
+    assert sol.status == ref.status == 1 and sol.iter == ref.iter
+    assert abs(sol.objval - ref.objval) <= 1e-8 * (1 + abs(ref.objval))
+    assert np.allclose(sol.primal, ref.primal, atol=1e-7)
+
+
+def test_maxcut_n1000_reaches_tolerance():
+    """BASELINE config 1 (Max-Cut ER n=1000, single PSD cone): converges to the solver's
+    own tolerances; the solution is feasible and PSD; weak duality holds."""
+    pr = P.maxcut(1000, seed=0)
+    opt = Optimizer(tol_gap=1e-4, tol_feasibility=1e-4, time_limit=600.0)
+    sol = opt.optimize(pr)
+    assert opt.termination_status() == "OPTIMAL"
+    assert sol.gap <= 1e-4 and sol.primal_feasible_user_tol
+    X = P.unpack_psd(sol.primal, 1000)
+    assert np.abs(np.diag(X) - 1).max() <= 1e-4 * (1 + math.sqrt(1000.0))     # equa_feasibility, residuals.jl:6-11
+    assert np.linalg.eigvalsh(X).min() >= -1e-6
+    assert sol.stats["lanczos_matvecs"] > 0

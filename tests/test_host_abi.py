@@ -1,0 +1,160 @@
+"""CPU-only tests of the C-ABI library: it loads without a GPU, exports every
+symbol include/proxsdp_hip.h declares, its options struct matches the
+reference's Options names/defaults, and its host-side logic (start vector,
+K x K eigen-solver, preprocess!/norm_scaling) agrees with the oracle.  No
+compute entry point is called successfully here (there is no GPU); they must
+fail loudly instead of falling back to a CPU path."""
+import ctypes
+import dataclasses
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import oracle
+from oracle import eig as oeig
+from oracle import pdhg as opdhg
+from proxsdp_jl_amd import binding as B
+from proxsdp_jl_amd import problems as P
+from proxsdp_jl_amd.optimizer import Optimizer
+
+from kat_problems import KATS, sdp_wiki
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    L = B.lib()
+    names = B.header_symbols()
+    assert len(names) >= 14
+    for name in names:
+        assert hasattr(L, name), f"{name} declared in include/proxsdp_hip.h but not exported"
+    assert L.proxsdp_hip_abi_version() == 1
+
+
+def test_options_struct_layout_and_defaults_match_reference_options():
+    o = B.default_options()
+    assert o.struct_size == ctypes.sizeof(B.Options)
+    ref = oracle.Options()
+    for f in dataclasses.fields(ref):
+        got = B.get_option(o, f.name)                      # by-name getter on the C side
+        assert got == pytest.approx(float(getattr(ref, f.name))), f.name
+        assert float(getattr(o, f.name)) == got, f"ctypes offset of {f.name} differs from the C struct"
+    # round trip through the by-name setter hits the same field ctypes sees
+    for k, (name, ctype) in enumerate(B.Options._fields_):
+        if name.startswith("pad") or name == "struct_size":
+            continue
+        B.set_option(o, name, 3 + k)
+        assert float(getattr(o, name)) == 3 + k, name
+
+
+def test_unknown_option_is_an_error():
+    """MOI_wrapper.jl:84-93 / moitest.jl:153-156."""
+    with pytest.raises(KeyError):
+        Optimizer(unsupportedarg=10)
+    opt = Optimizer(tol_gap=1e-6, max_iter=7)
+    assert opt.get_attribute("tol_gap") == 1e-6 and opt.get_attribute("max_iter") == 7
+
+
+def test_optimizer_attribute_plumbing():
+    """moitest.jl:25-32,158-171."""
+    m = Optimizer()
+    assert m.SOLVER_NAME == "ProxSDP" and m.termination_status() == "OPTIMIZE_NOT_CALLED"
+    assert m.time_limit_sec() is None
+    m.set_time_limit_sec(0.0)
+    assert m.time_limit_sec() == 0.0
+    m.set_time_limit_sec(None)
+    assert m.time_limit_sec() is None
+    m.set_time_limit_sec(1.0)
+    assert m.time_limit_sec() == 1.0
+    assert m.silent()
+    m.set_silent(False)
+    assert not m.silent()
+
+
+def test_no_cpu_fallback_without_a_device():
+    if B.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(B.ProxSDPHipError) as e:
+        B.solve(sdp_wiki(False))
+    assert e.value.code == -2                               # PROXSDP_E_HIP
+    with pytest.raises(B.ProxSDPHipError):
+        B.symv_packed(np.ones(6), 3, np.ones(3))
+
+
+def test_invalid_problem_is_rejected_before_touching_the_device():
+    pr = sdp_wiki(False)
+    pr.psd = [np.array([0, 1, 2, 3, 4])]                    # not a triangular number
+    with pytest.raises(B.ProxSDPHipError) as e:
+        B.solve(pr)
+    assert e.value.code == -1
+    pr = sdp_wiki(False)
+    pr.psd = [np.array([0, 1, 2, 3, 4, 4])]                 # repeated variable
+    with pytest.raises(B.ProxSDPHipError) as e:
+        B.solve(pr)
+    assert e.value.code == -1
+
+
+def test_start_vector_bit_identical_to_oracle():
+    for n, seed, init in [(1, 1234, 3), (7, 1234, 3), (1000, 1234, 3), (513, 99, 3), (64, 5, 2), (10, 1, 1)]:
+        a = B.host_start_vector(n, seed, init)
+        b = oeig.start_vector(n, seed, init)
+        assert np.array_equal(a, b), (n, seed, init)
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 5, 12, 25, 33, 64, 129])
+def test_small_symmetric_eigensolver(k):
+    rng = np.random.default_rng(k)
+    A = rng.standard_normal((k, k))
+    A = A + A.T
+    d, V = B.host_symeig(A)
+    ref = np.linalg.eigvalsh(A)
+    scale = max(1.0, np.abs(ref).max())
+    assert np.allclose(d, ref, rtol=0, atol=5e-14 * scale * k)
+    assert np.allclose(V.T @ V, np.eye(k), atol=1e-13 * k)
+    assert np.allclose(A @ V, V * d, atol=1e-12 * scale * k)
+
+
+def test_small_eigensolver_arrowhead_and_degenerate():
+    # the Rayleigh quotient right after a thick restart: diag + arrow row + tridiagonal tail
+    k = 25
+    rng = np.random.default_rng(0)
+    T = np.diag(np.sort(rng.uniform(-1, 40, k))[::-1])
+    T[15, :15] = T[:15, 15] = rng.standard_normal(15) * 1e-3
+    for j in range(15, k - 1):
+        T[j, j + 1] = T[j + 1, j] = rng.uniform(0.1, 2)
+    d, V = B.host_symeig(T)
+    assert np.allclose(d, np.linalg.eigvalsh(T), atol=1e-12)
+    assert np.allclose(T @ V, V * d, atol=1e-11)
+    # repeated eigenvalues and an exactly diagonal matrix
+    d, V = B.host_symeig(np.diag([2.0, 2.0, 2.0, -1.0]))
+    assert np.allclose(d, [-1, 2, 2, 2]) and np.allclose(V.T @ V, np.eye(4))
+    d, V = B.host_symeig(np.zeros((6, 6)))
+    assert np.allclose(d, 0) and np.allclose(V.T @ V, np.eye(6))
+
+
+@pytest.mark.parametrize("build", [lambda: P.maxcut(9, seed=3), lambda: P.mimo(4, seed=1),
+                                   lambda: KATS["double_sdp_from_moi"][0](),
+                                   lambda: P.randsdp(5, 4, seed=2)])
+def test_preprocess_matches_oracle(build):
+    """preprocess! + norm_scaling (scaling.jl) and ||M||_F (pdhg.jl:121)."""
+    pr = build()
+    order, inv, c_scaled, fro = B.host_preprocess(pr)
+    aff, cones = oracle.to_standard_form(pr)
+    c_orig, var_ordering = opdhg.preprocess(aff, cones)
+    opdhg.norm_scaling(aff, cones)
+    M = sp.vstack([aff.A, aff.G])
+    assert np.array_equal(inv, var_ordering)
+    assert np.array_equal(order, np.argsort(var_ordering))
+    assert np.allclose(c_scaled, aff.c, rtol=1e-15, atol=0)
+    assert fro == pytest.approx(np.sqrt((M.data ** 2).sum()), rel=1e-14)
+
+
+def test_preprocess_reorders_cone_variables_first():
+    # variables 0,1 free; PSD cone on (4,2,3) given out of order; SOC on (5,6)
+    A = sp.csc_matrix(np.arange(14, dtype=float).reshape(2, 7) + 1)
+    pr = P.Problem(n=7, A=A, b=np.ones(2), G=sp.csc_matrix((0, 7)), h=np.zeros(0),
+                   c=np.arange(7, dtype=float), psd=[np.array([4, 2, 3])], soc=[np.array([5, 6])])
+    order, inv, c_scaled, fro = B.host_preprocess(pr)
+    assert list(order) == [4, 2, 3, 5, 6, 0, 1]
+    assert list(inv) == [5, 6, 1, 2, 0, 3, 4]
+    s = np.sqrt(2) / 2
+    assert np.allclose(c_scaled, [4, 2 * s, 3, 5, 6, 0, 1])
