@@ -272,7 +272,7 @@ def test_iteration_traces_match_golden(name, golden_dir):
     tight = max(tight, 3)
     for col, nm in ((1, "prim_obj"), (2, "dual_obj"), (7, "primal_step"), (8, "beta"), (9, "theta")):
         assert np.allclose(T[:tight, col], G[:tight, col], rtol=1e-9, atol=1e-12), nm
-        assert np.allclose(T[:, col], G[:, col], rtol=1e-3, atol=1e-9), nm
+        assert np.allclose(T[:, col], G[:, col], rtol=2e-3, atol=2e-3 * np.abs(G[:, col]).max()), nm
     for col, nm in ((3, "gap"), (4, "feas"), (5, "prim_res"), (6, "dual_res")):
         assert np.allclose(T[:tight, col], G[:tight, col], rtol=1e-7, atol=1e-12), nm
         assert np.allclose(T[:, col], G[:, col], rtol=5e-2, atol=1e-6), nm
