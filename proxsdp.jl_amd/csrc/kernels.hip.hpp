@@ -87,78 +87,108 @@ __device__ __forceinline__ void tile_coords(int t, int& I, int& J) {
 // fill of the raw packed values, diagonal pre-multiplied by sqrt(2), so that
 // smat(xp) v = u / sqrt(2)  (the off-diagonals of xp carry a sqrt(2) factor,
 // prox_operators.jl:5-13).  Replaces dsymv('U') (eigsolver.jl:678 / KrylovKit).
+// Bound: HBM -- 8*N bytes of the packed triangle per mat-vec, read once.
 //
-// One workgroup per 64x64 tile (I<=J) of the upper block-triangle.  Lane = row,
-// each wave owns 16 tile columns, so every global load instruction of a wave
-// reads 512 contiguous bytes of one packed column.  The tile contributes
-//   rows of block I :  sum_c T[r,c] v[J*64+c]      (row sums,   slot J)
-//   rows of block J :  sum_r T[r,c] v[I*64+r]      (column sums, slot I)
-// written to Ppart[slot][row]; every (slot,row) is written exactly once per
-// mat-vec, so no zero-fill and no atomics -- the consumer sums the nt slots in
-// a fixed order (deterministic).
+// One workgroup (4 waves) per 64x64 tile (I<=J) of the upper block-triangle.
+// Lane = tile row, each wave owns 16 tile columns and issues its 16 column loads
+// back to back (each load instruction reads 512 contiguous bytes of one packed
+// column), then
+//   row sums   : racc += T[r,c] * v[J*64+c]        (v[J*64+c] is wave-uniform:
+//                scalar loads), the 4 waves' partial row sums meet once in LDS
+//   column sums: in-register transpose-reduce of T[r,c]*v[I*64+r]: 4 fold stages
+//                halve the live columns per lane (8+4+2+1 exchanges), two plain
+//                exchanges finish -- 17 lane exchanges for 16 columns instead of
+//                16 full wave reductions, and no LDS round trip of the tile.
+// The tile contributes rows of block I (slot J, row sums) and rows of block J
+// (slot I, column sums) to Ppart[slot][row]; every (slot,row) is written exactly
+// once per mat-vec: no zero-fill, no atomics, and the consumer sums the nt slots
+// in a fixed order (deterministic).
 // ---------------------------------------------------------------------------
+template <int H, int NARR>
+__device__ __forceinline__ void fold_stage(double (&t)[NARR], int lane) {
+    // lanes whose bit H is set keep columns [H,2H) of the current set, the others [0,H)
+    const bool upper = (lane & H) != 0;
+#pragma unroll
+    for (int m = 0; m < H; ++m) {
+        const double lo = t[m], hi = t[m + H];
+        const double send = upper ? lo : hi;
+        const double keep = upper ? hi : lo;
+        t[m] = keep + __shfl_xor(send, H, WAVE);
+    }
+}
+
+// One workgroup (4 waves) per 64x64 tile; wave w owns tile columns [16w, 16w+16).
 __global__ void __launch_bounds__(TPB)
 k_symv_packed(const double* __restrict__ xp, int n, int nt, int npad,
               const double* __restrict__ v, double* __restrict__ Ppart,
               const LanczosCtl* __restrict__ ctl) {
     if (ctl != nullptr && ctl->stop) return;
-    __shared__ double s_vI[TILE], s_vJ[TILE];
-    __shared__ double s_prod[TILE][TILE + 1];   // [col][row], padded
     __shared__ double s_row[NWAVE][TILE];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int I, J;
     tile_coords(blockIdx.x, I, J);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (threadIdx.x < TILE) {
-        int gi = I * TILE + threadIdx.x;
-        s_vI[threadIdx.x] = gi < n ? v[gi] : 0.0;
-    } else if (threadIdx.x < 2 * TILE) {
-        int gj = J * TILE + threadIdx.x - TILE;
-        s_vJ[threadIdx.x - TILE] = gj < n ? v[gj] : 0.0;
-    }
     const int gi = I * TILE + lane;
-    double t[CPW];
+    const int j0 = J * TILE + wv * CPW;              // first global column of this wave
+    const double* __restrict__ vJ = v + j0;          // uniform address: scalar loads
+    const double vi = v[gi];                         // v is zero-padded to npad
     const bool diag = (I == J);
+    const bool interior = (I < J) && (J * TILE + TILE <= n);
+    double t[CPW];
+    if (interior) {
+        const double* __restrict__ xrow = xp + gi;
 #pragma unroll
-    for (int k = 0; k < CPW; ++k) {
-        const int c = w * CPW + k;
-        const int gj = J * TILE + c;
-        double val = 0.0;
-        if (gj < n && gi < n && gi <= gj) {
-            val = xp[(long long)gj * (gj + 1) / 2 + gi];
-            if (diag && gi == gj) val *= SQRT2;
+        for (int c = 0; c < CPW; ++c) {
+            const long long gj = j0 + c;
+            t[c] = xrow[gj * (gj + 1) / 2];
         }
-        t[k] = val;
-    }
-    __syncthreads();
-    const double vi = s_vI[lane];
-    double rowacc = 0.0;
+    } else {
+        // diagonal / ragged tiles: unconditional loads from clamped (always valid)
+        // addresses, masked afterwards -- a branch per load would serialise the
+        // memory round trips
+        const int gic = min(gi, n - 1);
 #pragma unroll
-    for (int k = 0; k < CPW; ++k) {
-        const int c = w * CPW + k;
-        rowacc += t[k] * s_vJ[c];
-        // column-sum contribution; on a diagonal tile the diagonal entry itself
-        // must be counted once only (it is in the row sum)
-        double pc = t[k] * vi;
-        if (diag && lane == c) pc = 0.0;
-        s_prod[c][lane] = pc;
-    }
-    s_row[w][lane] = rowacc;
-    __syncthreads();
-    if (threadIdx.x < TILE) {
-        const int r = threadIdx.x;
-        double rs = (s_row[0][r] + s_row[1][r]) + (s_row[2][r] + s_row[3][r]);
-        double cs = 0.0;
-#pragma unroll 8
-        for (int l = 0; l < TILE; ++l) cs += s_prod[r][l];   // column r of the tile
-        if (diag) {
-            const int g = I * TILE + r;
-            if (g < npad) Ppart[(long long)I * npad + g] = rs + cs;
-        } else {
-            const int grow = I * TILE + r;     // rows of block I, slot J
-            if (grow < npad) Ppart[(long long)J * npad + grow] = rs;
-            const int gcol = J * TILE + r;     // rows of block J, slot I
-            if (gcol < npad) Ppart[(long long)I * npad + gcol] = cs;
+        for (int c = 0; c < CPW; ++c) {
+            const int gj = j0 + c;
+            const int gjc = min(gj, n - 1);
+            const double a = xp[(long long)gjc * (gjc + 1) / 2 + min(gic, gjc)];
+            const bool ok = (gj < n) && (gi < n) && (gi <= gj);
+            // the diagonal entry is counted once (row sum), as X_ii = xp_ii
+            t[c] = ok ? ((diag && gi == gj) ? a * SQRT2 : a) : 0.0;
         }
+    }
+    double racc = 0.0;
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        racc += t[c] * vJ[c];
+        t[c] *= vi;
+        if (diag && gi == j0 + c) t[c] = 0.0;        // the diagonal entry is in the row sum only
+    }
+    s_row[wv][lane] = racc;
+    // column sums: fold 16 columns over lane bits 3..0, then all-reduce over bits 4,5
+    fold_stage<8>(t, lane);
+    fold_stage<4>(t, lane);
+    fold_stage<2>(t, lane);
+    fold_stage<1>(t, lane);
+    double cs = t[0];
+    cs += __shfl_xor(cs, 16, WAVE);
+    cs += __shfl_xor(cs, 32, WAVE);                  // column (lane & 15) of this wave's strip
+    __syncthreads();
+    if (diag) {
+        // rows of block I get row sums and column sums (same slot)
+        __shared__ double s_col[TILE];
+        if (lane < CPW) s_col[wv * CPW + lane] = cs;
+        __syncthreads();
+        if (wv == 0) {
+            const double rs = (s_row[0][lane] + s_row[1][lane]) + (s_row[2][lane] + s_row[3][lane]);
+            Ppart[(long long)I * npad + gi] = rs + s_col[lane];
+        }
+    } else {
+        if (wv == 0) {
+            const double rs = (s_row[0][lane] + s_row[1][lane]) + (s_row[2][lane] + s_row[3][lane]);
+            Ppart[(long long)J * npad + gi] = rs;                    // rows of block I, slot J
+        }
+        if (lane < CPW) Ppart[(long long)I * npad + j0 + lane] = cs; // rows of block J, slot I
     }
 }
 
@@ -167,25 +197,31 @@ k_symv_packed(const double* __restrict__ xp, int n, int nt, int npad,
 // passes against the whole basis), scalars kept on the device: replaces the
 // BLAS-1 work inside KrylovKit's LanczosIterator (call site eigsolver.jl:802).
 //   dots1      : w = (sum of symv partials)/sqrt2 ; hpart = V[:,0..k]' w
-//   apply_dots : w -= V h ; hpart2 = V' w
-//   apply_norm : w -= V h2 ; nrmpart = |w|^2
+//   apply<0>   : w -= V h ; hpart2 = V' w
+//   apply<1>   : w -= V h2 ; nrmpart = |w|^2
 //   finish     : alpha_k = h[k]+h2[k]; beta_k = |w|; V[:,k+1] = w/beta_k, or stop
-// Grid = ceil(n/256) workgroups, one row per thread.
+// Grid = nt workgroups of 64 rows; the 4 waves of a workgroup split the slots
+// (dots1) and the basis columns j (all kernels) and meet in LDS.  These kernels
+// are latency-bound (n*K*8 bytes of L2-resident basis), so the point of the
+// layout is parallel width, not bytes.
 // ---------------------------------------------------------------------------
 constexpr int MAXK = 160;           // capacity of the Krylov basis (krylovdim+1 <= MAXK)
+constexpr int LZ_ROWS = TILE;       // rows per workgroup in the Lanczos vector kernels
 
-__device__ __forceinline__ void dots_against_basis(const double* __restrict__ V, int ldv, int kk,
-                                                   int i, bool valid, double wi,
-                                                   double* __restrict__ hpart_wg, double (*s_h)[NWAVE]) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int j = 0; j < kk; ++j) {
-        double p = valid ? V[(long long)j * ldv + i] * wi : 0.0;
-        p = wave_sum(p);
-        if (lane == 0) s_h[j][w] = p;
+// dots of this workgroup's 64 rows of w against basis columns j = wv, wv+4, ... < kk
+__device__ __forceinline__ void lz_dots(const double* __restrict__ V, int ldv, int kk, int i, double wi,
+                                        int wv, int lane, double* __restrict__ hpart_wg) {
+    for (int j = wv; j < kk; j += 2 * NWAVE) {
+        const int j2 = j + NWAVE;
+        double p0 = V[(long long)j * ldv + i] * wi;
+        double p1 = (j2 < kk) ? V[(long long)j2 * ldv + i] * wi : 0.0;
+        p0 = wave_sum(p0);
+        p1 = wave_sum(p1);
+        if (lane == 0) {
+            hpart_wg[j] = p0;
+            if (j2 < kk) hpart_wg[j2] = p1;
+        }
     }
-    __syncthreads();
-    for (int j = threadIdx.x; j < kk; j += TPB)
-        hpart_wg[j] = (s_h[j][0] + s_h[j][1]) + (s_h[j][2] + s_h[j][3]);
 }
 
 __global__ void __launch_bounds__(TPB)
@@ -193,16 +229,16 @@ k_lz_dots1(const double* __restrict__ Ppart, int nt, int n, int npad,
            const double* __restrict__ V, int ldv, int k,
            double* __restrict__ wbuf, double* __restrict__ hpart, const LanczosCtl* __restrict__ ctl) {
     if (ctl->stop) return;
-    __shared__ double s_h[MAXK][NWAVE];
-    const int i = blockIdx.x * TPB + threadIdx.x;
-    const bool valid = i < n;
-    double wi = 0.0;
-    if (valid) {
-        for (int s = 0; s < nt; ++s) wi += Ppart[(long long)s * npad + i];
-        wi *= INV_SQRT2;
-        wbuf[i] = wi;
-    }
-    dots_against_basis(V, ldv, k + 1, i, valid, wi, hpart + (long long)blockIdx.x * MAXK, s_h);
+    __shared__ double s_acc[NWAVE][LZ_ROWS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = blockIdx.x * LZ_ROWS + lane;       // < npad always; rows >= n carry zeros
+    double a = 0.0;
+    for (int s = wv; s < nt; s += NWAVE) a += Ppart[(long long)s * npad + i];
+    s_acc[wv][lane] = a;
+    __syncthreads();
+    const double wi = ((s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane])) * INV_SQRT2;
+    if (wv == 0) wbuf[i] = wi;
+    lz_dots(V, ldv, k + 1, i, wi, wv, lane, hpart + (long long)blockIdx.x * MAXK);
 }
 
 // mode 0: apply + second dots; mode 1: apply + squared norm
@@ -212,30 +248,36 @@ k_lz_apply(double* __restrict__ wbuf, int n, const double* __restrict__ V, int l
            const double* __restrict__ hpart_in, int nwg, double* __restrict__ hsum_out,
            double* __restrict__ part_out, const LanczosCtl* __restrict__ ctl) {
     if (ctl->stop) return;
-    __shared__ double s_hsum[MAXK];
-    __shared__ double s_h[MAXK][NWAVE];
-    __shared__ double s_red[NWAVE];
+    __shared__ double s_h[MAXK];
+    __shared__ double s_d[NWAVE][LZ_ROWS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int kk = k + 1;
-    for (int j = threadIdx.x; j < kk; j += TPB) {
+    // h_j = sum over workgroups of the partial dots (fixed order: lane-strided, then shuffle tree)
+    for (int j = wv; j < kk; j += NWAVE) {
         double h = 0.0;
-        for (int g = 0; g < nwg; ++g) h += hpart_in[(long long)g * MAXK + j];
-        s_hsum[j] = h;
-        if (blockIdx.x == 0) hsum_out[j] = h;
+        for (int g = lane; g < nwg; g += WAVE) h += hpart_in[(long long)g * MAXK + j];
+        h = wave_sum(h);
+        if (lane == 0) {
+            s_h[j] = h;
+            if (blockIdx.x == 0) hsum_out[j] = h;
+        }
     }
     __syncthreads();
-    const int i = blockIdx.x * TPB + threadIdx.x;
-    const bool valid = i < n;
-    double wi = 0.0;
-    if (valid) {
-        wi = wbuf[i];
-        for (int j = 0; j < kk; ++j) wi -= V[(long long)j * ldv + i] * s_hsum[j];
-        wbuf[i] = wi;
-    }
+    const int i = blockIdx.x * LZ_ROWS + lane;
+    double d = 0.0;
+    for (int j = wv; j < kk; j += NWAVE) d += V[(long long)j * ldv + i] * s_h[j];
+    s_d[wv][lane] = d;
+    __syncthreads();
+    const double wi = wbuf[i] - ((s_d[0][lane] + s_d[1][lane]) + (s_d[2][lane] + s_d[3][lane]));
+    __syncthreads();                                   // every wave has read wbuf[i] before wave 0 rewrites it
+    if (wv == 0) wbuf[i] = wi;
     if (MODE == 0) {
-        dots_against_basis(V, ldv, kk, i, valid, wi, part_out + (long long)blockIdx.x * MAXK, s_h);
+        lz_dots(V, ldv, kk, i, wi, wv, lane, part_out + (long long)blockIdx.x * MAXK);
     } else {
-        double r = block_sum(valid ? wi * wi : 0.0, s_red);
-        if (threadIdx.x == 0) part_out[blockIdx.x] = r;
+        if (wv == 0) {
+            const double r = wave_sum(wi * wi);
+            if (lane == 0) part_out[blockIdx.x] = r;
+        }
     }
 }
 
@@ -244,20 +286,26 @@ k_lz_finish(const double* __restrict__ wbuf, int n, const double* __restrict__ n
             double* __restrict__ V, int ldv, int k, const double* __restrict__ h1, const double* __restrict__ h2,
             double* __restrict__ alphas, double* __restrict__ betas, LanczosCtl* __restrict__ ctl, double tol) {
     if (ctl->stop) return;
-    double ss = 0.0;
-    for (int g = 0; g < nwg; ++g) ss += nrmpart[g];
-    const double beta = sqrt(ss);
+    __shared__ double s_beta;
+    if (threadIdx.x < WAVE) {
+        double ss = 0.0;
+        for (int g = threadIdx.x; g < nwg; g += WAVE) ss += nrmpart[g];
+        ss = wave_sum(ss);
+        if (threadIdx.x == 0) s_beta = sqrt(ss);
+    }
+    __syncthreads();
+    const double beta = s_beta;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         alphas[k] = h1[k] + h2[k];
         betas[k] = beta;
     }
-    const int i = blockIdx.x * TPB + threadIdx.x;
     if (beta <= tol) {
-        // every workgroup sees the same beta; the flag is only READ by later
+        // every workgroup computes the same beta; the flag is only READ by later
         // launches (stream order), so a plain store by one thread is enough
         if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->kstop = k + 1; ctl->stop = 1; }
         return;
     }
+    const int i = blockIdx.x * TPB + threadIdx.x;
     if (i < n) V[(long long)(k + 1) * ldv + i] = wbuf[i] / beta;
 }
 

@@ -229,9 +229,9 @@ inline void Solver::alloc_eigwork(EigWork& W, int n, int max_nev) {
     W.Z.alloc((size_t)W.npad * W.cap);
     W.w.alloc(W.npad);
     W.Ppart.alloc((size_t)W.nt * W.npad);
-    W.hpart1.alloc((size_t)W.nwg * dev::MAXK);
-    W.hpart2.alloc((size_t)W.nwg * dev::MAXK);
-    W.nrmpart.alloc(W.nwg);
+    W.hpart1.alloc((size_t)W.nt * dev::MAXK);       // one row of partial dots per 64-row workgroup
+    W.hpart2.alloc((size_t)W.nt * dev::MAXK);
+    W.nrmpart.alloc(W.nt);
     W.hsum1.alloc(dev::MAXK); W.hsum2.alloc(dev::MAXK);
     W.alphas.alloc(dev::MAXK); W.betas.alloc(dev::MAXK);
     W.U.alloc((size_t)dev::MAXK * dev::MAXK);
@@ -256,7 +256,7 @@ inline void Solver::setup_device() {
 
 // ------------------------------------------------------------------ kernels launch helpers
 inline void Solver::launch_symv(EigWork& W, const double* xp, const double* v, bool use_ctl) {
-    const int ntile = W.nt * (W.nt + 1) / 2;
+    const int ntile = W.nt * (W.nt + 1) / 2;      // one workgroup per 64x64 tile
     bool prof = opt.profile_symv_every > 0 && (st.symv_launches % opt.profile_symv_every) == 0;
     size_t slot = 0;
     if (prof) {
@@ -330,14 +330,14 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev) {
     while (true) {
         for (int k = kfirst; k < krylovdim; ++k) {
             launch_symv(W, xp, W.V.p + (size_t)k * W.npad, true);
-            hipLaunchKernelGGL(dev::k_lz_dots1, dim3(W.nwg), dim3(dev::TPB), 0, stream,
+            hipLaunchKernelGGL(dev::k_lz_dots1, dim3(W.nt), dim3(dev::TPB), 0, stream,
                                W.Ppart.p, W.nt, W.n, W.npad, W.V.p, W.npad, k, W.w.p, W.hpart1.p, W.ctl.p);
-            hipLaunchKernelGGL(dev::k_lz_apply<0>, dim3(W.nwg), dim3(dev::TPB), 0, stream,
-                               W.w.p, W.n, W.V.p, W.npad, k, W.hpart1.p, W.nwg, W.hsum1.p, W.hpart2.p, W.ctl.p);
-            hipLaunchKernelGGL(dev::k_lz_apply<1>, dim3(W.nwg), dim3(dev::TPB), 0, stream,
-                               W.w.p, W.n, W.V.p, W.npad, k, W.hpart2.p, W.nwg, W.hsum2.p, W.nrmpart.p, W.ctl.p);
+            hipLaunchKernelGGL(dev::k_lz_apply<0>, dim3(W.nt), dim3(dev::TPB), 0, stream,
+                               W.w.p, W.n, W.V.p, W.npad, k, W.hpart1.p, W.nt, W.hsum1.p, W.hpart2.p, W.ctl.p);
+            hipLaunchKernelGGL(dev::k_lz_apply<1>, dim3(W.nt), dim3(dev::TPB), 0, stream,
+                               W.w.p, W.n, W.V.p, W.npad, k, W.hpart2.p, W.nt, W.hsum2.p, W.nrmpart.p, W.ctl.p);
             hipLaunchKernelGGL(dev::k_lz_finish, dim3(W.nwg), dim3(dev::TPB), 0, stream,
-                               W.w.p, W.n, W.nrmpart.p, W.nwg, W.V.p, W.npad, k, W.hsum1.p, W.hsum2.p,
+                               W.w.p, W.n, W.nrmpart.p, W.nt, W.V.p, W.npad, k, W.hsum1.p, W.hsum2.p,
                                W.alphas.p, W.betas.p, W.ctl.p, step_tol);
         }
         W.alphas.download(al.data(), krylovdim, stream);
