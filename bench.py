@@ -17,7 +17,7 @@ collective, scaling "weak"; value = total iterations of all ranks / max time.
 
 Extra objects on the JSON line: "roofline" for the dominant kernel
 (k_symv_packed; HIP events recorded by the library on its own stream around
-every 4th launch inside the timed solve) and "cpu_baseline" (the NumPy/SciPy
+every 16th launch inside the timed solve) and "cpu_baseline" (the NumPy/SciPy
 oracle -- a restatement, NOT the Julia reference, which cannot run here -- on a
 bounded sample of the same instance, rank 0, N = 1 only).
 """
@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--time-to-tol", action="store_true",
                     help="also run the full solve to tol 1e-4 and report time_to_tol_s")
-    ap.add_argument("--profile-every", type=int, default=4)
+    ap.add_argument("--profile-every", type=int, default=16)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

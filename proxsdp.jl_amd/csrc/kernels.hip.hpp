@@ -35,17 +35,68 @@ struct LanczosCtl {                 // device-resident control block of one PSD 
     int pad[2];
 };
 
+// ---- cross-lane primitives (gfx950).  __shfl_* lowers to ds_bpermute_b32 (an LDS
+// round trip, ~100+ cycles) per 32-bit half; the reductions below are latency
+// chains, so they use DPP row shifts / broadcasts (a few cycles each) instead.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double dpp_f64(double old, double v) {
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROW_MASK, BANK_MASK, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROW_MASK, BANK_MASK, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double bcast_lane63(double v) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+// sum over the 64 lanes, result in EVERY lane.  Fixed shape: row_shr 1,2,4,8 inside
+// each row of 16, row_bcast15 into rows 1/3, row_bcast31 into rows 2/3, lane 63 holds
+// the total.  Must be called by a full wave.
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
-    return v;                       // valid in lane 0
+    v += dpp_f64<0x111, 0xF, 0xF>(0.0, v);      // row_shr:1
+    v += dpp_f64<0x112, 0xF, 0xF>(0.0, v);      // row_shr:2
+    v += dpp_f64<0x114, 0xF, 0xF>(0.0, v);      // row_shr:4
+    v += dpp_f64<0x118, 0xF, 0xF>(0.0, v);      // row_shr:8
+    v += dpp_f64<0x142, 0xA, 0xF>(0.0, v);      // row_bcast:15 -> rows 1,3
+    v += dpp_f64<0x143, 0xC, 0xF>(0.0, v);      // row_bcast:31 -> rows 2,3
+    return bcast_lane63(v);
 }
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, WAVE));
-    return v;
+    v = fmax(v, dpp_f64<0x111, 0xF, 0xF>(v, v));
+    v = fmax(v, dpp_f64<0x112, 0xF, 0xF>(v, v));
+    v = fmax(v, dpp_f64<0x114, 0xF, 0xF>(v, v));
+    v = fmax(v, dpp_f64<0x118, 0xF, 0xF>(v, v));
+    v = fmax(v, dpp_f64<0x142, 0xA, 0xF>(v, v));
+    v = fmax(v, dpp_f64<0x143, 0xC, 0xF>(v, v));
+    return bcast_lane63(v);
 }
-// block-wide sum; result valid in thread 0.  `sm` needs NWAVE doubles.
+// value of lane (lane ^ H); H = 1, 2, 4, 8 by DPP (quad_perm / row shifts / row_ror)
+template <int H>
+__device__ __forceinline__ double lane_xor(double v) {
+    if constexpr (H == 1) return dpp_f64<0xB1, 0xF, 0xF>(v, v);          // quad_perm [1,0,3,2]
+    else if constexpr (H == 2) return dpp_f64<0x4E, 0xF, 0xF>(v, v);     // quad_perm [2,3,0,1]
+    else if constexpr (H == 4) {
+        double t = dpp_f64<0x104, 0xF, 0x5>(v, v);                      // row_shl:4 into banks 0,2
+        return dpp_f64<0x114, 0xF, 0xA>(t, v);                          // row_shr:4 into banks 1,3
+    } else if constexpr (H == 8) return dpp_f64<0x128, 0xF, 0xF>(v, v);  // row_ror:8
+    else return __shfl_xor(v, H, WAVE);
+}
+// v + (value of lane ^ 16) and v + (value of lane ^ 32) through the gfx950
+// v_permlane16_swap / v_permlane32_swap instructions (no LDS)
+__device__ __forceinline__ double add_xor16(double v) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+__device__ __forceinline__ double add_xor32(double v) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+// block-wide sum; result valid in thread 0.  `sm` needs NWAVE doubles.  Must be
+// called by every thread of the workgroup.
 __device__ __forceinline__ double block_sum(double v, double* sm) {
     v = wave_sum(v);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -113,7 +164,7 @@ __device__ __forceinline__ void fold_stage(double (&t)[NARR], int lane) {
         const double lo = t[m], hi = t[m + H];
         const double send = upper ? lo : hi;
         const double keep = upper ? hi : lo;
-        t[m] = keep + __shfl_xor(send, H, WAVE);
+        t[m] = keep + lane_xor<H>(send);
     }
 }
 
@@ -170,9 +221,8 @@ k_symv_packed(const double* __restrict__ xp, int n, int nt, int npad,
     fold_stage<4>(t, lane);
     fold_stage<2>(t, lane);
     fold_stage<1>(t, lane);
-    double cs = t[0];
-    cs += __shfl_xor(cs, 16, WAVE);
-    cs += __shfl_xor(cs, 32, WAVE);                  // column (lane & 15) of this wave's strip
+    double cs = add_xor16(t[0]);
+    cs = add_xor32(cs);                              // column (lane & 15) of this wave's strip
     __syncthreads();
     if (diag) {
         // rows of block I get row sums and column sums (same slot)
@@ -196,21 +246,26 @@ k_symv_packed(const double* __restrict__ xp, int n, int nt, int npad,
 // Lanczos recurrence with full re-orthogonalisation (two classical Gram-Schmidt
 // passes against the whole basis), scalars kept on the device: replaces the
 // BLAS-1 work inside KrylovKit's LanczosIterator (call site eigsolver.jl:802).
-//   dots1      : w = (sum of symv partials)/sqrt2 ; hpart = V[:,0..k]' w
-//   apply<0>   : w -= V h ; hpart2 = V' w
-//   apply<1>   : w -= V h2 ; nrmpart = |w|^2
-//   finish     : alpha_k = h[k]+h2[k]; beta_k = |w|; V[:,k+1] = w/beta_k, or stop
+//   dots1  : w = (sum of symv partials)/sqrt2 ; hpart = V[:,0..k]' w
+//   apply  : w' = w - V h1 ; hpart2 = V' w' and |w'|^2
+//   finish : beta_k^2 = |w'|^2 - |h2|^2 ; alpha_k = h1[k]+h2[k] ; V[:,k+1] = (w' - V h2)/beta_k, or stop
+// Three dependent launches per Lanczos step after the mat-vec (each boundary is a
+// global reduction).
 // Grid = nt workgroups of 64 rows; the 4 waves of a workgroup split the slots
 // (dots1) and the basis columns j (all kernels) and meet in LDS.  These kernels
 // are latency-bound (n*K*8 bytes of L2-resident basis), so the point of the
 // layout is parallel width, not bytes.
 // ---------------------------------------------------------------------------
-constexpr int MAXK = 160;           // capacity of the Krylov basis (krylovdim+1 <= MAXK)
+constexpr int MAXK = 160;           // capacity of the Krylov basis (krylovdim+1 < MAXK)
 constexpr int LZ_ROWS = TILE;       // rows per workgroup in the Lanczos vector kernels
+constexpr int NRM_SLOT = MAXK - 1;  // slot of a partial-dots row that carries |w'|^2
 
+// Partial dots live column-major over workgroups: hpart[j * pld + g] (pld = number of
+// workgroups rounded up to 64, padding stays zero), so that the consumer reads the
+// partials of one basis column with ONE coalesced load per wave.
 // dots of this workgroup's 64 rows of w against basis columns j = wv, wv+4, ... < kk
 __device__ __forceinline__ void lz_dots(const double* __restrict__ V, int ldv, int kk, int i, double wi,
-                                        int wv, int lane, double* __restrict__ hpart_wg) {
+                                        int wv, int lane, double* __restrict__ hpart, int pld, int g) {
     for (int j = wv; j < kk; j += 2 * NWAVE) {
         const int j2 = j + NWAVE;
         double p0 = V[(long long)j * ldv + i] * wi;
@@ -218,85 +273,118 @@ __device__ __forceinline__ void lz_dots(const double* __restrict__ V, int ldv, i
         p0 = wave_sum(p0);
         p1 = wave_sum(p1);
         if (lane == 0) {
-            hpart_wg[j] = p0;
-            if (j2 < kk) hpart_wg[j2] = p1;
+            hpart[(long long)j * pld + g] = p0;
+            if (j2 < kk) hpart[(long long)j2 * pld + g] = p1;
         }
     }
+}
+// s_h[j] = sum over workgroups of the partials of column j, j < kk and j == NRM_SLOT when
+// `with_norm`: one coalesced load + one DPP wave reduction per column (fixed order).
+// Ends with a barrier.
+__device__ __forceinline__ void lz_reduce_partials(const double* __restrict__ hpart, int pld, int kk,
+                                                   bool with_norm, double* __restrict__ s_h) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int total = kk + (with_norm ? 1 : 0);
+    for (int jj = wv; jj < total; jj += 2 * NWAVE) {
+        const int ja = (jj < kk) ? jj : NRM_SLOT;
+        const int j2 = jj + NWAVE;
+        const int jb = (j2 < kk) ? j2 : NRM_SLOT;
+        double ha = 0.0, hb = 0.0;
+        for (int g = lane; g < pld; g += WAVE) {
+            ha += hpart[(long long)ja * pld + g];
+            if (j2 < total) hb += hpart[(long long)jb * pld + g];
+        }
+        ha = wave_sum(ha);
+        hb = wave_sum(hb);
+        if (lane == 0) {
+            s_h[ja] = ha;
+            if (j2 < total) s_h[jb] = hb;
+        }
+    }
+    __syncthreads();
 }
 
 __global__ void __launch_bounds__(TPB)
 k_lz_dots1(const double* __restrict__ Ppart, int nt, int n, int npad,
            const double* __restrict__ V, int ldv, int k,
-           double* __restrict__ wbuf, double* __restrict__ hpart, const LanczosCtl* __restrict__ ctl) {
+           double* __restrict__ wbuf, double* __restrict__ hpart, int pld, const LanczosCtl* __restrict__ ctl) {
     if (ctl->stop) return;
     __shared__ double s_acc[NWAVE][LZ_ROWS];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int i = blockIdx.x * LZ_ROWS + lane;       // < npad always; rows >= n carry zeros
-    double a = 0.0;
-    for (int s = wv; s < nt; s += NWAVE) a += Ppart[(long long)s * npad + i];
-    s_acc[wv][lane] = a;
+    double a0 = 0.0, a1 = 0.0;
+    int s = wv;
+    for (; s + NWAVE < nt; s += 2 * NWAVE) {
+        a0 += Ppart[(long long)s * npad + i];
+        a1 += Ppart[(long long)(s + NWAVE) * npad + i];
+    }
+    if (s < nt) a0 += Ppart[(long long)s * npad + i];
+    s_acc[wv][lane] = a0 + a1;
     __syncthreads();
     const double wi = ((s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane])) * INV_SQRT2;
     if (wv == 0) wbuf[i] = wi;
-    lz_dots(V, ldv, k + 1, i, wi, wv, lane, hpart + (long long)blockIdx.x * MAXK);
+    lz_dots(V, ldv, k + 1, i, wi, wv, lane, hpart, pld, blockIdx.x);
 }
 
-// mode 0: apply + second dots; mode 1: apply + squared norm
-template <int MODE>
+// first Gram-Schmidt pass applied, second pass measured:
+//   h1 = sum of partial dots;  w' = w - V h1;  hpart_out = V' w' and |w'|^2 (slot NRM_SLOT)
 __global__ void __launch_bounds__(TPB)
 k_lz_apply(double* __restrict__ wbuf, int n, const double* __restrict__ V, int ldv, int k,
-           const double* __restrict__ hpart_in, int nwg, double* __restrict__ hsum_out,
-           double* __restrict__ part_out, const LanczosCtl* __restrict__ ctl) {
+           const double* __restrict__ hpart_in, int pld, double* __restrict__ hsum_out,
+           double* __restrict__ hpart_out, const LanczosCtl* __restrict__ ctl) {
     if (ctl->stop) return;
     __shared__ double s_h[MAXK];
     __shared__ double s_d[NWAVE][LZ_ROWS];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int kk = k + 1;
-    // h_j = sum over workgroups of the partial dots (fixed order: lane-strided, then shuffle tree)
-    for (int j = wv; j < kk; j += NWAVE) {
-        double h = 0.0;
-        for (int g = lane; g < nwg; g += WAVE) h += hpart_in[(long long)g * MAXK + j];
-        h = wave_sum(h);
-        if (lane == 0) {
-            s_h[j] = h;
-            if (blockIdx.x == 0) hsum_out[j] = h;
-        }
-    }
+    lz_reduce_partials(hpart_in, pld, kk, false, s_h);
+    if (blockIdx.x == 0)
+        for (int j = threadIdx.x; j < kk; j += TPB) hsum_out[j] = s_h[j];
+    const int i = blockIdx.x * LZ_ROWS + lane;
+    double d = 0.0;
+    for (int j = wv; j < kk; j += NWAVE) d += V[(long long)j * ldv + i] * s_h[j];
+    s_d[wv][lane] = d;
+    const double w0 = wbuf[i];
     __syncthreads();
+    const double wi = w0 - ((s_d[0][lane] + s_d[1][lane]) + (s_d[2][lane] + s_d[3][lane]));
+    if (wv == 0) {
+        wbuf[i] = wi;
+        const double r = wave_sum(wi * wi);
+        if (lane == 0) hpart_out[(long long)NRM_SLOT * pld + blockIdx.x] = r;
+    }
+    lz_dots(V, ldv, kk, i, wi, wv, lane, hpart_out, pld, blockIdx.x);
+}
+
+// second pass applied and the step closed in ONE kernel:
+//   h2 = sum of partial dots;  beta^2 = |w'|^2 - |h2|^2  (= |w' - V h2|^2 exactly, V being
+//   orthonormal; h2 is the rounding-level second-pass correction, so nothing cancels
+//   unless w' itself is numerically inside span(V), where beta <= tol ends the run anyway);
+//   alpha_k = h1[k] + h2[k];  V[:,k+1] = (w' - V h2)/beta, or stop when beta <= tol.
+__global__ void __launch_bounds__(TPB)
+k_lz_finish(const double* __restrict__ wbuf, int n, double* __restrict__ V, int ldv, int k,
+            const double* __restrict__ hpart_in, int pld, const double* __restrict__ h1,
+            double* __restrict__ alphas, double* __restrict__ betas, LanczosCtl* __restrict__ ctl, double tol) {
+    if (ctl->stop) return;
+    __shared__ double s_h[MAXK];
+    __shared__ double s_d[NWAVE][LZ_ROWS];
+    __shared__ double s_beta;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int kk = k + 1;
+    lz_reduce_partials(hpart_in, pld, kk, true, s_h);
+    if (wv == 0) {
+        double hh = 0.0;
+        for (int j = lane; j < kk; j += WAVE) hh += s_h[j] * s_h[j];
+        hh = wave_sum(hh);
+        if (lane == 0) s_beta = sqrt(fmax(s_h[NRM_SLOT] - hh, 0.0));
+    }
     const int i = blockIdx.x * LZ_ROWS + lane;
     double d = 0.0;
     for (int j = wv; j < kk; j += NWAVE) d += V[(long long)j * ldv + i] * s_h[j];
     s_d[wv][lane] = d;
     __syncthreads();
-    const double wi = wbuf[i] - ((s_d[0][lane] + s_d[1][lane]) + (s_d[2][lane] + s_d[3][lane]));
-    __syncthreads();                                   // every wave has read wbuf[i] before wave 0 rewrites it
-    if (wv == 0) wbuf[i] = wi;
-    if (MODE == 0) {
-        lz_dots(V, ldv, kk, i, wi, wv, lane, part_out + (long long)blockIdx.x * MAXK);
-    } else {
-        if (wv == 0) {
-            const double r = wave_sum(wi * wi);
-            if (lane == 0) part_out[blockIdx.x] = r;
-        }
-    }
-}
-
-__global__ void __launch_bounds__(TPB)
-k_lz_finish(const double* __restrict__ wbuf, int n, const double* __restrict__ nrmpart, int nwg,
-            double* __restrict__ V, int ldv, int k, const double* __restrict__ h1, const double* __restrict__ h2,
-            double* __restrict__ alphas, double* __restrict__ betas, LanczosCtl* __restrict__ ctl, double tol) {
-    if (ctl->stop) return;
-    __shared__ double s_beta;
-    if (threadIdx.x < WAVE) {
-        double ss = 0.0;
-        for (int g = threadIdx.x; g < nwg; g += WAVE) ss += nrmpart[g];
-        ss = wave_sum(ss);
-        if (threadIdx.x == 0) s_beta = sqrt(ss);
-    }
-    __syncthreads();
     const double beta = s_beta;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        alphas[k] = h1[k] + h2[k];
+        alphas[k] = h1[k] + s_h[k];
         betas[k] = beta;
     }
     if (beta <= tol) {
@@ -305,8 +393,10 @@ k_lz_finish(const double* __restrict__ wbuf, int n, const double* __restrict__ n
         if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->kstop = k + 1; ctl->stop = 1; }
         return;
     }
-    const int i = blockIdx.x * TPB + threadIdx.x;
-    if (i < n) V[(long long)(k + 1) * ldv + i] = wbuf[i] / beta;
+    if (wv == 0) {
+        const double wi = wbuf[i] - ((s_d[0][lane] + s_d[1][lane]) + (s_d[2][lane] + s_d[3][lane]));
+        V[(long long)(k + 1) * ldv + i] = wi / beta;          // rows >= n stay zero
+    }
 }
 
 // out[:, c] = sum_j V[:, j] U[j, c]  (basis rotation at a thick restart and the

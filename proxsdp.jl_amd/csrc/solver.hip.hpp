@@ -98,10 +98,10 @@ struct CircularVector {
 
 // ------------------------------------------------------------------ per-block Lanczos workspace
 struct EigWork {
-    int n = 0, nt = 0, npad = 0, nwg = 0, cap = 0;   // cap = columns of V (krylovdim_max + 1)
+    int n = 0, nt = 0, npad = 0, nwg = 0, cap = 0, pld = 0;   // cap = columns of V (krylovdim_max + 1)
     int64_t N = 0;
     DevBuf<double> V, Z;            // npad x cap each (V: Krylov basis, Z: rotation target / Ritz vectors)
-    DevBuf<double> w, Ppart, hpart1, hpart2, nrmpart, hsum1, hsum2, alphas, betas, U, lam, resid;
+    DevBuf<double> w, Ppart, hpart1, hpart2, hsum1, alphas, betas, U, lam, resid;
     DevBuf<dev::LanczosCtl> ctl;
     // full-eig fallback
     DevBuf<double> A, D, E;
@@ -223,23 +223,24 @@ inline void Solver::alloc_eigwork(EigWork& W, int n, int max_nev) {
     W.nwg = ceil_div(n, dev::TPB);
     int kd = std::max(2 * max_nev + 1, (int)opt.eigsolver_min_lanczos);
     W.cap = kd + 1;
-    if (W.cap > dev::MAXK)
+    if (W.cap >= dev::NRM_SLOT)
         throw std::invalid_argument("krylov dimension exceeds the library limit (raise dev::MAXK)");
     W.V.alloc((size_t)W.npad * W.cap);
     W.Z.alloc((size_t)W.npad * W.cap);
     W.w.alloc(W.npad);
     W.Ppart.alloc((size_t)W.nt * W.npad);
-    W.hpart1.alloc((size_t)W.nt * dev::MAXK);       // one row of partial dots per 64-row workgroup
-    W.hpart2.alloc((size_t)W.nt * dev::MAXK);
-    W.nrmpart.alloc(W.nt);
-    W.hsum1.alloc(dev::MAXK); W.hsum2.alloc(dev::MAXK);
+    W.pld = ceil_div(W.nt, dev::WAVE) * dev::WAVE;   // partial dots: [MAXK][pld], padding stays zero
+    W.hpart1.alloc((size_t)W.pld * dev::MAXK);
+    W.hpart2.alloc((size_t)W.pld * dev::MAXK);
+    W.hpart1.zero(stream); W.hpart2.zero(stream);
+    W.hsum1.alloc(dev::MAXK);
     W.alphas.alloc(dev::MAXK); W.betas.alloc(dev::MAXK);
     W.U.alloc((size_t)dev::MAXK * dev::MAXK);
     W.lam.alloc(std::max(n, dev::MAXK));
     W.resid.alloc(W.npad);
     W.ctl.alloc(1);
     W.V.zero(stream); W.Z.zero(stream); W.w.zero(stream);
-    W.hsum1.zero(stream); W.hsum2.zero(stream); W.alphas.zero(stream); W.betas.zero(stream);
+    W.hsum1.zero(stream); W.alphas.zero(stream); W.betas.zero(stream);
     W.resid.zero(stream);
 }
 
@@ -331,13 +332,11 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev) {
         for (int k = kfirst; k < krylovdim; ++k) {
             launch_symv(W, xp, W.V.p + (size_t)k * W.npad, true);
             hipLaunchKernelGGL(dev::k_lz_dots1, dim3(W.nt), dim3(dev::TPB), 0, stream,
-                               W.Ppart.p, W.nt, W.n, W.npad, W.V.p, W.npad, k, W.w.p, W.hpart1.p, W.ctl.p);
-            hipLaunchKernelGGL(dev::k_lz_apply<0>, dim3(W.nt), dim3(dev::TPB), 0, stream,
-                               W.w.p, W.n, W.V.p, W.npad, k, W.hpart1.p, W.nt, W.hsum1.p, W.hpart2.p, W.ctl.p);
-            hipLaunchKernelGGL(dev::k_lz_apply<1>, dim3(W.nt), dim3(dev::TPB), 0, stream,
-                               W.w.p, W.n, W.V.p, W.npad, k, W.hpart2.p, W.nt, W.hsum2.p, W.nrmpart.p, W.ctl.p);
-            hipLaunchKernelGGL(dev::k_lz_finish, dim3(W.nwg), dim3(dev::TPB), 0, stream,
-                               W.w.p, W.n, W.nrmpart.p, W.nt, W.V.p, W.npad, k, W.hsum1.p, W.hsum2.p,
+                               W.Ppart.p, W.nt, W.n, W.npad, W.V.p, W.npad, k, W.w.p, W.hpart1.p, W.pld, W.ctl.p);
+            hipLaunchKernelGGL(dev::k_lz_apply, dim3(W.nt), dim3(dev::TPB), 0, stream,
+                               W.w.p, W.n, W.V.p, W.npad, k, W.hpart1.p, W.pld, W.hsum1.p, W.hpart2.p, W.ctl.p);
+            hipLaunchKernelGGL(dev::k_lz_finish, dim3(W.nt), dim3(dev::TPB), 0, stream,
+                               W.w.p, W.n, W.V.p, W.npad, k, W.hpart2.p, W.pld, W.hsum1.p,
                                W.alphas.p, W.betas.p, W.ctl.p, step_tol);
         }
         W.alphas.download(al.data(), krylovdim, stream);
