@@ -44,8 +44,10 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline sample budget")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--time-to-tol", action="store_true",
-                    help="also run the full solve to tol 1e-4 and report time_to_tol_s")
+    ap.add_argument("--no-time-to-tol", action="store_true",
+                    help="skip the full solve to tol 1e-4 (time_to_tol object)")
+    ap.add_argument("--krylov-rank", type=int, default=64,
+                    help="max_target_rank_krylov_eigs for the time-to-tol leg (metric: rank ~ sqrt(n))")
     ap.add_argument("--profile-every", type=int, default=16)
     args = ap.parse_args()
 
@@ -118,13 +120,22 @@ def main():
         "solve_wall_s": wall, "init_s": st["init_time"], "exit_s": st["exit_time"],
     }
 
-    if rank == 0 and world == 1 and args.time_to_tol:
-        o2 = Optimizer(device_id=local_rank, time_limit=600.0)
+    if rank == 0 and world == 1 and not args.no_time_to_tol:
+        # second half of the metric: wall time to status OPTIMAL at tol_gap = tol_feasibility = 1e-4.
+        # With the reference default max_target_rank_krylov_eigs = 16 the solve falls into a full
+        # eigendecomposition per iteration once target_rank reaches 17 (prox_operators.jl:46-49);
+        # the metric's "rank ~ sqrt(n)" regime keeps the Lanczos path, so the knob is raised here
+        # (and must be raised identically for any CPU comparison).
+        o2 = Optimizer(device_id=local_rank, time_limit=300.0, max_target_rank_krylov_eigs=args.krylov_rank)
         s2 = o2.optimize(pr)
         out["time_to_tol"] = {"status": o2.termination_status(), "time_s": s2.time, "iterations": int(s2.iter),
                               "objective": o2.objective_value(), "gap": s2.gap,
                               "whole_solve_it_per_s": s2.iter / max(s2.stats["loop_time"], 1e-9),
-                              "final_rank": int(s2.final_rank)}
+                              "final_rank": int(s2.final_rank),
+                              "lanczos_matvecs": int(s2.stats["lanczos_matvecs"]),
+                              "lanczos_restarts": int(s2.stats["lanczos_restarts"]),
+                              "full_eigs": int(s2.stats["full_eigs"]),
+                              "options": {"max_target_rank_krylov_eigs": args.krylov_rank}}
 
     if rank == 0 and world == 1 and not args.no_cpu:
         import oracle                                           # baseline leg only

@@ -4,7 +4,8 @@ from proxsdp_jl_amd import problems as P
 from proxsdp_jl_amd.optimizer import Optimizer
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
 pr = P.maxcut(n, seed=0)
-o = Optimizer(time_limit=240.0, profile_symv_every=16)
+import os
+o = Optimizer(time_limit=240.0, profile_symv_every=16, max_target_rank_krylov_eigs=int(os.environ.get('KR','64')))
 t=time.time(); s = o.optimize(pr, trace_capacity=20000); wall=time.time()-t
 tr = s.trace
 print(json.dumps(dict(n=n, status=o.termination_status(), iters=int(s.iter), time=s.time, wall=wall, obj=o.objective_value(), gap=s.gap,

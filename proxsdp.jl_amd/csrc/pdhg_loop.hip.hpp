@@ -363,6 +363,9 @@ inline void Solver::run() {
 
     // ---- device state ("Init", pdhg.jl:54-142)
     setup_device();
+    bool big_block = false;
+    for (const BlockInfo& B : P.blocks) big_block = big_block || B.n >= 256;
+    if (big_block) start_rocsolver_warmup();
     for (int k = 0; k < 2; ++k) {
         xbuf[k].alloc(P.n); Mtybuf[k].alloc(P.n);
         ybuf[k].alloc(std::max<int64_t>(P.Q, 1)); Mxbuf[k].alloc(std::max<int64_t>(P.Q, 1));
@@ -460,9 +463,13 @@ inline void Solver::run() {
         iter = k;
         lz_matvec_iter = 0; recon_r_iter = 0;
         primal_step_dev();
+        const double tl0 = now_s();
         if (opt.line_search_flag) last_trials = linesearch();
         else { dual_step_plain(); last_trials = 1; }
+        const double tl1 = now_s();
         residual_and_gap();
+        st.t_linesearch += tl1 - tl0;
+        st.t_residual += now_s() - tl1;
         {   // algorithmic bytes of this iteration
             const double t = (double)last_trials;
             double bb = 8.0 * (double)P.n * (11.0 + 3.0 * t) + 12.0 * (double)P.nnz * (1.0 + t) +
@@ -642,6 +649,7 @@ inline void Solver::run() {
     }
     PX_HIP(hipStreamSynchronize(stream));
     st.loop_time = now_s() - t_loop0;
+    if (warm.joinable()) warm.join();
 
     // ---- results (pdhg.jl:486-529)
     if (opt.certificate_search && certificate_search) {

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "host_util.hpp"
@@ -107,6 +108,8 @@ struct EigWork {
     DevBuf<double> A, D, E;
     DevBuf<rocblas_int> info;
     std::vector<double> resid_host;
+    std::vector<double> Ustage[2];
+    int ustage_next = 0;
     // results of the last call
     std::vector<double> vals;
     int count = 0, converged_eigs = 0, numiter = 0;
@@ -130,6 +133,7 @@ public:
         time0 = now_s();
     }
     ~Solver() {
+        if (warm.joinable()) warm.join();
         for (auto e : ev.e0) (void)hipEventDestroy(e);
         for (auto e : ev.e1) (void)hipEventDestroy(e);
         if (blas) (void)rocblas_destroy_handle(blas);
@@ -162,6 +166,8 @@ public:
     proxsdp_stats st{};
     double time0 = 0;
     const double* user_resid = nullptr;
+    std::thread warm;               // loads rocSOLVER's code objects while the loop runs
+    void start_rocsolver_warmup();
 
 private:
     // device state
@@ -255,6 +261,38 @@ inline void Solver::setup_device() {
     PX_ROC(rocblas_set_stream(blas, stream));
 }
 
+// rocSOLVER's first dsyevd in a process pays ~3 s of code-object loading.  The exit path
+// (cone_feas, pdhg.jl:685) always needs one; do a 2x2 dummy on a private handle/stream in
+// the background so that cost overlaps the PDHG loop instead of adding to SolveTimeSec.
+inline void Solver::start_rocsolver_warmup() {
+    const int dev_id = opt.device_id;
+    warm = std::thread([dev_id]() {
+        if (hipSetDevice(dev_id) != hipSuccess) return;
+        hipStream_t s = nullptr;
+        rocblas_handle h = nullptr;
+        if (hipStreamCreate(&s) != hipSuccess) return;
+        if (rocblas_create_handle(&h) == rocblas_status_success) {
+            (void)rocblas_set_stream(h, s);
+            double* buf = nullptr;
+            rocblas_int* info = nullptr;
+            const int n = 96;                           // large enough to take the blocked path
+            if (hipMalloc((void**)&buf, sizeof(double) * (n * n + 2 * n)) == hipSuccess &&
+                hipMalloc((void**)&info, sizeof(rocblas_int)) == hipSuccess) {
+                (void)hipMemsetAsync(buf, 0, sizeof(double) * (n * n + 2 * n), s);
+                (void)rocsolver_dsyevd(h, rocblas_evect_original, rocblas_fill_upper, n, buf, n,
+                                       buf + n * n, buf + n * n + n, info);
+                (void)rocsolver_dsyevd(h, rocblas_evect_none, rocblas_fill_upper, n, buf, n,
+                                       buf + n * n, buf + n * n + n, info);
+                (void)hipStreamSynchronize(s);
+            }
+            if (buf) (void)hipFree(buf);
+            if (info) (void)hipFree(info);
+            (void)rocblas_destroy_handle(h);
+        }
+        (void)hipStreamDestroy(s);
+    });
+}
+
 // ------------------------------------------------------------------ kernels launch helpers
 inline void Solver::launch_symv(EigWork& W, const double* xp, const double* v, bool use_ctl) {
     const int ntile = W.nt * (W.nt + 1) / 2;      // one workgroup per 64x64 tile
@@ -284,12 +322,15 @@ inline void Solver::launch_reconstruct(EigWork& W, const double* Z, int ldz, con
 
 inline void Solver::rotate(EigWork& W, int K, const std::vector<double>& U, int ldu, int ncols,
                            double* out, int copy_src, int copy_dst) {
-    // U: host column-major (ldu x >=ncols); upload the K x ncols part compactly
-    std::vector<double> tmp((size_t)K * std::max(ncols, 1));
+    // U: host column-major (ldu x >=ncols); upload the K x ncols part compactly from a
+    // staging buffer that alternates between two slots: two rotations can be in flight
+    // between host synchronisations (restart rotation, then the final Ritz-vector one)
+    std::vector<double>& tmp = W.Ustage[W.ustage_next];
+    W.ustage_next ^= 1;
+    tmp.resize((size_t)K * std::max(ncols, 1));
     for (int c = 0; c < ncols; ++c)
         for (int j = 0; j < K; ++j) tmp[(size_t)c * K + j] = U[(size_t)c * ldu + j];
     W.U.upload(tmp.data(), (size_t)K * ncols, stream);
-    PX_HIP(hipStreamSynchronize(stream));          // tmp is stack-scoped host memory
     const int maxcols = std::max(1, (int)(40 * 1024 / (8 * K)));   // keep dynamic LDS <= 40 KiB
     int c0 = 0;
     do {
@@ -378,7 +419,9 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev) {
             for (int c = 0; c < K; ++c)
                 for (int r = 0; r < K; ++r) Tw[(size_t)c * K + r] = T[(size_t)c * ld + r];
             std::vector<double> Dasc(K);
+            const double te0 = now_s();
             symeig_dense(K, Tw.data(), Dasc.data());
+            st.t_primal += now_s() - te0;            // (field reused: host K x K eigensolves)
             U.assign((size_t)K * K, 0.0);
             for (int c = 0; c < K; ++c) {                // :LR -> descending
                 D[c] = Dasc[K - 1 - c];
