@@ -51,26 +51,20 @@ def main():
     ap.add_argument("--profile-every", type=int, default=16)
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
+    from proxsdp_jl_amd import binding, problems, replicas
+    from proxsdp_jl_amd.optimizer import Optimizer
+    rank, local_rank, world = replicas.rank_info()
     dist = None
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-
-    from proxsdp_jl_amd import binding, problems
-    from proxsdp_jl_amd.optimizer import Optimizer
+        dist = replicas.init("nccl", rank, world, device=torch.device("cuda", local_rank))
 
     if binding.device_count() <= 0:
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     n = args.n
     K, W = args.steps, args.warmup
-    pr = problems.maxcut(n, seed=args.seed + rank)
+    pr = problems.maxcut(n, seed=replicas.replica_seed(args.seed, rank))
     N = n * (n + 1) // 2
 
     def sync():
@@ -89,11 +83,8 @@ def main():
         raise SystemExit(f"solve stopped after {len(tr)} iterations (< warmup+steps): status {sol.status}")
     t_start = tr[W - 1, 12] if W > 0 else 0.0
     t_steps = float(tr[W + K - 1, 12] - t_start)
-    if dist is not None:
-        t = torch.tensor([t_steps], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        t_steps = float(t.item())
-    value = world * K / t_steps
+    total_steps, t_steps = replicas.aggregate(dist, K, t_steps, device="cuda" if dist is not None else "cpu")
+    value = total_steps / t_steps
 
     st = sol.stats
     symv_ms = st["symv_profiled_ms"] / max(1, st["symv_profiled"])
