@@ -33,6 +33,7 @@ struct LanczosCtl {                 // device-resident control block of one PSD 
     int stop;                       // set when beta <= tol (invariant subspace)
     int kstop;                      // basis size at which it stopped
     int pad[2];
+    double carry;                   // h2[k] of the last closed step (alpha correction, see k_symv_finish)
 };
 
 // ---- cross-lane primitives (gfx950).  __shfl_* lowers to ds_bpermute_b32 (an LDS
@@ -169,16 +170,13 @@ __device__ __forceinline__ void fold_stage(double (&t)[NARR], int lane) {
 }
 
 // One workgroup (4 waves) per 64x64 tile; wave w owns tile columns [16w, 16w+16).
-__global__ void __launch_bounds__(TPB)
-k_symv_packed(const double* __restrict__ xp, int n, int nt, int npad,
-              const double* __restrict__ v, double* __restrict__ Ppart,
-              const LanczosCtl* __restrict__ ctl) {
-    if (ctl != nullptr && ctl->stop) return;
-    __shared__ double s_row[NWAVE][TILE];
+__device__ __forceinline__ void symv_tile(const double* __restrict__ xp, int n, int npad,
+                                          const double* __restrict__ v, double* __restrict__ Ppart,
+                                          int tile, double* __restrict__ s_row, double* __restrict__ s_col) {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int I, J;
-    tile_coords(blockIdx.x, I, J);
+    tile_coords(tile, I, J);
     const int gi = I * TILE + lane;
     const int j0 = J * TILE + wv * CPW;              // first global column of this wave
     const double* __restrict__ vJ = v + j0;          // uniform address: scalar loads
@@ -215,7 +213,7 @@ k_symv_packed(const double* __restrict__ xp, int n, int nt, int npad,
         t[c] *= vi;
         if (diag && gi == j0 + c) t[c] = 0.0;        // the diagonal entry is in the row sum only
     }
-    s_row[wv][lane] = racc;
+    s_row[wv * TILE + lane] = racc;
     // column sums: fold 16 columns over lane bits 3..0, then all-reduce over bits 4,5
     fold_stage<8>(t, lane);
     fold_stage<4>(t, lane);
@@ -226,20 +224,29 @@ k_symv_packed(const double* __restrict__ xp, int n, int nt, int npad,
     __syncthreads();
     if (diag) {
         // rows of block I get row sums and column sums (same slot)
-        __shared__ double s_col[TILE];
         if (lane < CPW) s_col[wv * CPW + lane] = cs;
         __syncthreads();
         if (wv == 0) {
-            const double rs = (s_row[0][lane] + s_row[1][lane]) + (s_row[2][lane] + s_row[3][lane]);
+            const double rs = (s_row[lane] + s_row[TILE + lane]) + (s_row[2 * TILE + lane] + s_row[3 * TILE + lane]);
             Ppart[(long long)I * npad + gi] = rs + s_col[lane];
         }
     } else {
         if (wv == 0) {
-            const double rs = (s_row[0][lane] + s_row[1][lane]) + (s_row[2][lane] + s_row[3][lane]);
+            const double rs = (s_row[lane] + s_row[TILE + lane]) + (s_row[2 * TILE + lane] + s_row[3 * TILE + lane]);
             Ppart[(long long)J * npad + gi] = rs;                    // rows of block I, slot J
         }
         if (lane < CPW) Ppart[(long long)I * npad + j0 + lane] = cs; // rows of block J, slot I
     }
+}
+
+__global__ void __launch_bounds__(TPB)
+k_symv_packed(const double* __restrict__ xp, int n, int nt, int npad,
+              const double* __restrict__ v, double* __restrict__ Ppart,
+              const LanczosCtl* __restrict__ ctl) {
+    if (ctl != nullptr && ctl->stop) return;
+    __shared__ double s_row[NWAVE * TILE];
+    __shared__ double s_col[TILE];
+    symv_tile(xp, n, npad, v, Ppart, blockIdx.x, s_row, s_col);
 }
 
 // ---------------------------------------------------------------------------
@@ -307,9 +314,12 @@ __device__ __forceinline__ void lz_reduce_partials(const double* __restrict__ hp
 __global__ void __launch_bounds__(TPB)
 k_lz_dots1(const double* __restrict__ Ppart, int nt, int n, int npad,
            const double* __restrict__ V, int ldv, int k,
-           double* __restrict__ wbuf, double* __restrict__ hpart, int pld, const LanczosCtl* __restrict__ ctl) {
+           double* __restrict__ wbuf, double* __restrict__ hpart, int pld, const LanczosCtl* __restrict__ ctl,
+           const double* __restrict__ betas, int scale_idx) {
     if (ctl->stop) return;
     __shared__ double s_acc[NWAVE][LZ_ROWS];
+    // the mat-vec ran on the un-normalised w' of step scale_idx (see k_symv_finish)
+    const double scale = (scale_idx >= 0) ? INV_SQRT2 / betas[scale_idx] : INV_SQRT2;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int i = blockIdx.x * LZ_ROWS + lane;       // < npad always; rows >= n carry zeros
     double a0 = 0.0, a1 = 0.0;
@@ -321,7 +331,7 @@ k_lz_dots1(const double* __restrict__ Ppart, int nt, int n, int npad,
     if (s < nt) a0 += Ppart[(long long)s * npad + i];
     s_acc[wv][lane] = a0 + a1;
     __syncthreads();
-    const double wi = ((s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane])) * INV_SQRT2;
+    const double wi = ((s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane])) * scale;
     if (wv == 0) wbuf[i] = wi;
     lz_dots(V, ldv, k + 1, i, wi, wv, lane, hpart, pld, blockIdx.x);
 }
@@ -355,19 +365,19 @@ k_lz_apply(double* __restrict__ wbuf, int n, const double* __restrict__ V, int l
     lz_dots(V, ldv, kk, i, wi, wv, lane, hpart_out, pld, blockIdx.x);
 }
 
-// second pass applied and the step closed in ONE kernel:
+// second pass applied and the step closed:
 //   h2 = sum of partial dots;  beta^2 = |w'|^2 - |h2|^2  (= |w' - V h2|^2 exactly, V being
 //   orthonormal; h2 is the rounding-level second-pass correction, so nothing cancels
 //   unless w' itself is numerically inside span(V), where beta <= tol ends the run anyway);
-//   alpha_k = h1[k] + h2[k];  V[:,k+1] = (w' - V h2)/beta, or stop when beta <= tol.
-__global__ void __launch_bounds__(TPB)
-k_lz_finish(const double* __restrict__ wbuf, int n, double* __restrict__ V, int ldv, int k,
-            const double* __restrict__ hpart_in, int pld, const double* __restrict__ h1,
-            double* __restrict__ alphas, double* __restrict__ betas, LanczosCtl* __restrict__ ctl, double tol) {
-    if (ctl->stop) return;
-    __shared__ double s_h[MAXK];
-    __shared__ double s_d[NWAVE][LZ_ROWS];
-    __shared__ double s_beta;
+//   alpha_k = h1[k] + h2[k] - carry;  V[:,k+1] = (w' - V h2)/beta, or stop when beta <= tol.
+// `g` = index of the 64-row group handled by this workgroup.
+__device__ __forceinline__ void lz_finish_body(const double* __restrict__ wbuf, double* __restrict__ V, int ldv, int k,
+                                               const double* __restrict__ hpart_in, int pld,
+                                               const double* __restrict__ h1, double* __restrict__ alphas,
+                                               double* __restrict__ betas, LanczosCtl* __restrict__ ctl,
+                                               double tol, int use_carry, int g,
+                                               double* __restrict__ s_h, double* __restrict__ s_d,
+                                               double* __restrict__ s_beta) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int kk = k + 1;
     lz_reduce_partials(hpart_in, pld, kk, true, s_h);
@@ -375,28 +385,65 @@ k_lz_finish(const double* __restrict__ wbuf, int n, double* __restrict__ V, int 
         double hh = 0.0;
         for (int j = lane; j < kk; j += WAVE) hh += s_h[j] * s_h[j];
         hh = wave_sum(hh);
-        if (lane == 0) s_beta = sqrt(fmax(s_h[NRM_SLOT] - hh, 0.0));
+        if (lane == 0) *s_beta = sqrt(fmax(s_h[NRM_SLOT] - hh, 0.0));
     }
-    const int i = blockIdx.x * LZ_ROWS + lane;
+    const int i = g * LZ_ROWS + lane;
     double d = 0.0;
     for (int j = wv; j < kk; j += NWAVE) d += V[(long long)j * ldv + i] * s_h[j];
-    s_d[wv][lane] = d;
+    s_d[wv * LZ_ROWS + lane] = d;
     __syncthreads();
-    const double beta = s_beta;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        alphas[k] = h1[k] + s_h[k];
+    const double beta = *s_beta;
+    if (g == 0 && threadIdx.x == 0) {
+        alphas[k] = h1[k] + s_h[k] - (use_carry ? ctl->carry : 0.0);
         betas[k] = beta;
+        ctl->carry = s_h[k];
     }
     if (beta <= tol) {
         // every workgroup computes the same beta; the flag is only READ by later
         // launches (stream order), so a plain store by one thread is enough
-        if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->kstop = k + 1; ctl->stop = 1; }
+        if (g == 0 && threadIdx.x == 0) { ctl->kstop = k + 1; ctl->stop = 1; }
         return;
     }
     if (wv == 0) {
-        const double wi = wbuf[i] - ((s_d[0][lane] + s_d[1][lane]) + (s_d[2][lane] + s_d[3][lane]));
+        const double wi = wbuf[i] - ((s_d[lane] + s_d[LZ_ROWS + lane]) + (s_d[2 * LZ_ROWS + lane] + s_d[3 * LZ_ROWS + lane]));
         V[(long long)(k + 1) * ldv + i] = wi / beta;          // rows >= n stay zero
     }
+}
+
+__global__ void __launch_bounds__(TPB)
+k_lz_finish(const double* __restrict__ wbuf, int n, double* __restrict__ V, int ldv, int k,
+            const double* __restrict__ hpart_in, int pld, const double* __restrict__ h1,
+            double* __restrict__ alphas, double* __restrict__ betas, LanczosCtl* __restrict__ ctl, double tol,
+            int use_carry) {
+    if (ctl->stop) return;
+    __shared__ double s_h[MAXK];
+    __shared__ double s_d[NWAVE * LZ_ROWS];
+    __shared__ double s_beta;
+    lz_finish_body(wbuf, V, ldv, k, hpart_in, pld, h1, alphas, betas, ctl, tol, use_carry, blockIdx.x, s_h, s_d, &s_beta);
+}
+
+// The step-closing work of step k and the mat-vec of step k+1 in ONE launch.
+// v_{k+1} = (w' - V h2)/beta is only known after the closing reductions, but
+//     A (w'/beta) = A v_{k+1} + [ V (T h2) + beta v_{k+1} h2[k] ] / beta
+// and the bracket lies in span(V, v_{k+1}), which the Gram-Schmidt passes of step k+1
+// remove anyway; so the mat-vec runs on w' (ready before the closing work), the 1/beta
+// is applied by k_lz_dots1, and alpha_{k+1} gets the exact correction -h2[k] (`carry`).
+// Workgroups [0, nt) close step k, workgroups [nt, nt + ntile) are mat-vec tiles.
+__global__ void __launch_bounds__(TPB)
+k_symv_finish(const double* __restrict__ xp, int n, int nt, int npad, double* __restrict__ Ppart,
+              const double* __restrict__ wbuf, double* __restrict__ V, int ldv, int k,
+              const double* __restrict__ hpart_in, int pld, const double* __restrict__ h1,
+              double* __restrict__ alphas, double* __restrict__ betas, LanczosCtl* __restrict__ ctl, double tol,
+              int use_carry) {
+    if (ctl->stop) return;
+    __shared__ double s_a[MAXK > NWAVE * TILE ? MAXK : NWAVE * TILE];   // s_h   | s_row
+    __shared__ double s_b[NWAVE * LZ_ROWS];                             // s_d   | s_col
+    __shared__ double s_beta;
+    if ((int)blockIdx.x < nt)
+        lz_finish_body(wbuf, V, ldv, k, hpart_in, pld, h1, alphas, betas, ctl, tol, use_carry, blockIdx.x,
+                       s_a, s_b, &s_beta);
+    else
+        symv_tile(xp, n, npad, wbuf, Ppart, (int)blockIdx.x - nt, s_a, s_b);
 }
 
 // out[:, c] = sum_j V[:, j] U[j, c]  (basis rotation at a thick restart and the

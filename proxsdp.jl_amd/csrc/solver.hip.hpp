@@ -147,6 +147,7 @@ public:
     void lanczos(EigWork& W, const double* xp, int nev);
     void full_eig_values(EigWork& W, const double* xp, double offscale, bool vectors, std::vector<double>& Dhost);
     void launch_symv(EigWork& W, const double* xp, const double* v, bool use_ctl);
+    void launch_symv_finish(EigWork& W, const double* xp, int kclose, double tol, bool use_carry);
     void launch_reconstruct(EigWork& W, const double* Z, int ldz, const double* lam, int r, double* xp_out);
     void rotate(EigWork& W, int K, const std::vector<double>& U, int ldu, int ncols, double* out, int copy_src, int copy_dst);
 
@@ -314,6 +315,28 @@ inline void Solver::launch_symv(EigWork& W, const double* xp, const double* v, b
     st.symv_bytes += 8.0 * (double)W.N + 16.0 * (double)W.n;
 }
 
+// k_symv_finish: closes Lanczos step `kclose` and runs the mat-vec of step kclose+1 on w'
+inline void Solver::launch_symv_finish(EigWork& W, const double* xp, int kclose, double tol, bool use_carry) {
+    const int ntile = W.nt * (W.nt + 1) / 2;
+    bool prof = opt.profile_symv_every > 0 && (st.symv_launches % opt.profile_symv_every) == 0;
+    size_t slot = 0;
+    if (prof) {
+        if (ev.used == ev.e0.size()) {
+            hipEvent_t a, b;
+            PX_HIP(hipEventCreate(&a)); PX_HIP(hipEventCreate(&b));
+            ev.e0.push_back(a); ev.e1.push_back(b);
+        }
+        slot = ev.used++;
+        PX_HIP(hipEventRecord(ev.e0[slot], stream));
+    }
+    hipLaunchKernelGGL(dev::k_symv_finish, dim3(W.nt + ntile), dim3(dev::TPB), 0, stream,
+                       xp, W.n, W.nt, W.npad, W.Ppart.p, W.w.p, W.V.p, W.npad, kclose, W.hpart2.p, W.pld,
+                       W.hsum1.p, W.alphas.p, W.betas.p, W.ctl.p, tol, use_carry ? 1 : 0);
+    if (prof) PX_HIP(hipEventRecord(ev.e1[slot], stream));
+    st.symv_launches++;
+    st.symv_bytes += 8.0 * (double)W.N + 16.0 * (double)W.n;
+}
+
 inline void Solver::launch_reconstruct(EigWork& W, const double* Z, int ldz, const double* lam, int r, double* xp_out) {
     const int ntile = W.nt * (W.nt + 1) / 2;
     hipLaunchKernelGGL(dev::k_reconstruct_packed, dim3(ntile), dim3(dev::TPB), 0, stream,
@@ -371,15 +394,21 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev) {
     dev::LanczosCtl hctl{};
     while (true) {
         for (int k = kfirst; k < krylovdim; ++k) {
-            launch_symv(W, xp, W.V.p + (size_t)k * W.npad, true);
+            if (k == kfirst) {
+                launch_symv(W, xp, W.V.p + (size_t)k * W.npad, true);          // v_k is ready (start / restart)
+            } else {
+                // close step k-1 and run the mat-vec of step k in one launch
+                launch_symv_finish(W, xp, k - 1, step_tol, k - 1 > kfirst);
+            }
             hipLaunchKernelGGL(dev::k_lz_dots1, dim3(W.nt), dim3(dev::TPB), 0, stream,
-                               W.Ppart.p, W.nt, W.n, W.npad, W.V.p, W.npad, k, W.w.p, W.hpart1.p, W.pld, W.ctl.p);
+                               W.Ppart.p, W.nt, W.n, W.npad, W.V.p, W.npad, k, W.w.p, W.hpart1.p, W.pld, W.ctl.p,
+                               W.betas.p, k == kfirst ? -1 : k - 1);
             hipLaunchKernelGGL(dev::k_lz_apply, dim3(W.nt), dim3(dev::TPB), 0, stream,
                                W.w.p, W.n, W.V.p, W.npad, k, W.hpart1.p, W.pld, W.hsum1.p, W.hpart2.p, W.ctl.p);
-            hipLaunchKernelGGL(dev::k_lz_finish, dim3(W.nt), dim3(dev::TPB), 0, stream,
-                               W.w.p, W.n, W.V.p, W.npad, k, W.hpart2.p, W.pld, W.hsum1.p,
-                               W.alphas.p, W.betas.p, W.ctl.p, step_tol);
         }
+        hipLaunchKernelGGL(dev::k_lz_finish, dim3(W.nt), dim3(dev::TPB), 0, stream,
+                           W.w.p, W.n, W.V.p, W.npad, krylovdim - 1, W.hpart2.p, W.pld, W.hsum1.p,
+                           W.alphas.p, W.betas.p, W.ctl.p, step_tol, (krylovdim - 1 > kfirst) ? 1 : 0);
         W.alphas.download(al.data(), krylovdim, stream);
         W.betas.download(be.data(), krylovdim, stream);
         PX_HIP(hipMemcpyAsync(&hctl, W.ctl.p, sizeof(hctl), hipMemcpyDeviceToHost, stream));
