@@ -138,7 +138,8 @@ typedef struct proxsdp_options {
     int32_t device_id;         /* HIP device ordinal, default 0                      */
     int32_t trace_capacity;    /* rows available in result.trace (0 = no trace)      */
     int32_t profile_symv_every;/* >0: bracket every k-th symv launch with HIP events  */
-    int32_t pad7;
+    int32_t support_path;      /* -1 auto (default), 0 dense vector passes, 1 force the
+                                * support-aware passes when legal */
 } proxsdp_options;
 
 #define PROXSDP_TRACE_COLS 14

@@ -483,11 +483,19 @@ k_lz_rotate(const double* __restrict__ V, int ldv, int n, int K, const double* _
 // write instead of (r+1) passes over 8*n^2 bytes.  Same tiling as the mat-vec.
 // ---------------------------------------------------------------------------
 constexpr int RCHUNK = 16;
+// FUSE_RES: while x_new is still in registers, also accumulate over the entries NOT in
+// the support set (bit mask) the two off-support terms of compute_residual!
+// (residuals.jl:41-48): max |x_new - x_old| and max |x_old|  (Mty = 0 off the support,
+// and x_old = the pre-projection buffer there).  Partials: respart[q*rstride + tile], q = 0,1.
+template <bool FUSE_RES>
 __global__ void __launch_bounds__(TPB)
 k_reconstruct_packed(const double* __restrict__ Z, int ldz, const double* __restrict__ lam, int r,
-                     int n, double* __restrict__ xp) {
+                     int n, double* __restrict__ xp, const double* __restrict__ xold,
+                     const unsigned* __restrict__ mask, long long mask_off, double* __restrict__ respart,
+                     int rstride) {
     __shared__ double s_ZI[RCHUNK][TILE];      // [k][row]
     __shared__ double s_ZJ[RCHUNK][TILE];      // [k][col], pre-multiplied by lambda
+    __shared__ double s_red[NWAVE];
     int I, J;
     tile_coords(blockIdx.x, I, J);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -517,13 +525,30 @@ k_reconstruct_packed(const double* __restrict__ Z, int ldz, const double* __rest
         }
     }
     const int gi = I * TILE + lane;
+    double m0 = 0.0, m1 = 0.0;
 #pragma unroll
     for (int k = 0; k < CPW; ++k) {
         const int gj = J * TILE + w * CPW + k;
         if (gj < n && gi <= gj) {
-            const double s = (gi == gj) ? 1.0 : SQRT2;
-            xp[(long long)gj * (gj + 1) / 2 + gi] = s * acc[k];
+            const double sc = (gi == gj) ? 1.0 : SQRT2;
+            const long long idx = (long long)gj * (gj + 1) / 2 + gi;
+            const double xn = sc * acc[k];
+            xp[idx] = xn;
+            if (FUSE_RES) {
+                const long long gidx = mask_off + idx;
+                const bool on = (mask[gidx >> 5] >> (gidx & 31)) & 1u;
+                if (!on) {
+                    const double xo = xold[idx];
+                    m0 = fmax(m0, fabs(xn - xo));
+                    m1 = fmax(m1, fabs(xo));
+                }
+            }
         }
+    }
+    if (FUSE_RES) {
+        const double r0 = block_max(m0, s_red);
+        const double r1 = block_max(m1, s_red);
+        if (threadIdx.x == 0) { respart[blockIdx.x] = r0; respart[rstride + blockIdx.x] = r1; }
     }
 }
 
@@ -744,6 +769,151 @@ k_residual_y(const double* __restrict__ y, const double* __restrict__ yold,
     }
 }
 
+// ---------------------------------------------------------------------------
+// Support-aware variants.  S = {i : column i of M is non-empty or c_i != 0} is fixed for
+// the solve; Mty and c vanish outside S, so  x .-= tau.*(Mty .+ c)  (pdhg.jl:622) only
+// touches S, Mty = M'y (pdhg.jl:556) only needs the columns in S, and the residual
+// (residuals.jl:41-48) splits into an off-support part (fused into the reconstruction)
+// and an on-support part over |S| entries.  For Max-Cut n=4000: |S| ~ 32e3 of 8.0e6.
+// ---------------------------------------------------------------------------
+// xsave = x[S];  x[S] -= tau*(MtyS + cS)   (in place: x becomes the matrix to project)
+__global__ void __launch_bounds__(TPB)
+k_primal_update_S(double* __restrict__ x, const int* __restrict__ supp, const double* __restrict__ MtyS,
+                  const double* __restrict__ cS, double tau, double* __restrict__ xsave, int ns) {
+    const int s = blockIdx.x * TPB + threadIdx.x;
+    if (s >= ns) return;
+    const int i = supp[s];
+    const double xi = x[i];
+    xsave[s] = xi;
+    x[i] = xi - tau * (MtyS[s] + cS[s]);
+}
+
+struct TrialBatch {                 // up to 4 linesearch candidates per launch
+    double bt[4], theta[4], tau[4], sigma[4];
+    int nc;
+};
+
+// candidates of y+ (pdhg.jl:547-553): grid.y = candidate; part[c][0][wg] = |y+ - y|^2 partials
+__global__ void __launch_bounds__(TPB)
+k_dual_trial_batch(const double* __restrict__ y, const double* __restrict__ Mx, const double* __restrict__ Mx_old,
+                   const double* __restrict__ bh, int p, int Q, TrialBatch tb,
+                   double* __restrict__ ycand, long long ystride, double* __restrict__ part, long long cstride) {
+    __shared__ double sm[NWAVE];
+    const int c = blockIdx.y;
+    const double bt = tb.bt[c], theta = tb.theta[c];
+    double* yout = ycand + (long long)c * ystride;
+    double ss = 0.0;
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < Q; i += gridDim.x * TPB) {
+        const double yi = y[i];
+        const double ybar = yi + bt * ((1.0 + theta) * Mx[i] - theta * Mx_old[i]);
+        const double proj = (i < p) ? bh[i] : fmin(ybar / bt, bh[i]);
+        const double yn = ybar - bt * proj;
+        yout[i] = yn;
+        const double d = yn - yi;
+        ss += d * d;
+    }
+    const double tot = block_sum(ss, sm);
+    if (threadIdx.x == 0) part[(long long)c * cstride + blockIdx.x] = tot;
+}
+
+// MtyS_c = (M' y_c)|S for every candidate + |MtyS_c - MtyS_old|^2 partials (pdhg.jl:556-563)
+__global__ void __launch_bounds__(TPB)
+k_spmvT_S_batch(const int* __restrict__ colptr, const int* __restrict__ row, const double* __restrict__ val,
+                const int* __restrict__ supp, int ns, const double* __restrict__ ycand, long long ystride,
+                double* __restrict__ MtyScand, long long mstride, const double* __restrict__ MtyS_old,
+                double* __restrict__ part, long long cstride) {
+    __shared__ double sm[NWAVE];
+    const int c = blockIdx.y;
+    const double* y = ycand + (long long)c * ystride;
+    double* out = MtyScand + (long long)c * mstride;
+    double ss = 0.0;
+    for (int s = blockIdx.x * TPB + threadIdx.x; s < ns; s += gridDim.x * TPB) {
+        const int col = supp[s];
+        double acc = 0.0;
+        for (int k = colptr[col]; k < colptr[col + 1]; ++k) acc += val[k] * y[row[k]];
+        out[s] = acc;
+        const double d = acc - MtyS_old[s];
+        ss += d * d;
+    }
+    const double tot = block_sum(ss, sm);
+    if (threadIdx.x == 0) part[(long long)c * cstride + blockIdx.x] = tot;
+}
+
+// on-support part of compute_residual! + c.x (residuals.jl:22,41-48), per candidate
+// part[c][q][wg], q = 0: max |dPx|  1: max |Px_old|  2: sum c*x
+__global__ void __launch_bounds__(TPB)
+k_residual_xS_batch(const double* __restrict__ xnew, const int* __restrict__ supp, int ns,
+                    const double* __restrict__ xsave, double xold_coef,
+                    const double* __restrict__ MtyScand, long long mstride, const double* __restrict__ MtyS_old,
+                    const double* __restrict__ cS, TrialBatch tb, double* __restrict__ part, int pstride,
+                    long long cstride) {
+    __shared__ double sm[NWAVE];
+    const int c = blockIdx.y;
+    const double tau = tb.tau[c];
+    const double* MtyS = MtyScand + (long long)c * mstride;
+    double m0 = 0.0, m1 = 0.0, s2 = 0.0;
+    for (int s = blockIdx.x * TPB + threadIdx.x; s < ns; s += gridDim.x * TPB) {
+        const double xi = xnew[supp[s]];
+        const double pold = xold_coef * xsave[s] - tau * MtyS_old[s];
+        const double pnew = xi - tau * MtyS[s];
+        m0 = fmax(m0, fabs(pnew - pold));
+        m1 = fmax(m1, fabs(pold));
+        s2 += cS[s] * xi;
+    }
+    const double r0 = block_max(m0, sm), r1 = block_max(m1, sm), r2 = block_sum(s2, sm);
+    if (threadIdx.x == 0) {
+        double* pp = part + (long long)c * cstride;
+        pp[blockIdx.x] = r0; pp[pstride + blockIdx.x] = r1; pp[2 * pstride + blockIdx.x] = r2;
+    }
+}
+
+// y part of compute_residual! + compute_gap! per candidate; part[c][q][wg], q as in k_residual_y
+__global__ void __launch_bounds__(TPB)
+k_residual_y_batch(const double* __restrict__ ycand, long long ystride, const double* __restrict__ yold,
+                   const double* __restrict__ Mx, const double* __restrict__ Mx_old,
+                   const double* __restrict__ bh, int p, int Q, TrialBatch tb,
+                   double* __restrict__ part, int pstride, long long cstride) {
+    __shared__ double sm[NWAVE];
+    const int c = blockIdx.y;
+    const double sigma = tb.sigma[c];
+    const double* y = ycand + (long long)c * ystride;
+    double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0, s4 = 0.0, s5 = 0.0;
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < Q; i += gridDim.x * TPB) {
+        const double yi = y[i], mx = Mx[i], rhs = bh[i];
+        const double pold = yold[i] - sigma * Mx_old[i];
+        const double pnew = yi - sigma * mx;
+        m0 = fmax(m0, fabs(pnew - pold));
+        m1 = fmax(m1, fabs(pold));
+        if (i < p) { m2 = fmax(m2, fabs(mx - rhs)); s4 += rhs * yi; }
+        else       { m3 = fmax(m3, mx - rhs);       s5 += rhs * yi; }
+    }
+    const double r0 = block_max(m0, sm), r1 = block_max(m1, sm), r2 = block_max(m2, sm), r3 = block_max(m3, sm);
+    const double r4 = block_sum(s4, sm), r5 = block_sum(s5, sm);
+    if (threadIdx.x == 0) {
+        double* pp = part + (long long)c * cstride;
+        const int b = blockIdx.x;
+        pp[b] = r0; pp[pstride + b] = r1; pp[2 * pstride + b] = r2; pp[3 * pstride + b] = r3;
+        pp[4 * pstride + b] = r4; pp[5 * pstride + b] = r5;
+    }
+}
+
+// non-PSD tail of x (SOC + free variables): x_new = x_trial copied to the other buffer,
+// with the off-support residual terms (as in the fused reconstruction)
+__global__ void __launch_bounds__(TPB)
+k_tail_copy_res(const double* __restrict__ xin, double* __restrict__ xout, long long start, long long N,
+                const unsigned* __restrict__ mask, double* __restrict__ respart, int rstride) {
+    __shared__ double sm[NWAVE];
+    double m0 = 0.0, m1 = 0.0;   // m0 stays 0: x_new == x_old here before the cone projections of the tail
+    for (long long i = start + (long long)blockIdx.x * TPB + threadIdx.x; i < N; i += (long long)gridDim.x * TPB) {
+        const double v = xin[i];
+        xout[i] = v;
+        const bool on = (mask[i >> 5] >> (i & 31)) & 1u;
+        if (!on) m1 = fmax(m1, fabs(v));
+    }
+    const double r0 = block_max(m0, sm), r1 = block_max(m1, sm);
+    if (threadIdx.x == 0) { respart[blockIdx.x] = r0; respart[rstride + blockIdx.x] = r1; }
+}
+
 #pragma clang fp contract(fast)
 // final fixed-order combine of per-workgroup partials: out[q] = sum or max over
 // part[q*stride .. q*stride+cnt).  One workgroup; ismax bit q selects max.
@@ -761,6 +931,22 @@ k_combine(const double* __restrict__ part, int stride, int cnt, int nq, unsigned
         if (threadIdx.x == 0) out[q] = r;
         __syncthreads();
     }
+}
+
+// one workgroup per quantity: out[q] = sum or max of part[q*stride .. +cnt)
+__global__ void __launch_bounds__(TPB)
+k_combine_multi(const double* __restrict__ part, int stride, int cnt, unsigned long long ismax,
+                double* __restrict__ out) {
+    __shared__ double sm[NWAVE];
+    const int q = blockIdx.x;
+    const bool mx = (ismax >> q) & 1ull;
+    double a = 0.0;
+    for (int i = threadIdx.x; i < cnt; i += TPB) {
+        const double v = part[(long long)q * stride + i];
+        a = mx ? fmax(a, v) : a + v;
+    }
+    const double r = mx ? block_max(a, sm) : block_sum(a, sm);
+    if (threadIdx.x == 0) out[q] = r;
 }
 
 // v[offdiag] *= s over all PSD blocks (fix_diag_scaling, pdhg.jl:734-743) -- used

@@ -20,19 +20,21 @@ inline void Solver::spmv(const double* x, double* y) {
                            csr_ptr.p, csr_col.p, csr_val.p, x, y, (int)P.Q);
 }
 
-// psd_projection! (prox_operators.jl:33-66), one block
-inline void Solver::project_block(int idx, double* x) {
+// psd_projection! (prox_operators.jl:33-66), one block: reads the packed block of xin,
+// writes the projected block into xout (xin == xout on the dense path)
+inline void Solver::project_block(int idx, const double* xin, double* xout, bool fuse) {
     EigWork& W = eig[idx];
-    double* xp = x + P.blocks[idx].off;
+    const double* xp = xin + P.blocks[idx].off;
+    double* xo = xout + P.blocks[idx].off;
     current_rank[idx] = 0;
     const bool krylov = !opt.full_eig_decomp && target_rank[idx] <= opt.max_target_rank_krylov_eigs &&
                         W.n > opt.min_size_krylov_eigs && (iter % opt.full_eig_freq) > opt.full_eig_len;
-    if (!krylov) { full_eig_project(idx, xp); return; }
+    if (!krylov) { full_eig_project(idx, xp, xo, fuse); return; }
     const int nev = (int)target_rank[idx];
     lanczos(W, xp, nev);
     if (!W.converged) {                       // prox_operators.jl:55-57
         st.krylov_fallbacks++;
-        full_eig_project(idx, xp);
+        full_eig_project(idx, xp, xo, fuse);
         return;
     }
     double mn = W.vals[0];
@@ -48,7 +50,8 @@ inline void Solver::project_block(int idx, double* x) {
     }
     current_rank[idx] += npos;
     if (npos > 0) W.lam.upload(W.vals.data() + first, npos, stream);
-    launch_reconstruct(W, W.Z.p + (size_t)first * W.npad, W.npad, W.lam.p, npos, xp);
+    launch_reconstruct(W, W.Z.p + (size_t)first * W.npad, W.npad, W.lam.p, npos, xo,
+                       fuse ? xp : nullptr, fuse ? idx : -1);
     recon_r_iter += npos;
 }
 
@@ -60,11 +63,29 @@ inline void Solver::psd_projection(double* x) {
         for (int idx : one_blocks) current_rank[idx] = 0;
     }
     for (size_t idx = 0; idx < P.blocks.size(); ++idx)
-        if (P.blocks[idx].n > 1) project_block((int)idx, x);
+        if (P.blocks[idx].n > 1) project_block((int)idx, x, x, false);
 }
 
 // primal_step! (pdhg.jl:611-637)
 inline void Solver::primal_step_dev() {
+    if (use_support) {
+        // x_k (buffer xc) becomes the matrix to project IN PLACE on the support; the projection
+        // is written to the other buffer, so off the support buffer xc still holds x_k = x_old
+        double* xcur = xbuf[xc].p;
+        double* xnew = xbuf[1 - xc].p;
+        hipLaunchKernelGGL(dev::k_primal_update_S, dim3(ceil_div(std::max(ns, 1), dev::TPB)), dim3(dev::TPB), 0, stream,
+                           xcur, supp_d.p, MtyS_cur.p, cS_d.p, primal_step, xsave_d.p, ns);
+        std::fill(min_eig.begin(), min_eig.end(), 0.0);
+        double t0 = now_s();
+        for (size_t idx = 0; idx < P.blocks.size(); ++idx) project_block((int)idx, xcur, xnew, true);
+        st.t_psd += now_s() - t0;
+        if (P.sdplen < P.n)
+            hipLaunchKernelGGL(dev::k_tail_copy_res, dim3(n_res_wg - tile_base.back()), dim3(dev::TPB), 0, stream,
+                               xcur, xnew, (long long)P.sdplen, (long long)P.n, mask_d.p,
+                               respart_d.p + tile_base.back(), rstride);
+        spmv(xnew, Mxbuf[1 - mxc].p);
+        return;
+    }
     const double* xi = xbuf[xc].p;
     double* xo = xbuf[1 - xc].p;
     hipLaunchKernelGGL(dev::k_primal_update, dim3(grid_for(P.n)), dim3(dev::TPB), 0, stream,
@@ -312,11 +333,147 @@ inline void Solver::cache_solution(const std::vector<double>& cvec) {
     st.exit_time += now_s() - t0;
 }
 
+// ---- support-aware path: setup and the batched linesearch + residual
+inline void Solver::setup_support() {
+    use_support = false;
+    if (opt.support_path == 0 || !opt.line_search_flag) return;
+    if (!P.socs.empty() || !one_blocks.empty() || P.blocks.empty()) return;
+    std::vector<int> supp;
+    for (int64_t k = 0; k < P.n; ++k)
+        if (P.colptr[k + 1] > P.colptr[k] || P.c[k] != 0.0) supp.push_back((int)k);
+    if (opt.support_path < 0 && (8 * (int64_t)supp.size() > P.n || P.n < 4096)) return;   // auto: only when it pays
+    ns = (int)supp.size();
+    std::vector<unsigned> mask((size_t)(P.n + 31) / 32 + 1, 0u);
+    std::vector<double> cS(std::max(ns, 1), 0.0);
+    for (int s = 0; s < ns; ++s) { mask[supp[s] >> 5] |= 1u << (supp[s] & 31); cS[s] = P.c[supp[s]]; }
+    supp_d.alloc(std::max(ns, 1)); mask_d.alloc(mask.size()); cS_d.alloc(std::max(ns, 1));
+    xsave_d.alloc(std::max(ns, 1)); MtyS_cur.alloc(std::max(ns, 1)); MtyS_cand.alloc((size_t)4 * std::max(ns, 1));
+    ycand_d.alloc((size_t)4 * std::max<int64_t>(P.Q, 1));
+    supp_d.upload(supp.data(), ns, stream); mask_d.upload(mask.data(), mask.size(), stream);
+    cS_d.upload(cS.data(), ns, stream);
+    MtyS_cur.zero(stream); MtyS_cand.zero(stream); xsave_d.zero(stream); ycand_d.zero(stream);
+    // residual partial slots: one per reconstruction tile of every block + the tail workgroups
+    tile_base.clear();
+    int base = 0;
+    for (const BlockInfo& B : P.blocks) {
+        tile_base.push_back(base);
+        const int nt = ceil_div(B.n, dev::TILE);
+        base += nt * (nt + 1) / 2;
+    }
+    tile_base.push_back(base);
+    if (P.sdplen < P.n) base += std::min(256, ceil_div(P.n - P.sdplen, dev::TPB));
+    n_res_wg = base;
+    rstride = base;
+    respart_d.alloc((size_t)2 * std::max(base, 1)); respart_d.zero(stream);
+    bpart.alloc((size_t)4 * 11 * PSTRIDE); bpart.zero(stream);
+    bscal.alloc(64); bscal.zero(stream);
+    hbscal.assign(64, 0.0);
+    PX_HIP(hipStreamSynchronize(stream));
+    use_support = true;
+}
+
+// linesearch! (pdhg.jl:532-582) + compute_residual! + compute_gap! (residuals.jl) on the
+// support path: up to 3 consecutive step-size candidates tau, 0.75 tau, 0.75^2 tau are
+// evaluated by one batch of small kernels (the dense terms were produced by the fused
+// reconstruction), the host reads all scalars with ONE synchronisation and takes the first
+// candidate the reference's loop would have accepted.
+inline int Solver::linesearch_residual_support() {
+    constexpr int NC = 3;
+    const int gq = std::min(PSTRIDE, grid_for(std::max<int64_t>(P.Q, 1)));
+    const int gs = std::min(PSTRIDE, grid_for(std::max(ns, 1)));
+    const long long cstride = 11LL * PSTRIDE;
+    const long long ystride = std::max<int64_t>(P.Q, 1), mstride = std::max(ns, 1);
+    const double xold_coef = (iter == 1 && opt.advanced_initialization) ? 0.0 : 1.0;
+    primal_step = primal_step * std::sqrt(1.0 + theta);
+    int trials = 0;
+    bool accepted = false;
+    const double* s_acc = nullptr;
+    // off-support residual maxima of this iteration (independent of the candidate)
+    hipLaunchKernelGGL(dev::k_combine_multi, dim3(2), dim3(dev::TPB), 0, stream,
+                       respart_d.p, rstride, n_res_wg, 0x3ull, bscal.p + NC * 11);
+    while (!accepted && trials < opt.max_linsearch_steps) {
+        dev::TrialBatch tb{};
+        double tau_c = primal_step;
+        int nc = 0;
+        for (; nc < NC && trials + nc < opt.max_linsearch_steps; ++nc) {
+            tb.tau[nc] = tau_c;
+            tb.theta[nc] = tau_c / primal_step_old;
+            tb.bt[nc] = beta * tau_c;
+            tb.sigma[nc] = beta * tau_c;
+            tau_c *= opt.linsearch_decay;
+        }
+        tb.nc = nc;
+        hipLaunchKernelGGL(dev::k_dual_trial_batch, dim3(gq, nc), dim3(dev::TPB), 0, stream,
+                           ybuf[yc].p, Mxbuf[1 - mxc].p, Mxbuf[mxc].p, bh_d.p, (int)P.p, (int)P.Q, tb,
+                           ycand_d.p, ystride, bpart.p, cstride);
+        hipLaunchKernelGGL(dev::k_spmvT_S_batch, dim3(gs, nc), dim3(dev::TPB), 0, stream,
+                           csc_ptr.p, csc_row.p, csc_val.p, supp_d.p, ns, ycand_d.p, ystride,
+                           MtyS_cand.p, mstride, MtyS_cur.p, bpart.p + PSTRIDE, cstride);
+        hipLaunchKernelGGL(dev::k_residual_xS_batch, dim3(gs, nc), dim3(dev::TPB), 0, stream,
+                           xbuf[1 - xc].p, supp_d.p, ns, xsave_d.p, xold_coef, MtyS_cand.p, mstride, MtyS_cur.p,
+                           cS_d.p, tb, bpart.p + 2 * PSTRIDE, PSTRIDE, cstride);
+        hipLaunchKernelGGL(dev::k_residual_y_batch, dim3(gq, nc), dim3(dev::TPB), 0, stream,
+                           ycand_d.p, ystride, ybuf[yc].p, Mxbuf[1 - mxc].p, Mxbuf[mxc].p, bh_d.p, (int)P.p, (int)P.Q,
+                           tb, bpart.p + 5 * PSTRIDE, PSTRIDE, cstride);
+        // per candidate: q0,q1 sums | q2,q3 max, q4 sum | q5..q8 max, q9,q10 sum
+        unsigned long long ismax = 0;
+        for (int c = 0; c < nc; ++c) ismax |= 0x1ECull << (11 * c);      // bits 2,3,5,6,7,8
+        hipLaunchKernelGGL(dev::k_combine_multi, dim3(nc * 11), dim3(dev::TPB), 0, stream,
+                           bpart.p, PSTRIDE, std::max(gq, gs), ismax, bscal.p);
+        PX_HIP(hipMemcpyAsync(hbscal.data(), bscal.p, (NC * 11 + 2) * sizeof(double), hipMemcpyDeviceToHost, stream));
+        PX_HIP(hipStreamSynchronize(stream));
+        for (int c = 0; c < nc; ++c) {
+            ++trials;
+            const double* sc = hbscal.data() + 11 * c;
+            primal_step = tb.tau[c];
+            theta = tb.theta[c];
+            const double y_norm = std::sqrt(sc[0]), Mty_norm = std::sqrt(sc[1]);
+            const bool ok = std::sqrt(beta) * primal_step * Mty_norm <= opt.delta * y_norm;
+            const bool last = trials >= opt.max_linsearch_steps;
+            if (ok || last) {
+                if (!ok) primal_step *= opt.linsearch_decay;     // reference quirk: decayed once more, trial kept
+                accepted = true;
+                s_acc = sc;
+                // y <- y_c, Mty <- Mty_c
+                PX_HIP(hipMemcpyAsync(ybuf[1 - yc].p, ycand_d.p + (size_t)c * ystride, (size_t)P.Q * 8,
+                                      hipMemcpyDeviceToDevice, stream));
+                PX_HIP(hipMemcpyAsync(MtyS_cur.p, MtyS_cand.p + (size_t)c * mstride, (size_t)ns * 8,
+                                      hipMemcpyDeviceToDevice, stream));
+                break;
+            }
+            primal_step = tb.tau[c] * opt.linsearch_decay;
+        }
+    }
+    primal_step_old = primal_step;
+    dual_step = beta * primal_step;
+    st.linesearch_trials += trials;
+    // ---- residuals and gap from the accepted candidate's scalars
+    const double m0 = std::max(s_acc[2], hbscal[NC * 11]);
+    const double m1 = std::max(s_acc[3], hbscal[NC * 11 + 1]);
+    const double pres = std::sqrt((double)P.n) * m0 / std::max({m1, P.norm_b, P.norm_h, 1.0});
+    const double dres = std::sqrt((double)P.Q) * s_acc[5] / std::max({s_acc[6], P.norm_c, 1.0});
+    h_pres.at(iter) = pres;
+    h_dres.at(iter) = dres;
+    h_comb.at(iter) = std::max(pres, dres);
+    if (P.p > 0) equa_feasibility = s_acc[7] / (1.0 + P.norm_b);
+    if (P.m > 0) ineq_feasibility = s_acc[8] / (1.0 + P.norm_h);
+    h_feas.at(iter) = std::max(equa_feasibility, ineq_feasibility);
+    const double po = s_acc[4];
+    double d_o = 0.0;
+    if (P.p > 0) d_o -= s_acc[9];
+    if (P.m > 0) d_o -= s_acc[10];
+    h_pobj.at(iter) = po;
+    h_dobj.at(iter) = d_o;
+    h_gap.at(iter) = std::fabs(po - d_o) / (1.0 + std::fabs(po) + std::fabs(d_o));
+    xc = 1 - xc; yc = 1 - yc; mxc = 1 - mxc;
+    return trials;
+}
+
 // ---- hooks for the kernel-level test entry points
 inline void Solver::test_project(int idx, double* xp, int tr) {
     target_rank.assign(1, tr); current_rank.assign(1, 0); min_eig.assign(1, 0.0);
     iter = 1;
-    project_block(idx, xp - P.blocks[idx].off);
+    project_block(idx, xp - P.blocks[idx].off, xp - P.blocks[idx].off, false);
 }
 inline void Solver::test_spmv(bool transpose, const double* in, double* out) {
     setup_device();
@@ -428,6 +585,7 @@ inline void Solver::run() {
         soc_off.upload(so.data(), so.size(), stream); soc_len.upload(sl.data(), sl.size(), stream);
         PX_HIP(hipStreamSynchronize(stream));
     }
+    setup_support();
     double spectral_norm = P.frob;                       // LinearAlgebra.norm(M), pdhg.jl:121
     if (spectral_norm < 1e-10) spectral_norm = 1.0;
     primal_step = 1.0 / spectral_norm;
@@ -446,6 +604,7 @@ inline void Solver::run() {
     auto cert_infeas = [&]() {                           // certificate_infeasibility (pdhg.jl:655-668)
         std::fill(c_host.begin(), c_host.end(), 0.0);
         c_d.zero(stream);
+        if (use_support) cS_d.zero(stream);
         certificate_parameters();
     };
     auto cert_dual_infeas = [&]() {                      // certificate_dual_infeasibility (pdhg.jl:639-653)
@@ -464,12 +623,17 @@ inline void Solver::run() {
         lz_matvec_iter = 0; recon_r_iter = 0;
         primal_step_dev();
         const double tl0 = now_s();
-        if (opt.line_search_flag) last_trials = linesearch();
-        else { dual_step_plain(); last_trials = 1; }
-        const double tl1 = now_s();
-        residual_and_gap();
-        st.t_linesearch += tl1 - tl0;
-        st.t_residual += now_s() - tl1;
+        if (use_support) {
+            last_trials = linesearch_residual_support();
+            st.t_linesearch += now_s() - tl0;
+        } else {
+            if (opt.line_search_flag) last_trials = linesearch();
+            else { dual_step_plain(); last_trials = 1; }
+            const double tl1 = now_s();
+            residual_and_gap();
+            st.t_linesearch += tl1 - tl0;
+            st.t_residual += now_s() - tl1;
+        }
         {   // algorithmic bytes of this iteration
             const double t = (double)last_trials;
             double bb = 8.0 * (double)P.n * (11.0 + 3.0 * t) + 12.0 * (double)P.nnz * (1.0 + t) +

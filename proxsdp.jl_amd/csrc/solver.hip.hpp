@@ -148,7 +148,8 @@ public:
     void full_eig_values(EigWork& W, const double* xp, double offscale, bool vectors, std::vector<double>& Dhost);
     void launch_symv(EigWork& W, const double* xp, const double* v, bool use_ctl);
     void launch_symv_finish(EigWork& W, const double* xp, int kclose, double tol, bool use_carry);
-    void launch_reconstruct(EigWork& W, const double* Z, int ldz, const double* lam, int r, double* xp_out);
+    void launch_reconstruct(EigWork& W, const double* Z, int ldz, const double* lam, int r, double* xp_out,
+                            const double* xp_old = nullptr, int blk = -1);
     void rotate(EigWork& W, int K, const std::vector<double>& U, int ldu, int ncols, double* out, int copy_src, int copy_dst);
 
     // test hooks (capi.hip)
@@ -203,8 +204,10 @@ private:
 
     void primal_step_dev();
     void psd_projection(double* x);
-    void project_block(int idx, double* x);
-    void full_eig_project(int idx, double* xp);
+    void project_block(int idx, const double* xin, double* xout, bool fuse);
+    void setup_support();
+    int  linesearch_residual_support();
+    void full_eig_project(int idx, const double* xp_in, double* xp_out, bool fuse);
     void spmv(const double* x, double* y);
     int  linesearch();
     void dual_step_plain();
@@ -219,6 +222,14 @@ private:
     std::vector<double> b_host, h_host, c_host;   // current (possibly zeroed by a certificate search)
     bool have_snapshot = false;
     bool debug = std::getenv("PROXSDP_HIP_DEBUG") != nullptr;
+    // support-aware vector passes
+    bool use_support = false;
+    int ns = 0, rstride = 0, n_res_wg = 0;
+    std::vector<int> tile_base;                 // first residual-partial slot of each PSD block
+    DevBuf<int> supp_d;
+    DevBuf<unsigned> mask_d;
+    DevBuf<double> cS_d, xsave_d, MtyS_cur, MtyS_cand, ycand_d, respart_d, bpart, bscal;
+    std::vector<double> hbscal;
 };
 
 // ------------------------------------------------------------------ setup
@@ -337,10 +348,17 @@ inline void Solver::launch_symv_finish(EigWork& W, const double* xp, int kclose,
     st.symv_bytes += 8.0 * (double)W.N + 16.0 * (double)W.n;
 }
 
-inline void Solver::launch_reconstruct(EigWork& W, const double* Z, int ldz, const double* lam, int r, double* xp_out) {
+inline void Solver::launch_reconstruct(EigWork& W, const double* Z, int ldz, const double* lam, int r, double* xp_out,
+                                       const double* xp_old, int blk) {
     const int ntile = W.nt * (W.nt + 1) / 2;
-    hipLaunchKernelGGL(dev::k_reconstruct_packed, dim3(ntile), dim3(dev::TPB), 0, stream,
-                       Z, ldz, lam, r, W.n, xp_out);
+    if (use_support && xp_old != nullptr && blk >= 0)
+        hipLaunchKernelGGL(dev::k_reconstruct_packed<true>, dim3(ntile), dim3(dev::TPB), 0, stream,
+                           Z, ldz, lam, r, W.n, xp_out, xp_old, mask_d.p, (long long)P.blocks[blk].off,
+                           respart_d.p + tile_base[blk], rstride);
+    else
+        hipLaunchKernelGGL(dev::k_reconstruct_packed<false>, dim3(ntile), dim3(dev::TPB), 0, stream,
+                           Z, ldz, lam, r, W.n, xp_out, (const double*)nullptr, (const unsigned*)nullptr, 0LL,
+                           (double*)nullptr, 0);
 }
 
 inline void Solver::rotate(EigWork& W, int K, const std::vector<double>& U, int ldu, int ncols,
@@ -528,10 +546,10 @@ inline void Solver::full_eig_values(EigWork& W, const double* xp, double offscal
 }
 
 // full_eig! (prox_operators.jl:111-126)
-inline void Solver::full_eig_project(int idx, double* xp) {
+inline void Solver::full_eig_project(int idx, const double* xp_in, double* xp_out, bool fuse) {
     EigWork& W = eig[idx];
     std::vector<double> D;
-    full_eig_values(W, xp, dev::INV_SQRT2, true, D);
+    full_eig_values(W, xp_in, dev::INV_SQRT2, true, D);
     st.full_eigs++;
     const int n = W.n;
     int npos = 0, rank = 0;
@@ -539,7 +557,8 @@ inline void Solver::full_eig_project(int idx, double* xp) {
     current_rank[idx] = rank;
     min_eig[idx] = 0.0;
     // ascending order: the positive eigenpairs are the trailing npos columns
-    launch_reconstruct(W, W.A.p + (size_t)(n - npos) * n, n, W.D.p + (n - npos), npos, xp);
+    launch_reconstruct(W, W.A.p + (size_t)(n - npos) * n, n, W.D.p + (n - npos), npos, xp_out,
+                       fuse ? xp_in : nullptr, fuse ? idx : -1);
     recon_r_iter += npos;
 }
 

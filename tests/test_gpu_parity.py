@@ -180,13 +180,16 @@ def _gopt(**kw):
     return o
 
 
+@pytest.mark.parametrize("support_path", [0, 1], ids=["dense", "support"])
 @pytest.mark.parametrize("name", list(KATS))
-def test_known_answers_and_golden_results(name, golden_dir):
+def test_known_answers_and_golden_results(name, support_path, golden_dir):
     """The reference's KATs (test/moi_proxsdp_unit.jl) on the HIP path, and the
-    oracle's committed final Result for the same problem."""
+    oracle's committed final Result for the same problem -- with the dense vector
+    passes and with the support-aware ones forced on (falls back to dense where the
+    path is not legal: LPs, 1x1 blocks)."""
     build, expected, atol, xexp = KATS[name]
     gold = json.loads((golden_dir / "kat_results.json").read_text())[name]
-    opt = _gopt()
+    opt = _gopt(support_path=support_path)
     sol = opt.optimize(build())
     assert opt.termination_status() == "OPTIMAL"
     assert opt.primal_status() == "FEASIBLE_POINT" and opt.dual_status() == "FEASIBLE_POINT"
@@ -312,11 +315,12 @@ def test_sdplib_against_oracle(fname, lit, tol, golden_dir):
     assert abs(sol.iter - ref.iter) <= 0.25 * ref.iter
 
 
-def test_block_diagonal_model_two_blocks():
+@pytest.mark.parametrize("support_path", [0, 1], ids=["dense", "support"])
+def test_block_diagonal_model_two_blocks(support_path):
     """Two independent MIMO instances in one block-diagonal model (the shape of the
     'MIMO x 8 blocks' config) against the oracle."""
     pr = P.block_diag_problems([P.mimo(6, seed=1), P.mimo(7, seed=2)])
-    opt = _gopt()
+    opt = _gopt(support_path=support_path)
     sol = opt.optimize(pr)
     o = Options()
     o.tol_gap = o.tol_feasibility = 1e-6
@@ -324,6 +328,24 @@ def test_block_diagonal_model_two_blocks():
     assert sol.status == ref.status == 1 and sol.iter == ref.iter
     assert abs(sol.objval - ref.objval) <= 1e-8 * (1 + abs(ref.objval))
     assert np.allclose(sol.primal, ref.primal, atol=1e-7)
+
+
+def test_support_and_dense_paths_agree_on_maxcut():
+    """Max-Cut n=300, 150 iterations: the support-aware passes and the dense passes are the
+    same arithmetic on the support and exact zeros elsewhere."""
+    pr = P.maxcut(300, seed=2)
+    sols = []
+    for sp in (0, 1):
+        opt = Optimizer(max_iter=150, support_path=sp)
+        sols.append(opt.optimize(pr, trace_capacity=150))
+    a, b = sols
+    assert a.iter == b.iter == 150
+    assert np.array_equal(a.trace[:, 11], b.trace[:, 11])                 # linesearch trials
+    mv = a.trace[:, 13]
+    tight = max(3, int(np.argmax(mv > 25)) if np.any(mv > 25) else 150)
+    for col in (1, 2, 3, 4, 5, 6, 7, 9):
+        assert np.allclose(a.trace[:tight, col], b.trace[:tight, col], rtol=1e-10, atol=1e-13), col
+    assert abs(a.objval - b.objval) <= 1e-3 * (1 + abs(a.objval))
 
 
 def test_maxcut_n1000_reaches_tolerance():
