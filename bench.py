@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--krylov-rank", type=int, default=64,
                     help="max_target_rank_krylov_eigs for the time-to-tol leg (metric: rank ~ sqrt(n))")
     ap.add_argument("--profile-every", type=int, default=16)
+    ap.add_argument("--support-path", type=int, default=-1, help="-1 auto, 0 dense vector passes, 1 support-aware")
     args = ap.parse_args()
 
     import torch
@@ -72,7 +73,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    opt = Optimizer(max_iter=W + K, device_id=local_rank, profile_symv_every=args.profile_every)
+    opt = Optimizer(max_iter=W + K, device_id=local_rank, profile_symv_every=args.profile_every,
+                    support_path=args.support_path)
     sync()
     t0 = time.time()
     sol = opt.optimize(pr, trace_capacity=W + K)

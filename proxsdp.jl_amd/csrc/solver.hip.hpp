@@ -75,6 +75,22 @@ struct DevBuf {
     }
 };
 
+// pinned host memory (fast, truly asynchronous small read-backs)
+struct PinnedBuf {
+    double* p = nullptr;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+    PinnedBuf(PinnedBuf&& o) noexcept : p(o.p) { o.p = nullptr; }
+    PinnedBuf& operator=(PinnedBuf&& o) noexcept { if (this != &o) { release(); p = o.p; o.p = nullptr; } return *this; }
+    ~PinnedBuf() { release(); }
+    void alloc(size_t count) {
+        release();
+        if (hipHostMalloc((void**)&p, count * sizeof(double), hipHostMallocDefault) != hipSuccess) { p = nullptr; throw std::bad_alloc(); }
+    }
+    void release() { if (p) { (void)hipHostFree(p); p = nullptr; } }
+};
+
 static inline double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -102,8 +118,13 @@ struct EigWork {
     int n = 0, nt = 0, npad = 0, nwg = 0, cap = 0, pld = 0;   // cap = columns of V (krylovdim_max + 1)
     int64_t N = 0;
     DevBuf<double> V, Z;            // npad x cap each (V: Krylov basis, Z: rotation target / Ritz vectors)
-    DevBuf<double> w, Ppart, hpart1, hpart2, hsum1, alphas, betas, U, lam, resid;
-    DevBuf<dev::LanczosCtl> ctl;
+    DevBuf<double> w, Ppart, hpart1, hpart2, hsum1, U, lam, resid;
+    // alphas[MAXK] | betas[MAXK] | LanczosCtl in ONE device record, read back with one copy
+    DevBuf<double> rec;
+    double* alphas_p = nullptr; double* betas_p = nullptr; dev::LanczosCtl* ctl_p = nullptr;
+    PinnedBuf rec_pinned;           // pinned mirror of `rec`
+    double* rec_host = nullptr;
+    static constexpr size_t REC_DOUBLES = 2 * dev::MAXK + sizeof(dev::LanczosCtl) / sizeof(double);
     // full-eig fallback
     DevBuf<double> A, D, E;
     DevBuf<rocblas_int> info;
@@ -112,7 +133,7 @@ struct EigWork {
     int ustage_next = 0;
     // results of the last call
     std::vector<double> vals;
-    int count = 0, converged_eigs = 0, numiter = 0;
+    int count = 0, converged_eigs = 0, numiter = 0, prev_numiter = 1;
     bool converged = false;
 };
 
@@ -252,13 +273,16 @@ inline void Solver::alloc_eigwork(EigWork& W, int n, int max_nev) {
     W.hpart2.alloc((size_t)W.pld * dev::MAXK);
     W.hpart1.zero(stream); W.hpart2.zero(stream);
     W.hsum1.alloc(dev::MAXK);
-    W.alphas.alloc(dev::MAXK); W.betas.alloc(dev::MAXK);
+    W.rec.alloc(EigWork::REC_DOUBLES);
+    W.alphas_p = W.rec.p; W.betas_p = W.rec.p + dev::MAXK;
+    W.ctl_p = reinterpret_cast<dev::LanczosCtl*>(W.rec.p + 2 * dev::MAXK);
+    W.rec_pinned.alloc(EigWork::REC_DOUBLES);
+    W.rec_host = W.rec_pinned.p;
     W.U.alloc((size_t)dev::MAXK * dev::MAXK);
     W.lam.alloc(std::max(n, dev::MAXK));
     W.resid.alloc(W.npad);
-    W.ctl.alloc(1);
     W.V.zero(stream); W.Z.zero(stream); W.w.zero(stream);
-    W.hsum1.zero(stream); W.alphas.zero(stream); W.betas.zero(stream);
+    W.hsum1.zero(stream); W.rec.zero(stream);
     W.resid.zero(stream);
 }
 
@@ -307,7 +331,7 @@ inline void Solver::start_rocsolver_warmup() {
 
 // ------------------------------------------------------------------ kernels launch helpers
 inline void Solver::launch_symv(EigWork& W, const double* xp, const double* v, bool use_ctl) {
-    const int ntile = W.nt * (W.nt + 1) / 2;      // one workgroup per 64x64 tile
+    const int ntile = ceil_div(W.nt * (W.nt + 1) / 2, dev::SYMV_TPW);      // SYMV_TPW 64x64 tiles per workgroup
     bool prof = opt.profile_symv_every > 0 && (st.symv_launches % opt.profile_symv_every) == 0;
     size_t slot = 0;
     if (prof) {
@@ -320,7 +344,7 @@ inline void Solver::launch_symv(EigWork& W, const double* xp, const double* v, b
         PX_HIP(hipEventRecord(ev.e0[slot], stream));
     }
     hipLaunchKernelGGL(dev::k_symv_packed, dim3(ntile), dim3(dev::TPB), 0, stream,
-                       xp, W.n, W.nt, W.npad, v, W.Ppart.p, use_ctl ? W.ctl.p : nullptr);
+                       xp, W.n, W.nt, W.npad, v, W.Ppart.p, use_ctl ? W.ctl_p : nullptr);
     if (prof) PX_HIP(hipEventRecord(ev.e1[slot], stream));
     st.symv_launches++;
     st.symv_bytes += 8.0 * (double)W.N + 16.0 * (double)W.n;
@@ -328,7 +352,7 @@ inline void Solver::launch_symv(EigWork& W, const double* xp, const double* v, b
 
 // k_symv_finish: closes Lanczos step `kclose` and runs the mat-vec of step kclose+1 on w'
 inline void Solver::launch_symv_finish(EigWork& W, const double* xp, int kclose, double tol, bool use_carry) {
-    const int ntile = W.nt * (W.nt + 1) / 2;
+    const int ntile = ceil_div(W.nt * (W.nt + 1) / 2, dev::SYMV_TPW);
     bool prof = opt.profile_symv_every > 0 && (st.symv_launches % opt.profile_symv_every) == 0;
     size_t slot = 0;
     if (prof) {
@@ -342,7 +366,7 @@ inline void Solver::launch_symv_finish(EigWork& W, const double* xp, int kclose,
     }
     hipLaunchKernelGGL(dev::k_symv_finish, dim3(W.nt + ntile), dim3(dev::TPB), 0, stream,
                        xp, W.n, W.nt, W.npad, W.Ppart.p, W.w.p, W.V.p, W.npad, kclose, W.hpart2.p, W.pld,
-                       W.hsum1.p, W.alphas.p, W.betas.p, W.ctl.p, tol, use_carry ? 1 : 0);
+                       W.hsum1.p, W.alphas_p, W.betas_p, W.ctl_p, tol, use_carry ? 1 : 0);
     if (prof) PX_HIP(hipEventRecord(ev.e1[slot], stream));
     st.symv_launches++;
     st.symv_bytes += 8.0 * (double)W.N + 16.0 * (double)W.n;
@@ -397,40 +421,54 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev) {
     const double tol = arpack ? opt.arpack_tol : opt.krylovkit_tol;
     const long long maxiter = arpack ? (long long)opt.arpack_max_iter : (long long)opt.krylovkit_max_iter;
     if (!arpack && opt.krylovkit_eager) throw std::invalid_argument("krylovkit_eager=true is not implemented");
+    W.prev_numiter = std::max(W.numiter, 1);
     W.converged = false; W.count = 0; W.converged_eigs = 0; W.numiter = 0; W.vals.clear();
     st.lanczos_calls++;
     if (arpack && (!(0 < nev && nev < W.n) || krylovdim > W.n)) return;   // dsaupd info=-1/-3 -> error -> fallback
 
     const double step_tol = arpack ? 0.0 : tol;       // invariant-subspace test inside the recurrence
-    PX_HIP(hipMemsetAsync(W.ctl.p, 0, sizeof(dev::LanczosCtl), stream));
+    PX_HIP(hipMemsetAsync(W.ctl_p, 0, sizeof(dev::LanczosCtl), stream));
     PX_HIP(hipMemcpyAsync(W.V.p, W.resid.p, (size_t)W.npad * 8, hipMemcpyDeviceToDevice, stream));
 
     const int ld = krylovdim + 1;
     std::vector<double> T((size_t)ld * ld, 0.0), Tw, D(ld), U, f(ld), al(ld), be(ld);
     int howmany = nev, numiter = 1, converged = 0, K = 0, kfirst = 0;
+    bool presymv = false;
     double betaK = 0.0;
     dev::LanczosCtl hctl{};
     while (true) {
         for (int k = kfirst; k < krylovdim; ++k) {
             if (k == kfirst) {
-                launch_symv(W, xp, W.V.p + (size_t)k * W.npad, true);          // v_k is ready (start / restart)
+                if (!presymv) launch_symv(W, xp, W.V.p + (size_t)k * W.npad, true);   // v_k is ready (start)
+                else { st.symv_launches++; st.symv_bytes += 8.0 * (double)W.N + 16.0 * (double)W.n; }
+                presymv = false;               // after a restart the mat-vec of v_keep is already in Ppart
             } else {
                 // close step k-1 and run the mat-vec of step k in one launch
                 launch_symv_finish(W, xp, k - 1, step_tol, k - 1 > kfirst);
             }
             hipLaunchKernelGGL(dev::k_lz_dots1, dim3(W.nt), dim3(dev::TPB), 0, stream,
-                               W.Ppart.p, W.nt, W.n, W.npad, W.V.p, W.npad, k, W.w.p, W.hpart1.p, W.pld, W.ctl.p,
-                               W.betas.p, k == kfirst ? -1 : k - 1);
+                               W.Ppart.p, W.nt, W.n, W.npad, W.V.p, W.npad, k, W.w.p, W.hpart1.p, W.pld, W.ctl_p,
+                               W.betas_p, k == kfirst ? -1 : k - 1);
             hipLaunchKernelGGL(dev::k_lz_apply, dim3(W.nt), dim3(dev::TPB), 0, stream,
-                               W.w.p, W.n, W.V.p, W.npad, k, W.hpart1.p, W.pld, W.hsum1.p, W.hpart2.p, W.ctl.p);
+                               W.w.p, W.n, W.V.p, W.npad, k, W.hpart1.p, W.pld, W.hsum1.p, W.hpart2.p, W.ctl_p);
         }
         hipLaunchKernelGGL(dev::k_lz_finish, dim3(W.nt), dim3(dev::TPB), 0, stream,
                            W.w.p, W.n, W.V.p, W.npad, krylovdim - 1, W.hpart2.p, W.pld, W.hsum1.p,
-                           W.alphas.p, W.betas.p, W.ctl.p, step_tol, (krylovdim - 1 > kfirst) ? 1 : 0);
-        W.alphas.download(al.data(), krylovdim, stream);
-        W.betas.download(be.data(), krylovdim, stream);
-        PX_HIP(hipMemcpyAsync(&hctl, W.ctl.p, sizeof(hctl), hipMemcpyDeviceToHost, stream));
+                           W.alphas_p, W.betas_p, W.ctl_p, step_tol, (krylovdim - 1 > kfirst) ? 1 : 0);
+        // the first mat-vec of a possible next cycle only needs v_K = V[:,krylovdim], which is
+        // final now: enqueue it before the host round trip so the GPU works during the K x K
+        // eigensolve (wasted only when this cycle turns out to be the last one)
+        // -- speculated only when this block's previous projection needed a restart too
+        const bool speculate = W.prev_numiter > 1 || numiter > 1;
+        if (speculate) {
+            launch_symv(W, xp, W.V.p + (size_t)krylovdim * W.npad, true);
+            st.symv_launches--; st.symv_bytes -= 8.0 * (double)W.N + 16.0 * (double)W.n;   // counted when used
+        }
+        PX_HIP(hipMemcpyAsync(W.rec_host, W.rec.p, EigWork::REC_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, stream));
         PX_HIP(hipStreamSynchronize(stream));
+        std::copy(W.rec_host, W.rec_host + krylovdim, al.begin());
+        std::copy(W.rec_host + dev::MAXK, W.rec_host + dev::MAXK + krylovdim, be.begin());
+        std::memcpy(&hctl, W.rec_host + 2 * dev::MAXK, sizeof(hctl));
         if (ev.used) {                                   // harvest profiled symv launches
             for (size_t s = 0; s < ev.used; ++s) {
                 float ms = 0.f;
@@ -499,6 +537,7 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev) {
             T[(size_t)keep * ld + j] = f[j];
         }
         kfirst = keep;
+        presymv = speculate;
         ++numiter;
         st.lanczos_restarts++;
     }
