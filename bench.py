@@ -38,8 +38,8 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--n", type=int, default=4000, help="PSD side (metric: 4000)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline sample budget")
@@ -92,6 +92,11 @@ def main():
     symv_ms = st["symv_profiled_ms"] / max(1, st["symv_profiled"])
     symv_bytes = 8.0 * N + 16.0 * n                       # algorithmic bytes of one mat-vec
     achieved = symv_bytes / (symv_ms * 1e-3) / 1e9 if symv_ms > 0 else 0.0
+    # HBM traffic per launch from PMC counters: bench.py cannot run rocprofv3 on itself (and
+    # `rocprofv3 --pmc` segfaults on the full solve in this image), so the figure is the one
+    # measured on the isolated kernel at n = 4000 with separate --pmc FETCH_SIZE / WRITE_SIZE
+    # passes and the gfx950 x2 FETCH correction: profiles/r01_pmc_fetch_write_symv.md
+    traffic = (2 * 31492.7 + 1984.5) * 1024 if n == 4000 else None
     mv_timed = float(tr[W:W + K, 13].sum())
     trials_timed = float(tr[W:W + K, 11].sum())
     out = {
@@ -106,7 +111,8 @@ def main():
                    "lanczos_matvecs_per_step": mv_timed / K, "linesearch_trials_per_step": trials_timed / K,
                    "target_rank": int(tr[W + K - 1, 10])},
         "roofline": {"bound": "hbm", "kernel": "k_symv_packed", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": "profiles/r01_pmc_fetch_write_symv.md (2*FETCH_SIZE + WRITE_SIZE, isolated kernel)",
                      "bytes_per_launch": symv_bytes, "avg_launch_ms": symv_ms,
                      "launches_profiled": int(st["symv_profiled"]), "launches": int(st["symv_launches"]),
                      "loop_algorithmic_GBs": st["algorithmic_bytes"] / max(st["loop_time"], 1e-9) / 1e9},

@@ -248,6 +248,16 @@ __device__ __forceinline__ void symv_reduce(int npad, const double* __restrict__
 // SYMV_TPW tiles per workgroup (tile ids first, first + stride, ...): the loads of the next
 // tile are issued before the current tile is reduced, so the reduction (shuffles, LDS
 // meeting, barrier) of one tile overlaps the memory latency of the next.
+// XCD-aware tile order.  Workgroup b runs on XCD b % 8 (each XCD has its own L2).  A column
+// segment of a tile is 512 bytes at an arbitrary 8-byte alignment, i.e. it straddles 5 cache
+// lines of 128 B, and the vertically adjacent tile (I+1, J) needs the same boundary lines:
+// with tiles dealt round-robin those lines are fetched twice (measured: 2*FETCH_SIZE =
+// 79.8 MB for 64.1 MB algorithmic at n = 4000).  Here XCD x walks the contiguous tile range
+// [x*q, (x+1)*q) in order, so the neighbour's lines are still in that XCD's L2.
+__device__ __forceinline__ int xcd_tile(int b, int ntile) {
+    const int q = (ntile + 7) >> 3;
+    return (b & 7) * q + (b >> 3);            // >= ntile for the padding workgroups
+}
 constexpr int SYMV_TPW = 1;          // measured: 2 tiles/workgroup is not faster (16.0 vs 14.7 us at n=4000)
 __device__ __forceinline__ void symv_tiles(const double* __restrict__ xp, int n, int npad, int ntile,
                                            const double* __restrict__ v, double* __restrict__ Ppart,
@@ -256,7 +266,7 @@ __device__ __forceinline__ void symv_tiles(const double* __restrict__ xp, int n,
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     double ta[CPW], tb[CPW];
-    int tile = first;
+    int tile = xcd_tile(first, ntile);
     if (tile >= ntile) return;
     symv_load(xp, n, tile, lane, wv, ta);
 #pragma unroll
@@ -529,8 +539,11 @@ k_reconstruct_packed(const double* __restrict__ Z, int ldz, const double* __rest
     __shared__ double s_ZI[RCHUNK][TILE];      // [k][row]
     __shared__ double s_ZJ[RCHUNK][TILE];      // [k][col], pre-multiplied by lambda
     __shared__ double s_red[NWAVE];
+    const int nt_ = (n + TILE - 1) / TILE;
+    const int tile = xcd_tile(blockIdx.x, nt_ * (nt_ + 1) / 2);   // XCD-aware order (see k_symv_packed)
+    if (tile >= nt_ * (nt_ + 1) / 2) return;
     int I, J;
-    tile_coords(blockIdx.x, I, J);
+    tile_coords(tile, I, J);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     double acc[CPW];
 #pragma unroll

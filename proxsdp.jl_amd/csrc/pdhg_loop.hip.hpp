@@ -358,7 +358,7 @@ inline void Solver::setup_support() {
     for (const BlockInfo& B : P.blocks) {
         tile_base.push_back(base);
         const int nt = ceil_div(B.n, dev::TILE);
-        base += nt * (nt + 1) / 2;
+        base += 8 * ceil_div(nt * (nt + 1) / 2, 8);      // reconstruction grid (padded to 8 XCDs)
     }
     tile_base.push_back(base);
     if (P.sdplen < P.n) base += std::min(256, ceil_div(P.n - P.sdplen, dev::TPB));
@@ -522,7 +522,7 @@ inline void Solver::run() {
     setup_device();
     bool big_block = false;
     for (const BlockInfo& B : P.blocks) big_block = big_block || B.n >= 256;
-    if (big_block) start_rocsolver_warmup();
+    if (big_block && std::getenv("PROXSDP_HIP_NO_WARMUP") == nullptr) start_rocsolver_warmup();
     for (int k = 0; k < 2; ++k) {
         xbuf[k].alloc(P.n); Mtybuf[k].alloc(P.n);
         ybuf[k].alloc(std::max<int64_t>(P.Q, 1)); Mxbuf[k].alloc(std::max<int64_t>(P.Q, 1));

@@ -331,7 +331,7 @@ inline void Solver::start_rocsolver_warmup() {
 
 // ------------------------------------------------------------------ kernels launch helpers
 inline void Solver::launch_symv(EigWork& W, const double* xp, const double* v, bool use_ctl) {
-    const int ntile = ceil_div(W.nt * (W.nt + 1) / 2, dev::SYMV_TPW);      // SYMV_TPW 64x64 tiles per workgroup
+    const int ntile = 8 * ceil_div(W.nt * (W.nt + 1) / 2, 8);     // one workgroup per 64x64 tile, padded to 8 XCDs
     bool prof = opt.profile_symv_every > 0 && (st.symv_launches % opt.profile_symv_every) == 0;
     size_t slot = 0;
     if (prof) {
@@ -352,7 +352,7 @@ inline void Solver::launch_symv(EigWork& W, const double* xp, const double* v, b
 
 // k_symv_finish: closes Lanczos step `kclose` and runs the mat-vec of step kclose+1 on w'
 inline void Solver::launch_symv_finish(EigWork& W, const double* xp, int kclose, double tol, bool use_carry) {
-    const int ntile = ceil_div(W.nt * (W.nt + 1) / 2, dev::SYMV_TPW);
+    const int ntile = 8 * ceil_div(W.nt * (W.nt + 1) / 2, 8);
     bool prof = opt.profile_symv_every > 0 && (st.symv_launches % opt.profile_symv_every) == 0;
     size_t slot = 0;
     if (prof) {
@@ -374,7 +374,7 @@ inline void Solver::launch_symv_finish(EigWork& W, const double* xp, int kclose,
 
 inline void Solver::launch_reconstruct(EigWork& W, const double* Z, int ldz, const double* lam, int r, double* xp_out,
                                        const double* xp_old, int blk) {
-    const int ntile = W.nt * (W.nt + 1) / 2;
+    const int ntile = 8 * ceil_div(W.nt * (W.nt + 1) / 2, 8);     // padded to the 8 XCDs (xcd_tile)
     if (use_support && xp_old != nullptr && blk >= 0)
         hipLaunchKernelGGL(dev::k_reconstruct_packed<true>, dim3(ntile), dim3(dev::TPB), 0, stream,
                            Z, ldz, lam, r, W.n, xp_out, xp_old, mask_d.p, (long long)P.blocks[blk].off,
