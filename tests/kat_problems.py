@@ -101,3 +101,31 @@ KATS = {
     "sdp_wiki_min": (lambda: sdp_wiki(False), -0.978, 1e-2, None),
     "sdp_wiki_max": (lambda: sdp_wiki(True), 0.872, 1e-2, None),
 }
+
+
+# ----------------------------------------------------------------- extra instances (own, not from the reference)
+def soc_norm():
+    """min t  s.t. (t, x1, x2) in SOC, x1 = 3, x2 = 4  ->  t = 5 (soc_projection!, prox_operators.jl:138-158)."""
+    return Problem(n=3, A=_mat([{1: 1}, {2: 1}], 3), b=np.array([3.0, 4.0]), G=_mat([], 3), h=np.zeros(0),
+                   c=_cvec(3, {0: 1}), soc=[np.arange(3)], name="soc_norm")
+
+
+def sdp_plus_soc():
+    """2x2 PSD block (vars 0..2) with X12 = 1, SOC (t, u1, u2) (vars 3..5) with u = (X11, 2),
+    min X11 + X22 + t, plus a free variable z (var 6) pinned to 1.5 by an equality."""
+    A = _mat([{1: 1}, {4: 1, 0: -1}, {5: 1}, {6: 1}], 7)
+    b = np.array([1.0, 0.0, 2.0, 1.5])
+    return Problem(n=7, A=A, b=b, G=_mat([], 7), h=np.zeros(0), c=_cvec(7, {0: 1, 2: 1, 3: 1, 6: 0.5}),
+                   psd=[np.arange(3)], soc=[np.arange(3, 6)], name="sdp_plus_soc")
+
+
+def infeasible_lp():
+    """x1 + x2 = -1 with x >= 0: primal infeasible (status INFEASIBLE = 6)."""
+    return Problem(n=2, A=_mat([{0: 1, 1: 1}], 2), b=np.array([-1.0]), G=_mat([{0: -1}, {1: -1}], 2),
+                   h=np.zeros(2), c=_cvec(2, {0: 1, 1: 1}), name="infeasible_lp")
+
+
+def unbounded_lp():
+    """min -x1 - x2  s.t. x1 - x2 = 0, x >= 0: dual infeasible (status DUAL_INFEASIBLE = 5)."""
+    return Problem(n=2, A=_mat([{0: 1, 1: -1}], 2), b=np.array([0.0]), G=_mat([{0: -1}, {1: -1}], 2),
+                   h=np.zeros(2), c=_cvec(2, {0: -1, 1: -1}), name="unbounded_lp")

@@ -18,7 +18,7 @@ from proxsdp_jl_amd import problems as P
 from proxsdp_jl_amd.optimizer import Optimizer
 
 from helpers import PROJ_CASES, oracle_project, planted_packed, smat, svec
-from kat_problems import KATS, sdp_wiki, simple_lp
+from kat_problems import KATS, sdp_wiki, simple_lp, soc_norm, sdp_plus_soc, unbounded_lp, infeasible_lp
 
 pytestmark = pytest.mark.gpu
 
@@ -233,6 +233,53 @@ def test_termination_statuses():
                     tol_feasibility_dual=1e-16, tol_psd=1e-16, time_limit=0.0)
     opt.optimize(simple_lp())
     assert opt.termination_status() == "TIME_LIMIT"
+
+
+@pytest.mark.parametrize("build", [soc_norm, sdp_plus_soc], ids=["soc_norm", "sdp_plus_soc"])
+def test_soc_cones_against_oracle(build):
+    """soc_projection! / soc_convergence (prox_operators.jl:138-158, residuals.jl:73-86) and the
+    cones-first variable order with free variables (scaling.jl:2-26)."""
+    pr = build()
+    opt = _gopt()
+    sol = opt.optimize(pr)
+    o = Options()
+    o.tol_gap = o.tol_feasibility = 1e-6
+    ref = oracle.solve(pr, o)
+    assert sol.status == ref.status == 1 and sol.iter == ref.iter
+    assert abs(sol.objval - ref.objval) <= 1e-9 * (1 + abs(ref.objval))
+    assert np.allclose(sol.primal, ref.primal, atol=1e-8) and np.allclose(sol.dual_cone, ref.dual_cone, atol=1e-8)
+    if build is soc_norm:
+        assert abs(opt.objective_value() - 5.0) < 1e-4
+
+
+def test_unbounded_lp_certificate_search():
+    """Unbounded LP: objective blow-up -> certificate search with b,h zeroed -> primal ray
+    (pdhg.jl:184-244, 407-422, 639-676) -- same branch sequence as the oracle."""
+    pr = unbounded_lp()
+    opt = _gopt()
+    sol = opt.optimize(pr)
+    o = Options()
+    o.tol_gap = o.tol_feasibility = 1e-6
+    ref = oracle.solve(pr, o)
+    assert sol.status == ref.status == 5 and sol.certificate_found and ref.certificate_found
+    assert opt.termination_status() == "DUAL_INFEASIBLE" and opt.primal_status() == "INFEASIBILITY_CERTIFICATE"
+    assert sol.iter == ref.iter
+    assert "Primal ray found" in sol.status_string
+
+
+def test_infeasible_lp_prefix_matches_oracle():
+    """Infeasible LP (the reference needs ~1e6 iterations to declare it): the first 3000
+    iterations follow the oracle exactly (no eigen-solver involved)."""
+    pr = infeasible_lp()
+    opt = Optimizer(max_iter=3000)
+    sol = opt.optimize(pr, trace_capacity=3000)
+    o = Options()
+    o.max_iter = 3000
+    ref = oracle.solve(pr, o, trace=True)
+    assert sol.status == ref.status and sol.iter == ref.iter
+    G = np.array([[t["prim_obj"], t["dual_obj"], t["feas"], t["primal_step"]] for t in ref.trace])
+    T = sol.trace[:, [1, 2, 4, 7]]
+    assert np.allclose(T, G, rtol=1e-9, atol=1e-12)
 
 
 @pytest.mark.parametrize("n", [2, 3, 4, 5])

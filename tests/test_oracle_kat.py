@@ -17,7 +17,7 @@ from oracle import Options
 from oracle import eig as oeig
 from proxsdp_jl_amd import problems as P
 
-from kat_problems import KATS, simple_lp, sdp_wiki
+from kat_problems import KATS, simple_lp, sdp_wiki, soc_norm, sdp_plus_soc, unbounded_lp
 
 
 def _opt(**kw):
@@ -182,3 +182,18 @@ def test_maxcut_generator_shapes():
     assert np.allclose(pr.c[d], -0.25 * L.diagonal())
     i, j = 3, int(np.nonzero(L[3].toarray().ravel() < 0)[0][0])
     assert np.isclose(pr.c[P.tri_index(i, j)], -0.25 * 2 * L[i, j])
+
+
+# ----------------------------------------------------------------- rows built beyond the BASELINE configs
+def test_soc_projection_known_answer():
+    """soc_projection!/soc_convergence (prox_operators.jl:138-158, residuals.jl:73-86): |(3,4)| = 5."""
+    r = oracle.solve(soc_norm(), _opt())
+    assert r.status == 1 and abs(r.objval - 5.0) < 1e-4 and np.allclose(r.primal, [5, 3, 4], atol=1e-4)
+    r = oracle.solve(sdp_plus_soc(), _opt())
+    assert r.status == 1 and r.primal[3] >= np.hypot(r.primal[4], r.primal[5]) - 1e-5
+
+
+def test_unbounded_lp_certificate():
+    """pdhg.jl:407-422 + certificate search :184-244, :639-676."""
+    r = oracle.solve(unbounded_lp(), _opt())
+    assert r.status == 5 and r.certificate_found
