@@ -395,6 +395,67 @@ def test_support_and_dense_paths_agree_on_maxcut():
     assert abs(a.objval - b.objval) <= 1e-3 * (1 + abs(a.objval))
 
 
+def _trace_cols(ref_trace):
+    return np.array([[t["prim_obj"], t["dual_obj"], t["gap"], t["feas"], t["primal_step"], t["trials"]]
+                     for t in ref_trace])
+
+
+def test_randsdp_config_against_oracle():
+    """BASELINE config 'randSDP' (test/base_randsdp.jl + moi_randsdp.jl) at a CPU-comparable
+    size: dense equality rows, variable bounds, n=60 (< 100 -> full_eig! every iteration)."""
+    pr = P.randsdp(60, 40, seed=3)
+    opt = Optimizer(max_iter=400)
+    sol = opt.optimize(pr, trace_capacity=400)
+    o = Options()
+    o.max_iter = 400
+    ref = oracle.solve(pr, o, trace=True)
+    assert sol.status == ref.status and sol.iter == ref.iter
+    G, T = _trace_cols(ref.trace), sol.trace[:, [1, 2, 3, 4, 7, 11]]
+    assert np.array_equal(T[:, 5], G[:, 5])
+    assert np.allclose(T[:60], G[:60], rtol=1e-7, atol=1e-10)
+    assert np.allclose(T[:, :2], G[:, :2], rtol=1e-4, atol=1e-6 * np.abs(G[:, :2]).max())
+    assert sol.stats["full_eigs"] == sol.iter
+
+
+@pytest.mark.parametrize("fname,iters", [("maxG51", 40), ("gpp500-1", 40)])
+def test_sdplib_full_eig_fallback_config(fname, iters, golden_dir):
+    """BASELINE config 'SDPLIB maxG51 / gpp500-1, full-rank fallback eig path'
+    (full_eig_decomp=true: rocSOLVER dsyevd + rank-r+ reconstruction every iteration);
+    gpp500-1 also has the all-ones constraint row of 125 250 entries (long-row SpMV) and,
+    with the reference reader's n = length(c) quirk, side 501."""
+    pr = P.sdplib(golden_dir / "sdplib" / f"{fname}.dat-s")
+    opt = Optimizer(max_iter=iters, full_eig_decomp=1)
+    sol = opt.optimize(pr, trace_capacity=iters)
+    o = Options()
+    o.max_iter = iters
+    o.full_eig_decomp = True
+    ref = oracle.solve(pr, o, trace=True)
+    assert sol.status == ref.status == 3 and sol.iter == ref.iter == iters
+    G, T = _trace_cols(ref.trace), sol.trace[:, [1, 2, 3, 4, 7, 11]]
+    assert np.array_equal(T[:, 5], G[:, 5])
+    assert np.allclose(T, G, rtol=1e-6, atol=1e-8 * np.abs(G).max())
+    assert sol.stats["full_eigs"] == iters and sol.stats["lanczos_matvecs"] == 0
+    assert sol.final_rank == ref.final_rank
+
+
+def test_mimo_dense_vector_path_against_oracle():
+    """BASELINE config 'MIMO' shape at n=120 (side 121 > 100: Lanczos path; every triangle
+    entry is box-constrained, so Mty is dense and the dense vector passes are used)."""
+    pr = P.mimo(120, seed=4)
+    opt = Optimizer(max_iter=150)
+    sol = opt.optimize(pr, trace_capacity=150)
+    o = Options()
+    o.max_iter = 150
+    ref = oracle.solve(pr, o, trace=True)
+    assert sol.status == ref.status and sol.iter == ref.iter
+    G, T = _trace_cols(ref.trace), sol.trace[:, [1, 2, 3, 4, 7, 11]]
+    assert np.array_equal(T[:, 5], G[:, 5])
+    mv = sol.trace[:, 13]
+    tight = max(3, int(np.argmax(mv > 25)) if np.any(mv > 25) else len(T))
+    assert np.allclose(T[:tight], G[:tight], rtol=1e-8, atol=1e-11)
+    assert sol.stats["lanczos_matvecs"] > 0
+
+
 def test_maxcut_n1000_reaches_tolerance():
     """BASELINE config 1 (Max-Cut ER n=1000, single PSD cone): converges to the solver's
     own tolerances; the solution is feasible and PSD; weak duality holds."""
