@@ -86,6 +86,17 @@ typedef struct proxsdp_problem {
      * uses its own counter-based generator (csrc/host_util.hpp, mirrored in
      * oracle/eig.py:start_vector). */
     const double* eig_resid;
+    /* optional block-sharded solve (multi-GPU, one process per GPU).
+     * When reduce_fn != NULL this problem is ONE SHARD of a block-diagonal model (its PSD
+     * blocks/variables and the constraint rows that touch only them).  The library calls
+     *     reduce_fn(reduce_ctx, sums, nsum, maxs, nmax)
+     * with host arrays; the callee must replace sums[] by the element-wise SUM and maxs[] by
+     * the element-wise MAX over all shards (e.g. two RCCL all-reduces) and return 0.  It is
+     * called once at start-up and once per PDHG iteration (plus rare extra calls), by every
+     * shard in the same order.  Only scalars cross shards: the reference's serial loop over
+     * blocks (prox_operators.jl:40) becomes one block set per GPU. */
+    void* reduce_ctx;
+    int (*reduce_fn)(void* ctx, double* sums, int32_t nsum, double* maxs, int32_t nmax);
 } proxsdp_problem;
 
 /* Options (options.jl:1-132): same names, same defaults (proxsdp_hip_default_options).

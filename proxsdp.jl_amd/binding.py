@@ -51,7 +51,11 @@ class Problem(C.Structure):
                 ("b", pf64), ("h", pf64), ("c", pf64),
                 ("n_psd", i64), ("psd_ptr", pi64), ("psd_idx", pi64),
                 ("n_soc", i64), ("soc_ptr", pi64), ("soc_idx", pi64),
-                ("index_base", i32), ("reserved0", i32), ("eig_resid", pf64)]
+                ("index_base", i32), ("reserved0", i32), ("eig_resid", pf64),
+                ("reduce_ctx", C.c_void_p), ("reduce_fn", C.c_void_p)]
+
+
+REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, pf64, i32, pf64, i32)
 
 
 def _opt_fields():
@@ -264,15 +268,32 @@ class SolveResult:
         return [dict(zip(TRACE_NAMES, row)) for row in self.trace]
 
 
-def solve(prob, options=None, eig_resid=None, trace_capacity=0):
+def solve(prob, options=None, eig_resid=None, trace_capacity=0, reduce=None):
     """proxsdp_hip_solve: replaces chambolle_pock(aff, con, options) (MOI_wrapper.jl:310).
     Returns the minimisation objective; sign/constant fix-up is the caller's
-    (MOI_wrapper.jl:336-337), see optimizer.Optimizer."""
+    (MOI_wrapper.jl:336-337), see optimizer.Optimizer.
+    reduce: optional callable(sums: np.ndarray, maxs: np.ndarray) -> None that all-reduces
+    the two arrays in place over the shards of a block-sharded solve (see sharded.py)."""
     L = lib()
     o = options if options is not None else default_options()
     if trace_capacity:
         o.trace_capacity = int(trace_capacity)
     M = _Marshalled(prob, eig_resid)
+    if reduce is not None:
+        def _cb(ctx, ps, ns, pm, nm):
+            try:
+                sums = np.ctypeslib.as_array(ps, shape=(ns,)) if ns > 0 else np.zeros(0)
+                maxs = np.ctypeslib.as_array(pm, shape=(nm,)) if nm > 0 else np.zeros(0)
+                reduce(sums, maxs)
+                return 0
+            except Exception:                      # never unwind into C
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = REDUCE_FN(_cb)
+        M.keep.append(cb)
+        M.P.reduce_fn = C.cast(cb, C.c_void_p)
+        M.P.reduce_ctx = None
     n, p, m = M.P.n, M.P.p, M.P.m
     arrays = [np.zeros(max(k, 1)) for k in (n, n, p, m, p, m)]
     trace = np.zeros((max(o.trace_capacity, 1), TRACE_COLS))

@@ -173,13 +173,13 @@ inline void Solver::residual_and_gap() {
     if (debug && iter <= 5)
         std::fprintf(stderr, "[dbg] it %lld res: %.6e %.6e cx %.6e | %.6e %.6e eq %.6e in %.6e by %.6e hy %.6e\n",
                      iter, s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], s[8]);
-    const double pres = std::sqrt((double)P.n) * s[0] / std::max({s[1], P.norm_b, P.norm_h, 1.0});
-    const double dres = std::sqrt((double)P.Q) * s[3] / std::max({s[4], P.norm_c, 1.0});
+    const double pres = std::sqrt(g_n) * s[0] / std::max({s[1], g_norm_b, g_norm_h, 1.0});
+    const double dres = std::sqrt(g_Q) * s[3] / std::max({s[4], g_norm_c, 1.0});
     h_pres.at(iter) = pres;
     h_dres.at(iter) = dres;
     h_comb.at(iter) = std::max(pres, dres);
-    if (P.p > 0) equa_feasibility = s[5] / (1.0 + P.norm_b);
-    if (P.m > 0) ineq_feasibility = s[6] / (1.0 + P.norm_h);
+    if (P.p > 0) equa_feasibility = s[5] / (1.0 + g_norm_b);
+    if (P.m > 0) ineq_feasibility = s[6] / (1.0 + g_norm_h);
     h_feas.at(iter) = std::max(equa_feasibility, ineq_feasibility);
     const double po = s[2];
     double d_o = 0.0;
@@ -305,7 +305,15 @@ inline void Solver::cache_solution(const std::vector<double>& cvec) {
         for (int64_t q = P.colptr[k]; q < P.colptr[k + 1]; ++q) slack[P.rowidx[q]] += P.val_orig[q] * xk;
     }
     std::vector<double> deq, din, dcone;
-    const double dfeas = dual_feas_host(y, cvec, &deq, &din, &dcone);
+    double dfeas = dual_feas_host(y, cvec, &deq, &din, &dcone);
+    long long fr = 0;
+    for (long long r : current_rank) fr += r;
+    if (sharded()) {                         // dual feasibility and rank over all shards
+        std::vector<double> sums = {(double)fr}, maxs = {dfeas};
+        reduce(sums, maxs);
+        fr = (long long)std::llround(sums[0]);
+        dfeas = maxs[0];
+    }
     res.status = stop_reason;
     std::snprintf(res.status_string, sizeof(res.status_string), "%s", stop_reason_string.c_str());
     if (res.primal)    for (int64_t i = 0; i < P.n; ++i) res.primal[i] = x[P.inv[i]];
@@ -320,8 +328,6 @@ inline void Solver::cache_solution(const std::vector<double>& cvec) {
     res.dual_objval = h_dobj.at(iter);
     res.gap = h_gap.at(iter);
     res.iter = iter;
-    long long fr = 0;
-    for (long long r : current_rank) fr += r;
     res.final_rank = (int32_t)fr;
     res.primal_feasible_user_tol = h_feas.at(iter) <= opt.tol_feasibility;
     res.dual_feasible_user_tol = dfeas <= opt.tol_feasibility_dual;
@@ -422,6 +428,32 @@ inline int Solver::linesearch_residual_support() {
                            bpart.p, PSTRIDE, std::max(gq, gs), ismax, bscal.p);
         PX_HIP(hipMemcpyAsync(hbscal.data(), bscal.p, (NC * 11 + 2) * sizeof(double), hipMemcpyDeviceToHost, stream));
         PX_HIP(hipStreamSynchronize(stream));
+        if (sharded()) {
+            // every shard evaluated the same candidates on its own blocks/rows: combine
+            std::vector<double> sums, maxs;
+            for (int c = 0; c < NC; ++c) {
+                const double* sc = hbscal.data() + 11 * c;
+                for (int q : {0, 1, 4, 9, 10}) sums.push_back(c < nc ? sc[q] : 0.0);
+                for (int q : {2, 3, 5, 6, 7, 8}) maxs.push_back(c < nc ? sc[q] : 0.0);
+            }
+            maxs.push_back(hbscal[NC * 11]); maxs.push_back(hbscal[NC * 11 + 1]);
+            maxs.push_back(convergedrank() ? 0.0 : 1.0);          // any shard not rank-converged
+            bool below = false;
+            for (size_t idx = 0; idx < P.blocks.size(); ++idx) below = below || target_rank[idx] < P.blocks[idx].n;
+            maxs.push_back(below ? 1.0 : 0.0);                    // any block with target_rank < side
+            maxs.push_back(now_s() - time0);                      // one clock for the limits
+            reduce(sums, maxs);
+            size_t si = 0, mi = 0;
+            for (int c = 0; c < NC; ++c) {
+                double* sc = hbscal.data() + 11 * c;
+                for (int q : {0, 1, 4, 9, 10}) sc[q] = sums[si++];
+                for (int q : {2, 3, 5, 6, 7, 8}) sc[q] = maxs[mi++];
+            }
+            hbscal[NC * 11] = maxs[mi++]; hbscal[NC * 11 + 1] = maxs[mi++];
+            g_not_converged_rank = maxs[mi++] > 0.5;
+            g_any_below_full = maxs[mi++] > 0.5;
+            g_elapsed = maxs[mi++];
+        }
         for (int c = 0; c < nc; ++c) {
             ++trials;
             const double* sc = hbscal.data() + 11 * c;
@@ -450,18 +482,18 @@ inline int Solver::linesearch_residual_support() {
     // ---- residuals and gap from the accepted candidate's scalars
     const double m0 = std::max(s_acc[2], hbscal[NC * 11]);
     const double m1 = std::max(s_acc[3], hbscal[NC * 11 + 1]);
-    const double pres = std::sqrt((double)P.n) * m0 / std::max({m1, P.norm_b, P.norm_h, 1.0});
-    const double dres = std::sqrt((double)P.Q) * s_acc[5] / std::max({s_acc[6], P.norm_c, 1.0});
+    const double pres = std::sqrt(g_n) * m0 / std::max({m1, g_norm_b, g_norm_h, 1.0});
+    const double dres = std::sqrt(g_Q) * s_acc[5] / std::max({s_acc[6], g_norm_c, 1.0});
     h_pres.at(iter) = pres;
     h_dres.at(iter) = dres;
     h_comb.at(iter) = std::max(pres, dres);
-    if (P.p > 0) equa_feasibility = s_acc[7] / (1.0 + P.norm_b);
-    if (P.m > 0) ineq_feasibility = s_acc[8] / (1.0 + P.norm_h);
+    if (g_p > 0) equa_feasibility = s_acc[7] / (1.0 + g_norm_b);
+    if (g_m > 0) ineq_feasibility = s_acc[8] / (1.0 + g_norm_h);
     h_feas.at(iter) = std::max(equa_feasibility, ineq_feasibility);
     const double po = s_acc[4];
     double d_o = 0.0;
-    if (P.p > 0) d_o -= s_acc[9];
-    if (P.m > 0) d_o -= s_acc[10];
+    if (g_p > 0) d_o -= s_acc[9];
+    if (g_m > 0) d_o -= s_acc[10];
     h_pobj.at(iter) = po;
     h_dobj.at(iter) = d_o;
     h_gap.at(iter) = std::fabs(po - d_o) / (1.0 + std::fabs(po) + std::fabs(d_o));
@@ -511,7 +543,21 @@ inline void Solver::run() {
     const size_t nb = P.blocks.size();
     target_rank.assign(nb, 2); current_rank.assign(nb, 2); min_eig.assign(nb, 0.0);
     time_limit = opt.time_limit;
-    if (opt.max_iter <= 0) max_iter_local = (nb > 0 || !P.socs.empty()) ? opt.max_iter_conic : opt.max_iter_lp;
+    {   // global constants (sums over shards of a block-sharded solve; local values otherwise)
+        std::vector<double> sums = {(double)P.n, (double)P.p, (double)P.m, P.norm_b * P.norm_b, P.norm_h * P.norm_h,
+                                    P.norm_c * P.norm_c, P.frob * P.frob};
+        std::vector<double> maxs = {(nb > 0 || !P.socs.empty()) ? 1.0 : 0.0};
+        reduce(sums, maxs);
+        g_n = sums[0]; g_p = sums[1]; g_m = sums[2]; g_Q = g_p + g_m;
+        g_norm_b = sharded() ? std::sqrt(sums[3]) : P.norm_b;
+        g_norm_h = sharded() ? std::sqrt(sums[4]) : P.norm_h;
+        g_norm_c = sharded() ? std::sqrt(sums[5]) : P.norm_c;
+        g_frob = sharded() ? std::sqrt(sums[6]) : P.frob;
+        g_conic = maxs[0] > 0.5;
+    }
+    if (sharded() && (opt.check_dual_feas || opt.support_path == 0 || !opt.line_search_flag))
+        throw std::domain_error("block-sharded solve: check_dual_feas / dense vector passes / no linesearch not implemented");
+    if (opt.max_iter <= 0) max_iter_local = g_conic ? opt.max_iter_conic : opt.max_iter_lp;
     else max_iter_local = opt.max_iter;
     int ada_count = 0;
     h_gap.init(2 * window); h_pobj.init(2 * window); h_dobj.init(2 * window); h_feas.init(2 * window);
@@ -585,8 +631,11 @@ inline void Solver::run() {
         soc_off.upload(so.data(), so.size(), stream); soc_len.upload(sl.data(), sl.size(), stream);
         PX_HIP(hipStreamSynchronize(stream));
     }
+    if (sharded()) opt.support_path = 1;                 // the sharded loop is built on the batched path
     setup_support();
-    double spectral_norm = P.frob;                       // LinearAlgebra.norm(M), pdhg.jl:121
+    if (sharded() && !use_support)
+        throw std::domain_error("block-sharded solve needs the support-aware path (no SOC / 1x1 cones)");
+    double spectral_norm = g_frob;                       // LinearAlgebra.norm(M), pdhg.jl:121
     if (spectral_norm < 1e-10) spectral_norm = 1.0;
     primal_step = 1.0 / spectral_norm;
     primal_step_old = primal_step;
@@ -681,6 +730,11 @@ inline void Solver::run() {
                     PX_HIP(hipStreamSynchronize(stream));
                     std::vector<double> zc(P.n, 0.0);
                     dual_feasibility = dual_feas_host(y, zc, nullptr, nullptr, nullptr);
+                    if (sharded()) {
+                        std::vector<double> sums, maxs = {dual_feasibility};
+                        reduce(sums, maxs);
+                        dual_feasibility = maxs[0];
+                    }
                     if (dual_feasibility < opt.tol_feasibility_dual) {
                         certificate_found = true;
                         stop_reason_string += " [Dual ray found]";
@@ -705,7 +759,7 @@ inline void Solver::run() {
         rank_update += 1;
         if (h_gap.at(iter) <= opt.tol_gap && h_feas.at(iter) <= opt.tol_feasibility &&
             (!opt.check_dual_feas || dual_feasibility < opt.tol_feasibility_dual)) {
-            if (convergedrank() && soc_convergence() && iter > opt.min_iter) {
+            if ((sharded() ? !g_not_converged_rank : convergedrank()) && soc_convergence() && iter > opt.min_iter) {
                 if (!certificate_search) {
                     stop_reason = 1;
                     stop_reason_string = "Optimal solution found";
@@ -723,6 +777,7 @@ inline void Solver::run() {
         } else if (k > window && h_comb.at(k - window) < h_comb.at(k) && rank_update > window) {
             update_cont += 1;
             if (update_cont > opt.divergence_min_update) {
+                if (sharded() && g_any_below_full) { rank_update = 0; update_cont = 0; }
                 for (size_t idx = 0; idx < nb; ++idx) {
                     if (target_rank[idx] < P.blocks[idx].n) { rank_update = 0; update_cont = 0; }
                     bump_rank((int)idx);
@@ -745,7 +800,8 @@ inline void Solver::run() {
         }
 
         // ---- iteration / time limits (pdhg.jl:334-382)
-        if (iter >= max_iter_local || now_s() - time0 >= time_limit) {
+        const double elapsed = sharded() ? g_elapsed : now_s() - time0;
+        if (iter >= max_iter_local || elapsed >= time_limit) {
             if (iter > opt.min_iter_time_infeas && h_gap.max_abs_diff() < opt.infeas_stable_gap_tol &&
                 h_gap.at(k) > opt.infeas_limit_gap_tol) {
                 if (h_feas.at(iter) <= opt.tol_feasibility / 100) {
@@ -769,7 +825,7 @@ inline void Solver::run() {
                 stop_reason_string = "Time limit hit, limit: " + std::to_string(time_limit) +
                                      " time: " + std::to_string(now_s() - time0);
             }
-            if (iter >= max_iter_local || now_s() - time0 >= time_limit) break;
+            if (iter >= max_iter_local || elapsed >= time_limit) break;
         }
         if (opt.certificate_search && certificate_search) continue;
 

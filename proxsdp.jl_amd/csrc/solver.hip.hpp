@@ -148,6 +148,8 @@ public:
         : opt(opt_in), res(res_out), P(prepare(prob)) {
         time0 = now_s();
         user_resid = prob.eig_resid;
+        reduce_fn = prob.reduce_fn;
+        reduce_ctx = prob.reduce_ctx;
     }
     // engine-only instance for the kernel-level test entry points (no problem data)
     Solver(const proxsdp_options& opt_in, proxsdp_result& res_out) : opt(opt_in), res(res_out) {
@@ -189,6 +191,19 @@ public:
     proxsdp_stats st{};
     double time0 = 0;
     const double* user_resid = nullptr;
+    // block-sharded solve: scalar all-reduce across shards (include/proxsdp_hip.h)
+    int (*reduce_fn)(void*, double*, int32_t, double*, int32_t) = nullptr;
+    void* reduce_ctx = nullptr;
+    bool sharded() const { return reduce_fn != nullptr; }
+    void reduce(std::vector<double>& sums, std::vector<double>& maxs) {
+        if (!reduce_fn) return;
+        if (reduce_fn(reduce_ctx, sums.data(), (int32_t)sums.size(), maxs.data(), (int32_t)maxs.size()) != 0)
+            throw std::runtime_error("reduce_fn failed");
+    }
+    // global (all-shard) problem constants; equal to the local ones when not sharded
+    double g_n = 0, g_Q = 0, g_p = 0, g_m = 0, g_norm_b = 0, g_norm_h = 0, g_norm_c = 0, g_frob = 0;
+    bool g_conic = false, g_not_converged_rank = false, g_any_below_full = false;
+    double g_elapsed = 0;
     std::thread warm;               // loads rocSOLVER's code objects while the loop runs
     void start_rocsolver_warmup();
 

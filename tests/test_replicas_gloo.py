@@ -45,3 +45,51 @@ def test_block_assignment():
     assert replicas.assign_blocks(8, 8) == list(range(8))
     assert replicas.assign_blocks(8, 2) == [0, 1, 0, 1, 0, 1, 0, 1]
     assert replicas.assign_blocks(3, 1) == [0, 0, 0]
+
+
+# ----------------------------------------------------------------- block-sharded path (host side)
+def test_split_block_diagonal():
+    import numpy as np
+    from proxsdp_jl_amd import problems, sharded
+    a, b = problems.mimo(3, seed=1), problems.maxcut(5, seed=2)
+    pr = problems.block_diag_problems([a, b])
+    s0, m0 = sharded.split_block_diagonal(pr, [0, 1], 0)
+    s1, m1 = sharded.split_block_diagonal(pr, [0, 1], 1)
+    assert s0.n == a.n and s1.n == b.n
+    assert (s0.A != a.A).nnz == 0 and (s0.G != a.G).nnz == 0 and np.array_equal(s0.c, a.c)
+    assert (s1.A != b.A).nnz == 0 and np.array_equal(s1.b, b.b) and s1.G.shape[0] == 0
+    assert np.array_equal(np.sort(np.concatenate([m0["vars"], m1["vars"]])), np.arange(pr.n))
+    # a row coupling the two blocks is rejected
+    import scipy.sparse as sp
+    bad = problems.Problem(n=pr.n, A=sp.vstack([pr.A, sp.csr_matrix(([1.0, 1.0], ([0, 0], [0, pr.n - 1])), shape=(1, pr.n))]).tocsc(),
+                           b=np.append(pr.b, 0.0), G=pr.G, h=pr.h, c=pr.c, psd=pr.psd)
+    with pytest.raises(ValueError):
+        sharded.split_block_diagonal(bad, [0, 1], 0)
+
+
+def _reduce_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import numpy as np
+    from proxsdp_jl_amd import sharded
+    dist = replicas.init("gloo", rank, world)
+    red = sharded.make_reduce(dist)
+    sums = np.array([1.0 + rank, 10.0]); maxs = np.array([float(rank), -1.0 - rank, 5.0])
+    red(sums, maxs)
+    q.put((rank, sums.tolist(), maxs.tolist()))
+    dist.destroy_process_group()
+
+
+def test_sharded_reduce_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 200)
+    procs = [ctx.Process(target=_reduce_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, sums, maxs in out:
+        assert sums == [3.0, 20.0] and maxs == [1.0, -1.0, 5.0]
