@@ -568,7 +568,10 @@ inline void Solver::run() {
     setup_device();
     bool big_block = false;
     for (const BlockInfo& B : P.blocks) big_block = big_block || B.n >= 256;
-    if (big_block && std::getenv("PROXSDP_HIP_NO_WARMUP") == nullptr) start_rocsolver_warmup();
+    // opt-in only: measured on MI355X/ROCm 7.2, loading rocSOLVER's code objects from a second
+    // thread stalls this thread's kernel launches (a 0.3 s solve took 8 s), so by default the
+    // exit path pays the one-off ~3 s initialisation itself in a cold process
+    if (big_block && std::getenv("PROXSDP_HIP_WARMUP") != nullptr) start_rocsolver_warmup();
     for (int k = 0; k < 2; ++k) {
         xbuf[k].alloc(P.n); Mtybuf[k].alloc(P.n);
         ybuf[k].alloc(std::max<int64_t>(P.Q, 1)); Mxbuf[k].alloc(std::max<int64_t>(P.Q, 1));

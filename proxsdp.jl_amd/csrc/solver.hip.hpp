@@ -313,8 +313,9 @@ inline void Solver::setup_device() {
 }
 
 // rocSOLVER's first dsyevd in a process pays ~3 s of code-object loading.  The exit path
-// (cone_feas, pdhg.jl:685) always needs one; do a 2x2 dummy on a private handle/stream in
-// the background so that cost overlaps the PDHG loop instead of adding to SolveTimeSec.
+// (cone_feas, pdhg.jl:685) always needs one.  Optional (PROXSDP_HIP_WARMUP=1): a dummy dsyevd
+// on a private handle/stream in a background thread -- OFF by default because the loader
+// serialises against the solver thread's launches.
 inline void Solver::start_rocsolver_warmup() {
     const int dev_id = opt.device_id;
     warm = std::thread([dev_id]() {
