@@ -489,33 +489,36 @@ k_symv_finish(const double* __restrict__ xp, int n, int nt, int npad, double* __
         symv_tiles(xp, n, npad, nt * (nt + 1) / 2, wbuf, Ppart, (int)blockIdx.x - nt, (int)gridDim.x - nt, s_a, s_b);
 }
 
-// out[:, c] = sum_j V[:, j] U[j, c]  (basis rotation at a thick restart and the
-// final Ritz vectors B*v, KrylovKit eigsolve); optional extra column copy.
+// out[:, c] = sum_j V[:, j] U[j, c]  (basis rotation at a thick restart and the final Ritz
+// vectors B*v, KrylovKit eigsolve); optional extra column copy.  A small GEMM: each
+// workgroup stages its 64-row tile of V (64 x K) and U (K x ncols) in LDS once, thread
+// (row, c mod 4) then produces the outputs (row, c), c = c mod 4, +4, ...
 __global__ void __launch_bounds__(TPB)
 k_lz_rotate(const double* __restrict__ V, int ldv, int n, int K, const double* __restrict__ U, int ldu,
             int ncols, double* __restrict__ out, int ldo, int copy_src, int copy_dst) {
-    extern __shared__ double s_U[];           // K x ncols
+    extern __shared__ double s_mem[];
+    double* s_U = s_mem;                          // [c][j], K x ncols
+    double* s_V = s_mem + (size_t)K * ncols;      // [j][r], K x 64 (+1 pad per column)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = blockIdx.x * LZ_ROWS + lane;    // < npad (ldv = npad), padding rows are zero
     for (int t = threadIdx.x; t < K * ncols; t += TPB) {
-        int j = t % K, c = t / K;
+        const int j = t % K, c = t / K;
         s_U[t] = U[(long long)c * ldu + j];
     }
+    for (int j = wv; j < K; j += NWAVE) s_V[j * (LZ_ROWS + 1) + lane] = V[(long long)j * ldv + i];
     __syncthreads();
-    const int i = blockIdx.x * TPB + threadIdx.x;
-    if (i >= n) return;
-    for (int c0 = 0; c0 < ncols; c0 += 8) {
-        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        const int cn = min(8, ncols - c0);
-        for (int j = 0; j < K; ++j) {
-            const double vij = V[(long long)j * ldv + i];
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-                if (c < cn) acc[c] += vij * s_U[(c0 + c) * K + j];
+    for (int c = wv; c < ncols; c += NWAVE) {
+        const double* u = s_U + (size_t)c * K;
+        double a0 = 0.0, a1 = 0.0;
+        int j = 0;
+        for (; j + 1 < K; j += 2) {
+            a0 += s_V[j * (LZ_ROWS + 1) + lane] * u[j];
+            a1 += s_V[(j + 1) * (LZ_ROWS + 1) + lane] * u[j + 1];
         }
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-            if (c < cn) out[(long long)(c0 + c) * ldo + i] = acc[c];
+        if (j < K) a0 += s_V[j * (LZ_ROWS + 1) + lane] * u[j];
+        out[(long long)c * ldo + i] = a0 + a1;
     }
-    if (copy_src >= 0) out[(long long)copy_dst * ldo + i] = V[(long long)copy_src * ldv + i];
+    if (copy_src >= 0 && wv == 0) out[(long long)copy_dst * ldo + i] = V[(long long)copy_src * ldv + i];
 }
 
 // ---------------------------------------------------------------------------

@@ -412,13 +412,15 @@ inline void Solver::rotate(EigWork& W, int K, const std::vector<double>& U, int 
     for (int c = 0; c < ncols; ++c)
         for (int j = 0; j < K; ++j) tmp[(size_t)c * K + j] = U[(size_t)c * ldu + j];
     W.U.upload(tmp.data(), (size_t)K * ncols, stream);
-    const int maxcols = std::max(1, (int)(40 * 1024 / (8 * K)));   // keep dynamic LDS <= 40 KiB
+    // dynamic LDS: U chunk (K x cn) + V tile (K x 65); keep it <= 60 KiB
+    const int vbytes = K * (dev::LZ_ROWS + 1) * 8;
+    const int maxcols = std::max(1, (60 * 1024 - vbytes) / (8 * K));
     int c0 = 0;
     do {
         const int cn = std::max(0, std::min(maxcols, ncols - c0));
         const bool last = (c0 + cn >= ncols);
         if (cn > 0 || (last && copy_src >= 0))
-            hipLaunchKernelGGL(dev::k_lz_rotate, dim3(W.nwg), dim3(dev::TPB), (size_t)K * cn * 8, stream,
+            hipLaunchKernelGGL(dev::k_lz_rotate, dim3(W.nt), dim3(dev::TPB), (size_t)K * cn * 8 + vbytes, stream,
                                W.V.p, W.npad, W.n, K, W.U.p + (size_t)c0 * K, K, cn,
                                out + (size_t)c0 * W.npad, W.npad, last ? copy_src : -1, copy_dst - c0);
         c0 += std::max(cn, 1);
