@@ -195,10 +195,10 @@ int proxsdp_hip_symv_packed(const double* packed, int64_t n, const double* v, do
         vd.zero(S.stream);
         vd.upload(v, n, S.stream);
         PX_HIP(hipMemsetAsync(W.ctl_p, 0, sizeof(proxsdp::dev::LanczosCtl), S.stream));
-        // y = (sum of partials)/sqrt2 through the first Lanczos kernel with an empty basis (k = -1)
+        // y = (sum of partials)/sqrt2
         S.launch_symv(W, x.p, vd.p, false);
-        hipLaunchKernelGGL(proxsdp::dev::k_lz_dots1, dim3(W.nt), dim3(proxsdp::dev::TPB), 0, S.stream,
-                           W.Ppart.p, W.nt, W.n, W.npad, W.V.p, W.npad, -1, W.w.p, W.hpart1.p, W.pld, W.ctl_p, W.betas_p, -1);
+        hipLaunchKernelGGL(proxsdp::dev::k_symv_collect, dim3(W.nt), dim3(proxsdp::dev::TPB), 0, S.stream,
+                           W.Ppart.p, W.nt, W.npad, W.w.p);
         W.w.download(y, n, S.stream);
         PX_HIP(hipStreamSynchronize(S.stream));
         if (repeat > 0 && ms) {

@@ -203,9 +203,13 @@ __device__ __forceinline__ void symv_load(const double* __restrict__ xp, int n, 
     }
 }
 // Reduce phase: row sums (LDS meeting of the 4 waves) and column sums (in-register fold).
+// Also emits this tile's share of v' P~ v (2 * v_I' T v_J for an off-diagonal tile) into
+// Apart[tile]: summed over tiles it gives the Rayleigh quotient alpha without a separate
+// dot-product kernel.
 __device__ __forceinline__ void symv_reduce(int npad, const double* __restrict__ v, double* __restrict__ Ppart,
                                             int tile, int lane, int wv, double (&t)[CPW],
-                                            double* __restrict__ s_row, double* __restrict__ s_col) {
+                                            double* __restrict__ s_row, double* __restrict__ s_col,
+                                            double* __restrict__ Apart) {
     int I, J;
     tile_coords(tile, I, J);
     const int gi = I * TILE + lane;
@@ -221,6 +225,7 @@ __device__ __forceinline__ void symv_reduce(int npad, const double* __restrict__
         if (diag && gi == j0 + c) t[c] = 0.0;        // the diagonal entry is in the row sum only
     }
     s_row[wv * TILE + lane] = racc;
+    const double aw = diag ? 0.0 : wave_sum(vi * racc);           // this wave's share of v_I' T v_J
     // column sums: fold 16 columns over lane bits 3..0, then all-reduce over bits 4,5
     fold_stage<8>(t, lane);
     fold_stage<4>(t, lane);
@@ -236,11 +241,16 @@ __device__ __forceinline__ void symv_reduce(int npad, const double* __restrict__
         if (wv == 0) {
             const double rs = (s_row[lane] + s_row[TILE + lane]) + (s_row[2 * TILE + lane] + s_row[3 * TILE + lane]);
             Ppart[(long long)I * npad + gi] = rs + s_col[lane];
+            const double a = wave_sum(vi * (rs + s_col[lane]));   // v_I' P~_II v_I
+            if (lane == 0) Apart[tile] = a;
         }
     } else {
+        if (lane == 0) s_col[wv] = aw;           // s_col is free on off-diagonal tiles
+        __syncthreads();
         if (wv == 0) {
             const double rs = (s_row[lane] + s_row[TILE + lane]) + (s_row[2 * TILE + lane] + s_row[3 * TILE + lane]);
             Ppart[(long long)J * npad + gi] = rs;                    // rows of block I, slot J
+            if (lane == 0) Apart[tile] = 2.0 * ((s_col[0] + s_col[1]) + (s_col[2] + s_col[3]));
         }
         if (lane < CPW) Ppart[(long long)I * npad + j0 + lane] = cs; // rows of block J, slot I
     }
@@ -262,7 +272,7 @@ constexpr int SYMV_TPW = 1;          // measured: 2 tiles/workgroup is not faste
 __device__ __forceinline__ void symv_tiles(const double* __restrict__ xp, int n, int npad, int ntile,
                                            const double* __restrict__ v, double* __restrict__ Ppart,
                                            int first, int stride, double* __restrict__ s_row,
-                                           double* __restrict__ s_col) {
+                                           double* __restrict__ s_col, double* __restrict__ Apart) {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     double ta[CPW], tb[CPW];
@@ -274,7 +284,7 @@ __device__ __forceinline__ void symv_tiles(const double* __restrict__ xp, int n,
         const int next = tile + stride;
         const bool has_next = (it + 1 < SYMV_TPW) && (next < ntile);
         if (has_next) symv_load(xp, n, next, lane, wv, tb);
-        symv_reduce(npad, v, Ppart, tile, lane, wv, ta, s_row + (it & 1) * (NWAVE * TILE), s_col + (it & 1) * TILE);
+        symv_reduce(npad, v, Ppart, tile, lane, wv, ta, s_row + (it & 1) * (NWAVE * TILE), s_col + (it & 1) * TILE, Apart);
         if (!has_next) break;
 #pragma unroll
         for (int c = 0; c < CPW; ++c) ta[c] = tb[c];
@@ -285,26 +295,30 @@ __device__ __forceinline__ void symv_tiles(const double* __restrict__ xp, int n,
 __global__ void __launch_bounds__(TPB)
 k_symv_packed(const double* __restrict__ xp, int n, int nt, int npad,
               const double* __restrict__ v, double* __restrict__ Ppart,
-              const LanczosCtl* __restrict__ ctl) {
+              const LanczosCtl* __restrict__ ctl, double* __restrict__ Apart) {
     if (ctl != nullptr && ctl->stop) return;
     __shared__ double s_row[2 * NWAVE * TILE];
     __shared__ double s_col[2 * TILE];
-    symv_tiles(xp, n, npad, nt * (nt + 1) / 2, v, Ppart, blockIdx.x, gridDim.x, s_row, s_col);
+    symv_tiles(xp, n, npad, nt * (nt + 1) / 2, v, Ppart, blockIdx.x, gridDim.x, s_row, s_col, Apart);
 }
 
 // ---------------------------------------------------------------------------
-// Lanczos recurrence with full re-orthogonalisation (two classical Gram-Schmidt
-// passes against the whole basis), scalars kept on the device: replaces the
-// BLAS-1 work inside KrylovKit's LanczosIterator (call site eigsolver.jl:802).
-//   dots1  : w = (sum of symv partials)/sqrt2 ; hpart = V[:,0..k]' w
-//   apply  : w' = w - V h1 ; hpart2 = V' w' and |w'|^2
-//   finish : beta_k^2 = |w'|^2 - |h2|^2 ; alpha_k = h1[k]+h2[k] ; V[:,k+1] = (w' - V h2)/beta_k, or stop
-// Three dependent launches per Lanczos step after the mat-vec (each boundary is a
-// global reduction).
-// Grid = nt workgroups of 64 rows; the 4 waves of a workgroup split the slots
-// (dots1) and the basis columns j (all kernels) and meet in LDS.  These kernels
-// are latency-bound (n*K*8 bytes of L2-resident basis), so the point of the
-// layout is parallel width, not bytes.
+// Lanczos recurrence with full re-orthogonalisation, scalars kept on the device:
+// replaces the BLAS-1 work inside KrylovKit's LanczosIterator (call site
+// eigsolver.jl:802; orth = two Gram-Schmidt passes against the whole basis).
+// TWO dependent launches per Lanczos step:
+//   k_symv_finish : closes step k-1 (beta^2 = |w'|^2 - |h2|^2, alpha, v_k = (w' - V h2)/beta,
+//                   or stop) in nt workgroups while the other workgroups run the mat-vec
+//                   tiles of step k on the un-corrected w'
+//   k_lz_orth     : w = A w'/beta from the partial slots; first pass PREDICTED from the
+//                   Lanczos relation (recurrence terms + image of the un-applied correction);
+//                   second pass MEASURED: hpart = V' w', |w'|^2
+// Every kernel boundary is a global reduction; a measured first pass would cost a third
+// launch per step (14.1 + 7.2 + 8.5 us -> 14.1 + 7.4 us at n = 4000, K = 53).
+// Grid = nt workgroups of 64 rows; the 4 waves of a workgroup split the slots and the
+// basis columns j and meet in LDS.  These kernels are latency-bound (n*K*8 bytes of
+// L2-resident basis), so the point of the layout is parallel width and loads in flight,
+// not bytes.
 // ---------------------------------------------------------------------------
 constexpr int MAXK = 160;           // capacity of the Krylov basis (krylovdim+1 < MAXK)
 constexpr int LZ_ROWS = TILE;       // rows per workgroup in the Lanczos vector kernels
@@ -354,58 +368,167 @@ __device__ __forceinline__ void lz_reduce_partials(const double* __restrict__ hp
     __syncthreads();
 }
 
+// y = smat(xp) v from the mat-vec partial slots (test seam / residual checks):
+// w = (sum of slots) / sqrt2, fixed order.
 __global__ void __launch_bounds__(TPB)
-k_lz_dots1(const double* __restrict__ Ppart, int nt, int n, int npad,
-           const double* __restrict__ V, int ldv, int k,
-           double* __restrict__ wbuf, double* __restrict__ hpart, int pld, const LanczosCtl* __restrict__ ctl,
-           const double* __restrict__ betas, int scale_idx) {
-    if (ctl->stop) return;
+k_symv_collect(const double* __restrict__ Ppart, int nt, int npad, double* __restrict__ wbuf) {
     __shared__ double s_acc[NWAVE][LZ_ROWS];
-    // the mat-vec ran on the un-normalised w' of step scale_idx (see k_symv_finish)
-    const double scale = (scale_idx >= 0) ? INV_SQRT2 / betas[scale_idx] : INV_SQRT2;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int i = blockIdx.x * LZ_ROWS + lane;       // < npad always; rows >= n carry zeros
-    double a0 = 0.0, a1 = 0.0;
-    int s = wv;
-    for (; s + NWAVE < nt; s += 2 * NWAVE) {
-        a0 += Ppart[(long long)s * npad + i];
-        a1 += Ppart[(long long)(s + NWAVE) * npad + i];
-    }
-    if (s < nt) a0 += Ppart[(long long)s * npad + i];
-    s_acc[wv][lane] = a0 + a1;
+    const int i = blockIdx.x * LZ_ROWS + lane;
+    double a0 = 0.0;
+    for (int s = wv; s < nt; s += NWAVE) a0 += Ppart[(long long)s * npad + i];
+    s_acc[wv][lane] = a0;
     __syncthreads();
-    const double wi = ((s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane])) * scale;
-    if (wv == 0) wbuf[i] = wi;
-    lz_dots(V, ldv, k + 1, i, wi, wv, lane, hpart, pld, blockIdx.x);
+    if (wv == 0) wbuf[i] = ((s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane])) * INV_SQRT2;
 }
 
-// first Gram-Schmidt pass applied, second pass measured:
-//   h1 = sum of partial dots;  w' = w - V h1;  hpart_out = V' w' and |w'|^2 (slot NRM_SLOT)
+// Lanczos recurrence and re-orthogonalisation measurements of step k in ONE kernel.
+//
+// The mat-vec of step k ran on the un-normalised, un-corrected w'_{k-1} (see k_symv_finish):
+// with h = h2_{k-1} (the measured pass of step k-1), beta = beta_{k-1} and the Lanczos
+// relation A V_{k-1} = V_{k-1} T_{k-1} + v_k r',
+//     w = A w'_{k-1}/beta = A v_k + V_{k-1} (T_{k-1} h)/beta + v_k c,     c = r'h/beta = h[k-1].
+// The bracketed terms are KNOWN (T is on the device: alphas/betas, and after a thick restart
+// the arrow part D, f in `arrow`), so they are subtracted here together with the recurrence
+// terms, instead of being measured by a separate dot-product launch.  Left unsubtracted they
+// would be re-injected every step and grow like (|T|/beta)^k.
+//     alpha~ = w' P~ w' / (sqrt2 beta^2)  from the mat-vec tiles' shares  (= alpha_k + 2c)
+//     w'     = w - V_{k-1} (T h/beta + r) - v_k (alpha~ - c)
+// then ONE measured full pass: hpart_out = V_k' w' and |w'|^2, applied by the closing kernel.
+// hsum_out[k] = alpha~ - c, so the closing kernel's alpha_k = hsum[k] + h2[k] - carry holds.
+// `first`: v_k is an exact, normalised basis vector (start of a cycle): no correction terms;
+// after a restart (keep > 0, k == keep) r = f.
+// arrow[0..MAXK) = f, arrow[MAXK..2 MAXK) = D (Ritz values), valid for indices < keep.
+// Latency-bound kernel (63 workgroups at n = 4000): EVERY global load is issued before the
+// first use, and each wave keeps its basis columns j = wv + 4c in registers for both the
+// subtraction and the measured pass; 16 column sums are reduced together by the fold network
+// of the mat-vec (15 + 2 DPP steps instead of 16 x 6).  NCH = 16-column chunks per wave
+// (k + 1 <= 64 NCH).
+__device__ __forceinline__ double fold16_all(double (&t)[16], int lane) {
+    fold_stage<8>(t, lane);
+    fold_stage<4>(t, lane);
+    fold_stage<2>(t, lane);
+    fold_stage<1>(t, lane);
+    return add_xor32(add_xor16(t[0]));               // lane holds column (lane & 15)
+}
+template <int NCH>
 __global__ void __launch_bounds__(TPB)
-k_lz_apply(double* __restrict__ wbuf, int n, const double* __restrict__ V, int ldv, int k,
-           const double* __restrict__ hpart_in, int pld, double* __restrict__ hsum_out,
-           double* __restrict__ hpart_out, const LanczosCtl* __restrict__ ctl) {
+k_lz_orth(const double* __restrict__ Ppart, int nt, int npad, const double* __restrict__ V, int ldv, int k,
+          double* __restrict__ wbuf, const double* __restrict__ hpart_prev, double* __restrict__ hpart_out, int pld,
+          double* __restrict__ hsum_out, const LanczosCtl* __restrict__ ctl,
+          const double* __restrict__ alphas, const double* __restrict__ betas,
+          const double* __restrict__ Apart, int napart, int first, const double* __restrict__ arrow, int keep) {
     if (ctl->stop) return;
-    __shared__ double s_h[MAXK];
-    __shared__ double s_d[NWAVE][LZ_ROWS];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int kk = k + 1;
-    lz_reduce_partials(hpart_in, pld, kk, false, s_h);
-    if (blockIdx.x == 0)
-        for (int j = threadIdx.x; j < kk; j += TPB) hsum_out[j] = s_h[j];
-    const int i = blockIdx.x * LZ_ROWS + lane;
-    double d = 0.0;
-    for (int j = wv; j < kk; j += NWAVE) d += V[(long long)j * ldv + i] * s_h[j];
-    s_d[wv][lane] = d;
-    const double w0 = wbuf[i];
+    constexpr int NC = 16 * NCH;
+    __shared__ double s_h[4 * NC];
+    __shared__ double s_q[4 * NC];
+    __shared__ double s_acc[NWAVE][LZ_ROWS];
+    __shared__ double s_red[NWAVE];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i = blockIdx.x * LZ_ROWS + lane;       // < npad always; rows >= n carry zeros
+    // ---- all loads
+    double pv[16];                                   // mat-vec partial slots wv, wv+4, ...
+#pragma unroll
+    for (int u = 0; u < 16; ++u) pv[u] = Ppart[(long long)min(wv + u * NWAVE, nt - 1) * npad + i];
+    double av[8];                                    // per-tile shares of w' P~ w'
+#pragma unroll
+    for (int u = 0; u < 8; ++u) av[u] = Apart[min((int)threadIdx.x + u * TPB, napart - 1)];
+    double vr[NC];                                   // basis columns of this wave (column k included)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) vr[c] = V[(long long)min(wv + 4 * c, k) * ldv + i];
+    double hp[NC];                                   // partial dots of step k-1, one workgroup share per lane
+    const int gl = min(lane, pld - 1);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) hp[c] = hpart_prev[(long long)min(wv + 4 * c, MAXK - 1) * pld + gl];
+    const double binv = first ? 1.0 : 1.0 / betas[k - 1];
+    // ---- reductions
+#pragma unroll
+    for (int u = 0; u < 16; ++u) if (wv + u * NWAVE >= nt) pv[u] = 0.0;
+    double acc = (((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]))) +
+                 (((pv[8] + pv[9]) + (pv[10] + pv[11])) + ((pv[12] + pv[13]) + (pv[14] + pv[15])));
+    for (int s = wv + 16 * NWAVE; s < nt; s += NWAVE) acc += Ppart[(long long)s * npad + i];      // n > 4096
+    s_acc[wv][lane] = acc;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) if ((int)threadIdx.x + u * TPB >= napart) av[u] = 0.0;
+    double a = ((av[0] + av[1]) + (av[2] + av[3])) + ((av[4] + av[5]) + (av[6] + av[7]));
+    for (int t = threadIdx.x + 8 * TPB; t < napart; t += TPB) a += Apart[t];                      // n > 4096
+    a = wave_sum(a);
+    if (lane == 0) s_red[wv] = a;
+    if (!first) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int j = wv + 4 * c;
+            if (lane >= pld || j >= k) hp[c] = 0.0;
+            else for (int g = lane + WAVE; g < pld; g += WAVE) hp[c] += hpart_prev[(long long)j * pld + g];   // n > 4096
+        }
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            double t[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) t[c] = hp[16 * ch + c];
+            const double hs = fold16_all(t, lane);
+            if (lane < 16) s_h[wv + 4 * (16 * ch + lane)] = hs;          // zero for j >= k
+        }
+    }
     __syncthreads();
-    const double wi = w0 - ((s_d[0][lane] + s_d[1][lane]) + (s_d[2][lane] + s_d[3][lane]));
+    // ---- coefficients: s_q[j], j < k, over V_{k-1}; s_q[k] = coefficient of v_k
+    const double alpha = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) * INV_SQRT2 * binv * binv;
+    const double wi = ((s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane])) * (INV_SQRT2 * binv);
+    double ck = alpha;
+    const int j = threadIdx.x;
+    if (first) {
+        if (j < keep) s_q[j] = arrow[j];
+    } else {
+        ck -= s_h[k - 1];
+        double fh = 0.0;
+        if (keep > 0 && k > keep) {                   // f'h (row `keep` of the arrow)
+            for (int jj = lane; jj < keep; jj += WAVE) fh += arrow[jj] * s_h[jj];
+            fh = wave_sum(fh);
+        }
+        if (j < k) {
+            const double hj = s_h[j];
+            double t;
+            if (j < keep) {
+                t = arrow[MAXK + j] * hj + (k > keep ? arrow[j] * s_h[keep] : 0.0);
+            } else {
+                t = alphas[j] * hj;
+                if (j + 1 < k) t += betas[j] * s_h[j + 1];
+                if (j == keep) t += fh;                               // fh = 0 when keep == 0
+                else if (j > 0) t += betas[j - 1] * s_h[j - 1];
+            }
+            s_q[j] = t * binv + (j == k - 1 ? betas[k - 1] : 0.0);
+        }
+    }
+    if (j == k) s_q[k] = ck;
+    __syncthreads();
+    // ---- w' = w - V q   (each wave its own columns, from registers)
+    double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+    for (int c = 0; c < NC; c += 2) {
+        const int j0 = wv + 4 * c, j1 = j0 + 4;
+        if (j0 <= k) d0 += vr[c] * s_q[j0];
+        if (j1 <= k) d1 += vr[c + 1] * s_q[j1];
+    }
+    s_acc[wv][lane] = d0 + d1;                        // (all reads of s_acc for wi precede the barrier above)
+    __syncthreads();
+    const double wp = wi - ((s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane]));
     if (wv == 0) {
-        wbuf[i] = wi;
-        const double r = wave_sum(wi * wi);
+        wbuf[i] = wp;
+        const double r = wave_sum(wp * wp);
         if (lane == 0) hpart_out[(long long)NRM_SLOT * pld + blockIdx.x] = r;
     }
-    lz_dots(V, ldv, kk, i, wi, wv, lane, hpart_out, pld, blockIdx.x);
+    if (blockIdx.x == 0 && threadIdx.x == 0) hsum_out[k] = ck;
+    // ---- measured pass: V_k' w'
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        double t[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) t[c] = (wv + 4 * (16 * ch + c) <= k) ? vr[16 * ch + c] * wp : 0.0;
+        const double hs = fold16_all(t, lane);
+        const int jc = wv + 4 * (16 * ch + lane);
+        if (lane < 16 && jc <= k) hpart_out[(long long)jc * pld + blockIdx.x] = hs;
+    }
 }
 
 // second pass applied and the step closed:
@@ -468,16 +591,16 @@ k_lz_finish(const double* __restrict__ wbuf, int n, double* __restrict__ V, int 
 // The step-closing work of step k and the mat-vec of step k+1 in ONE launch.
 // v_{k+1} = (w' - V h2)/beta is only known after the closing reductions, but
 //     A (w'/beta) = A v_{k+1} + [ V (T h2) + beta v_{k+1} h2[k] ] / beta
-// and the bracket lies in span(V, v_{k+1}), which the Gram-Schmidt passes of step k+1
-// remove anyway; so the mat-vec runs on w' (ready before the closing work), the 1/beta
-// is applied by k_lz_dots1, and alpha_{k+1} gets the exact correction -h2[k] (`carry`).
+// and the bracket lies in span(V, v_{k+1}) and is known: k_lz_orth subtracts it with the
+// recurrence terms; so the mat-vec runs on w' (ready before the closing work), the 1/beta
+// is applied by k_lz_orth, and alpha_{k+1} gets the exact correction -h2[k] (`carry`).
 // Workgroups [0, nt) close step k, workgroups [nt, nt + ntile) are mat-vec tiles.
 __global__ void __launch_bounds__(TPB)
 k_symv_finish(const double* __restrict__ xp, int n, int nt, int npad, double* __restrict__ Ppart,
               const double* __restrict__ wbuf, double* __restrict__ V, int ldv, int k,
               const double* __restrict__ hpart_in, int pld, const double* __restrict__ h1,
               double* __restrict__ alphas, double* __restrict__ betas, LanczosCtl* __restrict__ ctl, double tol,
-              int use_carry) {
+              int use_carry, double* __restrict__ Apart) {
     if (ctl->stop) return;
     __shared__ double s_a[2 * NWAVE * TILE];                            // s_h   | s_row (double-buffered)
     __shared__ double s_b[NWAVE * LZ_ROWS];                             // s_d   | s_col (double-buffered)
@@ -486,7 +609,7 @@ k_symv_finish(const double* __restrict__ xp, int n, int nt, int npad, double* __
         lz_finish_body(wbuf, V, ldv, k, hpart_in, pld, h1, alphas, betas, ctl, tol, use_carry, blockIdx.x,
                        s_a, s_b, &s_beta);
     else
-        symv_tiles(xp, n, npad, nt * (nt + 1) / 2, wbuf, Ppart, (int)blockIdx.x - nt, (int)gridDim.x - nt, s_a, s_b);
+        symv_tiles(xp, n, npad, nt * (nt + 1) / 2, wbuf, Ppart, (int)blockIdx.x - nt, (int)gridDim.x - nt, s_a, s_b, Apart);
 }
 
 // out[:, c] = sum_j V[:, j] U[j, c]  (basis rotation at a thick restart and the final Ritz

@@ -118,7 +118,9 @@ struct EigWork {
     int n = 0, nt = 0, npad = 0, nwg = 0, cap = 0, pld = 0;   // cap = columns of V (krylovdim_max + 1)
     int64_t N = 0;
     DevBuf<double> V, Z;            // npad x cap each (V: Krylov basis, Z: rotation target / Ritz vectors)
-    DevBuf<double> w, Ppart, hpart1, hpart2, hsum1, U, lam, resid;
+    DevBuf<double> w, Ppart, hpart1, hpart2, hsum1, U, lam, resid, Apart, arrow;
+    int napart = 0;
+    PinnedBuf arrow_host;
     // alphas[MAXK] | betas[MAXK] | LanczosCtl in ONE device record, read back with one copy
     DevBuf<double> rec;
     double* alphas_p = nullptr; double* betas_p = nullptr; dev::LanczosCtl* ctl_p = nullptr;
@@ -288,6 +290,10 @@ inline void Solver::alloc_eigwork(EigWork& W, int n, int max_nev) {
     W.hpart2.alloc((size_t)W.pld * dev::MAXK);
     W.hpart1.zero(stream); W.hpart2.zero(stream);
     W.hsum1.alloc(dev::MAXK);
+    W.napart = 8 * ceil_div(W.nt * (W.nt + 1) / 2, 8);
+    W.Apart.alloc(W.napart); W.Apart.zero(stream);      // padding tiles never write: stay zero
+    W.arrow.alloc(2 * dev::MAXK); W.arrow.zero(stream);   // arrow: f | D (see k_lz_orth)
+    W.arrow_host.alloc(2 * dev::MAXK);
     W.rec.alloc(EigWork::REC_DOUBLES);
     W.alphas_p = W.rec.p; W.betas_p = W.rec.p + dev::MAXK;
     W.ctl_p = reinterpret_cast<dev::LanczosCtl*>(W.rec.p + 2 * dev::MAXK);
@@ -360,10 +366,15 @@ inline void Solver::launch_symv(EigWork& W, const double* xp, const double* v, b
         PX_HIP(hipEventRecord(ev.e0[slot], stream));
     }
     hipLaunchKernelGGL(dev::k_symv_packed, dim3(ntile), dim3(dev::TPB), 0, stream,
-                       xp, W.n, W.nt, W.npad, v, W.Ppart.p, use_ctl ? W.ctl_p : nullptr);
+                       xp, W.n, W.nt, W.npad, v, W.Ppart.p, use_ctl ? W.ctl_p : nullptr, W.Apart.p);
     if (prof) PX_HIP(hipEventRecord(ev.e1[slot], stream));
     st.symv_launches++;
     st.symv_bytes += 8.0 * (double)W.N + 16.0 * (double)W.n;
+}
+
+// partial-dot buffer written by the orthogonalisation of step k
+inline double* lz_hpart(EigWork& W, int k) {
+    return (k & 1) ? W.hpart2.p : W.hpart1.p;
 }
 
 // k_symv_finish: closes Lanczos step `kclose` and runs the mat-vec of step kclose+1 on w'
@@ -381,8 +392,8 @@ inline void Solver::launch_symv_finish(EigWork& W, const double* xp, int kclose,
         PX_HIP(hipEventRecord(ev.e0[slot], stream));
     }
     hipLaunchKernelGGL(dev::k_symv_finish, dim3(W.nt + ntile), dim3(dev::TPB), 0, stream,
-                       xp, W.n, W.nt, W.npad, W.Ppart.p, W.w.p, W.V.p, W.npad, kclose, W.hpart2.p, W.pld,
-                       W.hsum1.p, W.alphas_p, W.betas_p, W.ctl_p, tol, use_carry ? 1 : 0);
+                       xp, W.n, W.nt, W.npad, W.Ppart.p, W.w.p, W.V.p, W.npad, kclose, lz_hpart(W, kclose), W.pld,
+                       W.hsum1.p, W.alphas_p, W.betas_p, W.ctl_p, tol, use_carry ? 1 : 0, W.Apart.p);
     if (prof) PX_HIP(hipEventRecord(ev.e1[slot], stream));
     st.symv_launches++;
     st.symv_bytes += 8.0 * (double)W.N + 16.0 * (double)W.n;
@@ -464,14 +475,17 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev) {
                 // close step k-1 and run the mat-vec of step k in one launch
                 launch_symv_finish(W, xp, k - 1, step_tol, k - 1 > kfirst);
             }
-            hipLaunchKernelGGL(dev::k_lz_dots1, dim3(W.nt), dim3(dev::TPB), 0, stream,
-                               W.Ppart.p, W.nt, W.n, W.npad, W.V.p, W.npad, k, W.w.p, W.hpart1.p, W.pld, W.ctl_p,
-                               W.betas_p, k == kfirst ? -1 : k - 1);
-            hipLaunchKernelGGL(dev::k_lz_apply, dim3(W.nt), dim3(dev::TPB), 0, stream,
-                               W.w.p, W.n, W.V.p, W.npad, k, W.hpart1.p, W.pld, W.hsum1.p, W.hpart2.p, W.ctl_p);
+            // recurrence, predicted correction and the measured full pass in one launch;
+            // the partial-dot buffers alternate by step parity (read k-1, write k)
+            double* hp[2] = {W.hpart1.p, W.hpart2.p};
+            auto orth = (k + 1 <= 64) ? dev::k_lz_orth<1> : (k + 1 <= 128) ? dev::k_lz_orth<2> : dev::k_lz_orth<3>;
+            hipLaunchKernelGGL(orth, dim3(W.nt), dim3(dev::TPB), 0, stream,
+                               W.Ppart.p, W.nt, W.npad, W.V.p, W.npad, k, W.w.p, hp[(k + 1) & 1], hp[k & 1], W.pld,
+                               W.hsum1.p, W.ctl_p, W.alphas_p, W.betas_p, W.Apart.p, W.napart,
+                               k == kfirst ? 1 : 0, W.arrow.p, kfirst);
         }
         hipLaunchKernelGGL(dev::k_lz_finish, dim3(W.nt), dim3(dev::TPB), 0, stream,
-                           W.w.p, W.n, W.V.p, W.npad, krylovdim - 1, W.hpart2.p, W.pld, W.hsum1.p,
+                           W.w.p, W.n, W.V.p, W.npad, krylovdim - 1, lz_hpart(W, krylovdim - 1), W.pld, W.hsum1.p,
                            W.alphas_p, W.betas_p, W.ctl_p, step_tol, (krylovdim - 1 > kfirst) ? 1 : 0);
         // the first mat-vec of a possible next cycle only needs v_K = V[:,krylovdim], which is
         // final now: enqueue it before the host round trip so the GPU works during the K x K
@@ -546,6 +560,10 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev) {
         if (numiter == maxiter) break;
         const int keep = arpack ? std::min(krylovdim - 1, nev + std::max(1, (krylovdim - nev) / 2))
                                 : (3 * krylovdim + 2 * converged) / 5;
+        // arrow part of the restarted T for k_lz_orth: f (couplings of v_K with the kept Ritz
+        // vectors) and D (their Ritz values)
+        for (int j = 0; j < keep; ++j) { W.arrow_host.p[j] = f[j]; W.arrow_host.p[dev::MAXK + j] = D[j]; }
+        PX_HIP(hipMemcpyAsync(W.arrow.p, W.arrow_host.p, 2 * dev::MAXK * sizeof(double), hipMemcpyHostToDevice, stream));
         rotate(W, K, U, K, keep, W.Z.p, K, keep);        // Z[:, :keep] = V U[:, :keep]; Z[:, keep] = V[:, K]
         std::swap(W.V.p, W.Z.p);
         std::fill(T.begin(), T.end(), 0.0);
