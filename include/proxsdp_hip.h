@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PROXSDP_HIP_ABI_VERSION 1
+#define PROXSDP_HIP_ABI_VERSION 2
 
 /* error codes (negative return values) */
 #define PROXSDP_E_INVALID  (-1)   /* invalid argument / inconsistent problem data */
@@ -97,6 +97,20 @@ typedef struct proxsdp_problem {
      * blocks (prox_operators.jl:40) becomes one block set per GPU. */
     void* reduce_ctx;
     int (*reduce_fn)(void* ctx, double* sums, int32_t nsum, double* maxs, int32_t nmax);
+    /* optional dense equality block, for models whose A_k are all dense (test/base_randsdp.jl:
+     * 4-23: n = 2000, m = 4000 gives 8.0e9 entries = 64 GB, beyond a sparse index type and
+     * pointless to index).  When M_dense != NULL it is A as a ROW-MAJOR p x n array of doubles,
+     * columns in the caller's variable order; the CSC `A` is then ignored (its pointers may be
+     * NULL) while G stays sparse (e.g. the variable bounds of test/moi_randsdp.jl:33-45).
+     * M_dense_on_device = 1: a device pointer on options.device_id (e.g. generated there);
+     * 0: host memory, uploaded once.  Borrowed and never modified either way (the reference
+     * scales aff.A in place, scaling.jl:24; here the column scaling is applied to the
+     * vectors).  Restrictions: the variables must already be in solver order (cone variables
+     * first, in cone order: psd_idx/soc_idx concatenated = 0,1,2,...), and reduce_fn must be
+     * NULL. */
+    const double* M_dense;
+    int32_t M_dense_on_device;
+    int32_t reserved1;
 } proxsdp_problem;
 
 /* Options (options.jl:1-132): same names, same defaults (proxsdp_hip_default_options).
@@ -176,6 +190,7 @@ typedef struct proxsdp_stats {
     double  loop_time;           /* s: the PDHG loop ("CP loop")                     */
     double  exit_time;           /* s: cache_solution                                */
     double  t_primal, t_psd, t_linesearch, t_residual;   /* s, host wall incl. syncs */
+    int64_t dense_passes;        /* passes over a dense A (A x or batched A' y), 8*p*n bytes each */
 } proxsdp_stats;
 
 /* Result (structs.jl:60-81).  Arrays are caller-allocated with the stated

@@ -52,7 +52,8 @@ class Problem(C.Structure):
                 ("n_psd", i64), ("psd_ptr", pi64), ("psd_idx", pi64),
                 ("n_soc", i64), ("soc_ptr", pi64), ("soc_idx", pi64),
                 ("index_base", i32), ("reserved0", i32), ("eig_resid", pf64),
-                ("reduce_ctx", C.c_void_p), ("reduce_fn", C.c_void_p)]
+                ("reduce_ctx", C.c_void_p), ("reduce_fn", C.c_void_p),
+                ("M_dense", C.c_void_p), ("M_dense_on_device", i32), ("reserved1", i32)]
 
 
 REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, pf64, i32, pf64, i32)
@@ -112,7 +113,7 @@ class Stats(C.Structure):
                 ("symv_launches", i64), ("symv_profiled", i64), ("symv_profiled_ms", f64),
                 ("symv_bytes", f64), ("algorithmic_bytes", f64), ("init_time", f64),
                 ("loop_time", f64), ("exit_time", f64), ("t_primal", f64), ("t_psd", f64),
-                ("t_linesearch", f64), ("t_residual", f64)]
+                ("t_linesearch", f64), ("t_residual", f64), ("dense_passes", i64)]
 
 
 class Result(C.Structure):
@@ -145,6 +146,18 @@ def lib():
         raise LibraryNotBuilt(
             f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C proxsdp.jl_amd/csrc`).  There is no CPU fallback.")
+    # PyTorch-ROCm wheels bundle their own HIP/HSA runtime.  Measured on the MI355X box: if the
+    # system runtime behind this library initialises first, torch can no longer see the GPU
+    # ("No HIP GPUs are available"); the other order works, including torch device pointers
+    # handed to the library (M_dense).  So when torch is already imported, let it go first.
+    import sys
+    if "torch" in sys.modules:
+        try:
+            tc = sys.modules["torch"].cuda
+            if tc.is_available():
+                tc.init()
+        except Exception:
+            pass
     L = C.CDLL(str(LIB_PATH))
     L.proxsdp_hip_abi_version.restype = C.c_int
     L.proxsdp_hip_last_error.restype = C.c_char_p
@@ -163,7 +176,7 @@ def lib():
     L.proxsdp_host_symeig.argtypes = [i32, pf64, pf64]
     L.proxsdp_host_start_vector.argtypes = [i64, i64, i32, pf64]
     L.proxsdp_host_preprocess.argtypes = [C.POINTER(Problem), pi64, pi64, pf64, pf64]
-    if L.proxsdp_hip_abi_version() != 1:
+    if L.proxsdp_hip_abi_version() != 2:
         raise ProxSDPHipError(-1, "ABI version mismatch")
     _lib = L
     return L
@@ -246,6 +259,22 @@ class _Marshalled:
             r = _f(np.concatenate([np.asarray(v, float).ravel() for v in eig_resid]))
             keep.append(r)
             P.eig_resid = _p(r)
+        Md = getattr(prob, "M_dense", None)
+        if Md is not None:
+            if prob.A.nnz:
+                raise ValueError("M_dense given: the sparse A must have no stored entries")
+            if hasattr(Md, "data_ptr"):                      # torch tensor on the GPU
+                if not (Md.is_cuda and Md.is_contiguous() and Md.dtype.is_floating_point and Md.element_size() == 8):
+                    raise ValueError("M_dense tensor must be a contiguous float64 CUDA tensor")
+                if tuple(Md.shape) != (P.p, P.n):
+                    raise ValueError("M_dense has the wrong shape")
+                P.M_dense, P.M_dense_on_device = Md.data_ptr(), 1
+            else:
+                Md = np.ascontiguousarray(Md, dtype=np.float64)
+                if Md.shape != (P.p, P.n):
+                    raise ValueError("M_dense has the wrong shape")
+                P.M_dense, P.M_dense_on_device = Md.ctypes.data, 0
+            keep.append(Md)
         self.P, self.keep = P, keep
 
 

@@ -1105,6 +1105,165 @@ k_combine(const double* __restrict__ part, int stride, int cnt, int nq, unsigned
     }
 }
 
+// ---------------------------------------------------------------------------
+// Dense constraint matrix (randSDP-scale models: every A_k dense, M = 64 GB at
+// n = 2000, m = 4000).  M is the caller's ROW-MAJOR Q x n array, used in place:
+// the sqrt(2)/2 column scaling of norm_scaling (scaling.jl:28-58) is applied to
+// the vector on the way in (M x) or to the result on the way out (M' y), so the
+// borrowed matrix is never modified or copied.  Both products stream M once:
+// 8*Q*n bytes, HBM-bound.
+// ---------------------------------------------------------------------------
+constexpr int DMV_ROWS = 4;          // rows per workgroup in M x (x is re-used from registers)
+constexpr int DMV_UNR = 4;           // column strips in flight per thread
+
+// part[cs][r] = sum over the column slice cs of M[r, j] * s_j * x_j   (grid: row groups x slices)
+__global__ void __launch_bounds__(TPB)
+k_dense_mv(const double* __restrict__ M, long long ld, int Q, long long n, const double* __restrict__ x,
+           const unsigned char* __restrict__ offdiag, double scale, double* __restrict__ part, int qpad) {
+    __shared__ double sm[DMV_ROWS][NWAVE];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * DMV_ROWS;
+    // column slice of this workgroup, in units of TPB * DMV_UNR columns
+    const long long chunk = (long long)TPB * DMV_UNR;
+    const long long nchunks = (n + chunk - 1) / chunk;
+    const long long per = (nchunks + gridDim.y - 1) / gridDim.y;
+    const long long c0 = (long long)blockIdx.y * per * chunk;
+    const long long c1 = (c0 + per * chunk < n) ? c0 + per * chunk : n;
+    const double* rowp[DMV_ROWS];
+#pragma unroll
+    for (int r = 0; r < DMV_ROWS; ++r) rowp[r] = M + (long long)min(r0 + r, Q - 1) * ld;
+    double acc[DMV_ROWS];
+#pragma unroll
+    for (int r = 0; r < DMV_ROWS; ++r) acc[r] = 0.0;
+    for (long long jb = c0; jb < c1; jb += chunk) {
+        double xv[DMV_UNR], mv[DMV_ROWS][DMV_UNR];
+#pragma unroll
+        for (int u = 0; u < DMV_UNR; ++u) {
+            const long long j = jb + (long long)u * TPB + threadIdx.x;
+            const long long jc = (j < c1) ? j : c1 - 1;
+            const double sc = (offdiag != nullptr && offdiag[jc]) ? scale : 1.0;
+            xv[u] = (j < c1) ? x[jc] * sc : 0.0;
+#pragma unroll
+            for (int r = 0; r < DMV_ROWS; ++r) mv[r][u] = rowp[r][jc];
+        }
+#pragma unroll
+        for (int r = 0; r < DMV_ROWS; ++r)
+#pragma unroll
+            for (int u = 0; u < DMV_UNR; ++u) acc[r] += mv[r][u] * xv[u];
+    }
+#pragma unroll
+    for (int r = 0; r < DMV_ROWS; ++r) {
+        const double w = wave_sum(acc[r]);
+        if (lane == 0) sm[r][wv] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < DMV_ROWS && r0 + (int)threadIdx.x < Q) {
+        const int r = threadIdx.x;
+        part[(long long)blockIdx.y * qpad + r0 + r] = (sm[r][0] + sm[r][1]) + (sm[r][2] + sm[r][3]);
+    }
+}
+// y[r] = sum of the slices (fixed order)
+__global__ void __launch_bounds__(TPB)
+k_dense_mv_fin(const double* __restrict__ part, int qpad, int nslice, int Q, double* __restrict__ y) {
+    const int r = blockIdx.x * TPB + threadIdx.x;
+    if (r >= Q) return;
+    double a = 0.0;
+    for (int sidx = 0; sidx < nslice; ++sidx) a += part[(long long)sidx * qpad + r];
+    y[r] = a;
+}
+
+// OUT_c[j] = s_j * sum_k M[k, j] * Y_c[k] (+ the sparse rows of [A;G]) for NC candidate vectors in ONE pass over M
+// (the linesearch candidates tau, 3/4 tau, (3/4)^2 tau share the 8*Q*n bytes), plus the
+// partials of |OUT_c - old|^2 (pdhg.jl:556-563) when `old` != NULL, plus `addc` (c_orig for
+// the exit path's dual cone).  Thread = column; the loop over rows keeps DMT_UNR loads in flight.
+constexpr int DMT_UNR = 8;
+template <int NC>
+__global__ void __launch_bounds__(TPB)
+k_dense_mtv(const double* __restrict__ M, long long ld, int Q, long long n, const double* __restrict__ Y,
+            long long ystride, const unsigned char* __restrict__ offdiag, double scale,
+            double* __restrict__ OUT, long long ostride, const double* __restrict__ old,
+            const double* __restrict__ addc, double* __restrict__ part, long long cstride,
+            const int* __restrict__ sp_colptr, const int* __restrict__ sp_row, const double* __restrict__ sp_val) {
+    __shared__ double sm[NWAVE];
+    double ss[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) ss[c] = 0.0;
+    const long long nchunk = (n + TPB - 1) / TPB;
+    for (long long b = blockIdx.x; b < nchunk; b += gridDim.x) {
+        const long long j = b * TPB + threadIdx.x;
+        const long long jc = (j < n) ? j : n - 1;
+        const double* col = M + jc;
+        double acc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+        int k = 0;
+        for (; k + DMT_UNR <= Q; k += DMT_UNR) {
+            double mv[DMT_UNR];
+#pragma unroll
+            for (int u = 0; u < DMT_UNR; ++u) mv[u] = col[(long long)(k + u) * ld];
+#pragma unroll
+            for (int u = 0; u < DMT_UNR; ++u)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[c] += mv[u] * Y[c * ystride + k + u];
+        }
+        for (; k < Q; ++k) {
+            const double mvk = col[(long long)k * ld];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[c] += mvk * Y[c * ystride + k];
+        }
+        if (j < n) {
+            const double sc = (offdiag != nullptr && offdiag[j]) ? scale : 1.0;
+            const double o = (old != nullptr) ? old[j] : 0.0;
+            const double ad = (addc != nullptr) ? addc[j] : 0.0;
+            double spv[NC];                               // sparse rows of M (G), already scaled
+#pragma unroll
+            for (int c = 0; c < NC; ++c) spv[c] = 0.0;
+            if (sp_colptr != nullptr)
+                for (int q = sp_colptr[j]; q < sp_colptr[j + 1]; ++q)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) spv[c] += sp_val[q] * Y[c * ystride + sp_row[q]];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const double v = acc[c] * sc + spv[c] + ad;
+                OUT[c * ostride + j] = v;
+                const double d = v - o;
+                ss[c] += d * d;
+            }
+        }
+    }
+    if (part != nullptr) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const double tot = block_sum(ss[c], sm);
+            if (threadIdx.x == 0) part[c * cstride + blockIdx.x] = tot;
+        }
+    }
+}
+
+// sum_kj (M[k,j] s_j)^2 partials: ||M||_F of the scaled matrix (pdhg.jl:121)
+__global__ void __launch_bounds__(TPB)
+k_dense_frob(const double* __restrict__ M, long long ld, int Q, long long n,
+             const unsigned char* __restrict__ offdiag, double scale, double* __restrict__ part) {
+    __shared__ double sm[NWAVE];
+    double ss = 0.0;
+    const long long nchunk = (n + TPB - 1) / TPB;
+    for (long long b = blockIdx.x; b < nchunk; b += gridDim.x) {
+        const long long j = b * TPB + threadIdx.x;
+        if (j >= n) continue;
+        const double sc = (offdiag != nullptr && offdiag[j]) ? scale : 1.0;
+        double a0 = 0.0, a1 = 0.0;
+        int k = 0;
+        for (; k + 1 < Q; k += 2) {
+            const double v0 = M[(long long)k * ld + j], v1 = M[(long long)(k + 1) * ld + j];
+            a0 += v0 * v0; a1 += v1 * v1;
+        }
+        if (k < Q) { const double v0 = M[(long long)k * ld + j]; a0 += v0 * v0; }
+        ss += (a0 + a1) * sc * sc;
+    }
+    const double tot = block_sum(ss, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
 // one workgroup per quantity: out[q] = sum or max of part[q*stride .. +cnt)
 __global__ void __launch_bounds__(TPB)
 k_combine_multi(const double* __restrict__ part, int stride, int cnt, unsigned long long ismax,

@@ -11,6 +11,10 @@ constexpr int NQ = 16;
 
 // pdhg.jl:634 (Mx = M x)
 inline void Solver::spmv(const double* x, double* y) {
+    spmv_sparse(x, y);                                   // all Q rows (zeros for the rows of a dense A)
+    if (P.dense()) dense_mv(x, y, true);                 // rows [0, p)
+}
+inline void Solver::spmv_sparse(const double* x, double* y) {
     if (P.Q == 0) return;
     if (csr_wave)
         hipLaunchKernelGGL(dev::k_spmv_csr_wave, dim3(ceil_div(P.Q, dev::NWAVE)), dim3(dev::TPB), 0, stream,
@@ -141,6 +145,9 @@ inline void Solver::dual_step_plain() {
     hipLaunchKernelGGL(dev::k_dual_trial, dim3(gq), dim3(dev::TPB), 0, stream,
                        ybuf[yc].p, Mxbuf[1 - mxc].p, Mxbuf[mxc].p, bh_d.p, (int)P.p, (int)P.Q, dual_step, 1.0,
                        ybuf[1 - yc].p, part.p);
+    if (P.dense())
+        dense_mtv(1, ybuf[1 - yc].p, 0, true, Mtybuf[1 - mtyc].p, 0, Mtybuf[mtyc].p, nullptr, part.p + PSTRIDE, 0);
+    else
     hipLaunchKernelGGL(dev::k_spmv_csc_norm, dim3(gx), dim3(dev::TPB), 0, stream,
                        csc_ptr.p, csc_row.p, csc_val.p, ybuf[1 - yc].p, Mtybuf[1 - mtyc].p, Mtybuf[mtyc].p,
                        (long long)P.n, part.p + PSTRIDE);
@@ -240,6 +247,13 @@ inline double Solver::dual_feas_host(const std::vector<double>& y, const std::ve
                                      std::vector<double>* dual_eq, std::vector<double>* dual_in,
                                      std::vector<double>* dual_cone_out) {
     std::vector<double> dc(cvec);
+    if (P.dense()) {                                          // c + M'y with the caller's (unscaled) M
+        DevBuf<double> yd(std::max<int64_t>(P.Q, 1)), cd(P.n), od(P.n);
+        yd.upload(y.data(), P.Q, stream); cd.upload(cvec.data(), P.n, stream);
+        dense_mtv(1, yd.p, 0, false, od.p, 0, nullptr, cd.p, nullptr, 0);
+        od.download(dc.data(), P.n, stream);
+        PX_HIP(hipStreamSynchronize(stream));
+    }
     for (int64_t k = 0; k < P.n; ++k) {
         double acc = 0.0;
         for (int64_t q = P.colptr[k]; q < P.colptr[k + 1]; ++q) acc += P.val_orig[q] * y[P.rowidx[q]];
@@ -300,6 +314,12 @@ inline void Solver::cache_solution(const std::vector<double>& cvec) {
     ybuf[yc].download(y.data(), P.Q, stream);
     PX_HIP(hipStreamSynchronize(stream));
     std::vector<double> slack(P.Q, 0.0);
+    if (P.dense() && P.p > 0) {                              // A x with the caller's (unscaled) dense A
+        DevBuf<double> sd(P.p);
+        dense_mv(xbuf[xc].p, sd.p, false);
+        sd.download(slack.data(), P.p, stream);
+        PX_HIP(hipStreamSynchronize(stream));
+    }
     for (int64_t k = 0; k < P.n; ++k) {
         const double xk = x[k];
         for (int64_t q = P.colptr[k]; q < P.colptr[k + 1]; ++q) slack[P.rowidx[q]] += P.val_orig[q] * xk;
@@ -337,6 +357,131 @@ inline void Solver::cache_solution(const std::vector<double>& cvec) {
     res.time = now_s() - time0;
     have_snapshot = true;
     st.exit_time += now_s() - t0;
+}
+
+// ---- dense constraint matrix (proxsdp_problem.M_dense; kernels.hip.hpp "Dense constraint matrix")
+inline void Solver::setup_dense() {
+    if (!P.dense()) return;
+    const size_t cnt = (size_t)P.p * (size_t)P.n;
+    if (P.Mdense_on_device) {
+        Md = P.Mdense;                                   // borrowed, read-only
+    } else {
+        Md_own.alloc(std::max<size_t>(cnt, 1));
+        const size_t chunk = (size_t)1 << 27;            // 1 GiB of doubles per copy
+        for (size_t o = 0; o < cnt; o += chunk)
+            PX_HIP(hipMemcpy(Md_own.p + o, P.Mdense + o, std::min(chunk, cnt - o) * sizeof(double), hipMemcpyHostToDevice));
+        Md = Md_own.p;
+    }
+    offdiag_d.alloc(P.n);
+    offdiag_d.upload(P.offdiag.data(), P.n, stream);
+    // M x: row groups x column slices; enough workgroups to fill 256 CUs several times over
+    const int rg = ceil_div((int)std::max<int64_t>(P.p, 1), dev::DMV_ROWS);
+    dmv_slices = std::max(1, std::min(64, ceil_div(2048, rg)));
+    const long long chunks = ((long long)P.n + dev::TPB * dev::DMV_UNR - 1) / (dev::TPB * dev::DMV_UNR);
+    dmv_slices = (int)std::min<long long>(dmv_slices, std::max<long long>(chunks, 1));
+    dmv_qpad = (int)std::max<int64_t>(P.p, 1);
+    dmv_part.alloc((size_t)dmv_slices * dmv_qpad);
+    Mtycand_d.alloc((size_t)3 * P.n);
+    ycand_d.alloc((size_t)4 * std::max<int64_t>(P.Q, 1));
+    bpart.alloc((size_t)4 * 2 * PSTRIDE); bpart.zero(stream);
+    bscal.alloc(64); bscal.zero(stream);
+    hbscal.assign(64, 0.0);
+    // ||M||_F of the column-scaled matrix (pdhg.jl:121 after norm_scaling)
+    const int gx = std::min(PSTRIDE, grid_for(P.n));
+    hipLaunchKernelGGL(dev::k_dense_frob, dim3(gx), dim3(dev::TPB), 0, stream,
+                       Md, (long long)P.n, (int)P.p, (long long)P.n, offdiag_d.p, std::sqrt(2.0) / 2.0, part.p);
+    hipLaunchKernelGGL(dev::k_combine, dim3(1), dim3(dev::TPB), 0, stream, part.p, PSTRIDE, gx, 1, 0u, scal.p);
+    double ss = 0.0;
+    PX_HIP(hipMemcpyAsync(&ss, scal.p, sizeof(double), hipMemcpyDeviceToHost, stream));
+    PX_HIP(hipStreamSynchronize(stream));
+    g_frob = std::sqrt(ss + P.frob * P.frob);            // + the sparse rows (G)
+}
+
+// y = M (s o x)  (scaled = the solver's M) or M x (the caller's M, exit path)
+inline void Solver::dense_mv(const double* x, double* y, bool scaled) {
+    if (P.p == 0) return;
+    const int rg = ceil_div((int)P.p, dev::DMV_ROWS);
+    hipLaunchKernelGGL(dev::k_dense_mv, dim3(rg, dmv_slices), dim3(dev::TPB), 0, stream,
+                       Md, (long long)P.n, (int)P.p, (long long)P.n, x, scaled ? offdiag_d.p : nullptr,
+                       std::sqrt(2.0) / 2.0, dmv_part.p, dmv_qpad);
+    hipLaunchKernelGGL(dev::k_dense_mv_fin, dim3(ceil_div((int)P.p, dev::TPB)), dim3(dev::TPB), 0, stream,
+                       dmv_part.p, dmv_qpad, dmv_slices, (int)P.p, y);
+    st.dense_passes += 1;
+}
+
+// OUT_c = s o (M' Y_c) [+ addc], c < nc <= 3, one pass over M
+inline void Solver::dense_mtv(int nc, const double* Y, long long ystride, bool scaled, double* OUT, long long ostride,
+                              const double* old, const double* addc, double* normpart, long long cstride) {
+    const int gx = std::min(PSTRIDE, grid_for(P.n));
+    const unsigned char* od = scaled ? offdiag_d.p : nullptr;
+    const double sc = std::sqrt(2.0) / 2.0;
+    auto launch = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(gx), dim3(dev::TPB), 0, stream, Md, (long long)P.n, (int)P.p, (long long)P.n,
+                           Y, ystride, od, sc, OUT, ostride, old, addc, normpart, cstride,
+                           scaled && P.nnz > 0 ? csc_ptr.p : nullptr, csc_row.p, csc_val.p);
+    };
+    if (nc == 1) launch(dev::k_dense_mtv<1>);
+    else if (nc == 2) launch(dev::k_dense_mtv<2>);
+    else launch(dev::k_dense_mtv<3>);
+    st.dense_passes += 1;
+}
+
+// linesearch! (pdhg.jl:532-582) with a dense M: the candidates tau, 3/4 tau, (3/4)^2 tau are
+// evaluated by ONE pass over M (8 Q n bytes) and one synchronisation; the host takes the first
+// candidate the reference's loop would have accepted.
+inline int Solver::linesearch_dense() {
+    constexpr int NC = 3;
+    const int gq = std::min(PSTRIDE, grid_for(std::max<int64_t>(P.Q, 1)));
+    const int gx = std::min(PSTRIDE, grid_for(P.n));
+    const long long cstride = 2LL * PSTRIDE;
+    const long long ystride = std::max<int64_t>(P.Q, 1);
+    primal_step = primal_step * std::sqrt(1.0 + theta);
+    int trials = 0;
+    bool accepted = false;
+    while (!accepted && trials < opt.max_linsearch_steps) {
+        dev::TrialBatch tb{};
+        double tau_c = primal_step;
+        int nc = 0;
+        for (; nc < NC && trials + nc < opt.max_linsearch_steps; ++nc) {
+            tb.tau[nc] = tau_c;
+            tb.theta[nc] = tau_c / primal_step_old;
+            tb.bt[nc] = beta * tau_c;
+            tb.sigma[nc] = beta * tau_c;
+            tau_c *= opt.linsearch_decay;
+        }
+        tb.nc = nc;
+        hipLaunchKernelGGL(dev::k_dual_trial_batch, dim3(gq, nc), dim3(dev::TPB), 0, stream,
+                           ybuf[yc].p, Mxbuf[1 - mxc].p, Mxbuf[mxc].p, bh_d.p, (int)P.p, (int)P.Q, tb,
+                           ycand_d.p, ystride, bpart.p, cstride);
+        dense_mtv(nc, ycand_d.p, ystride, true, Mtycand_d.p, (long long)P.n, Mtybuf[mtyc].p, nullptr,
+                  bpart.p + PSTRIDE, cstride);
+        hipLaunchKernelGGL(dev::k_combine_multi, dim3(nc * 2), dim3(dev::TPB), 0, stream,
+                           bpart.p, PSTRIDE, std::max(gq, gx), 0ull, bscal.p);
+        PX_HIP(hipMemcpyAsync(hbscal.data(), bscal.p, NC * 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
+        PX_HIP(hipStreamSynchronize(stream));
+        for (int c = 0; c < nc; ++c) {
+            ++trials;
+            primal_step = tb.tau[c];
+            theta = tb.theta[c];
+            const double y_norm = std::sqrt(hbscal[2 * c]), Mty_norm = std::sqrt(hbscal[2 * c + 1]);
+            const bool ok = std::sqrt(beta) * primal_step * Mty_norm <= opt.delta * y_norm;
+            const bool last = trials >= opt.max_linsearch_steps;
+            if (ok || last) {
+                if (!ok) primal_step *= opt.linsearch_decay;     // reference quirk: decayed once more, trial kept
+                accepted = true;
+                PX_HIP(hipMemcpyAsync(ybuf[1 - yc].p, ycand_d.p + (size_t)c * ystride, (size_t)P.Q * 8,
+                                      hipMemcpyDeviceToDevice, stream));
+                PX_HIP(hipMemcpyAsync(Mtybuf[1 - mtyc].p, Mtycand_d.p + (size_t)c * P.n, (size_t)P.n * 8,
+                                      hipMemcpyDeviceToDevice, stream));
+                break;
+            }
+            primal_step = tb.tau[c] * opt.linsearch_decay;
+        }
+    }
+    primal_step_old = primal_step;
+    dual_step = beta * primal_step;
+    st.linesearch_trials += trials;
+    return trials;
 }
 
 // ---- support-aware path: setup and the batched linesearch + residual
@@ -635,7 +780,9 @@ inline void Solver::run() {
         PX_HIP(hipStreamSynchronize(stream));
     }
     if (sharded()) opt.support_path = 1;                 // the sharded loop is built on the batched path
+    if (P.dense()) opt.support_path = 0;                 // every column of a dense M is in the support
     setup_support();
+    setup_dense();
     if (sharded() && !use_support)
         throw std::domain_error("block-sharded solve needs the support-aware path (no SOC / 1x1 cones)");
     double spectral_norm = g_frob;                       // LinearAlgebra.norm(M), pdhg.jl:121
@@ -679,7 +826,7 @@ inline void Solver::run() {
             last_trials = linesearch_residual_support();
             st.t_linesearch += now_s() - tl0;
         } else {
-            if (opt.line_search_flag) last_trials = linesearch();
+            if (opt.line_search_flag) last_trials = P.dense() ? linesearch_dense() : linesearch();
             else { dual_step_plain(); last_trials = 1; }
             const double tl1 = now_s();
             residual_and_gap();
@@ -690,6 +837,10 @@ inline void Solver::run() {
             const double t = (double)last_trials;
             double bb = 8.0 * (double)P.n * (11.0 + 3.0 * t) + 12.0 * (double)P.nnz * (1.0 + t) +
                         8.0 * (double)P.Q * (8.0 + 6.0 * t);
+            if (P.dense()) {                             // M x + one M'y pass per candidate batch
+                bb += 8.0 * (double)P.p * (double)P.n * (double)(st.dense_passes - dense_passes_seen);
+                dense_passes_seen = st.dense_passes;
+            }
             for (size_t idx = 0; idx < nb; ++idx) {
                 if (P.blocks[idx].n < 2) continue;
                 // per-block L and r are accumulated over blocks in lz_matvec_iter / recon_r_iter;

@@ -35,6 +35,11 @@ struct Prep {
     std::vector<SocInfo> socs;
     int64_t sdplen = 0, conelen = 0;
     double norm_b = 0, norm_h = 0, norm_c = 0, frob = 0;
+    // dense A (borrowed pointer, row-major p x n): the sparse members above then hold G only
+    // and the solver adds the dense part to frob (one device pass)
+    const double* Mdense = nullptr;
+    bool Mdense_on_device = false;
+    bool dense() const { return Mdense != nullptr; }
 };
 
 inline double norm2(const double* v, int64_t n) {
@@ -67,7 +72,10 @@ inline Prep prepare(const proxsdp_problem& P) {
     if (P.n < 0 || P.p < 0 || P.m < 0) throw std::invalid_argument("negative dimension");
     if (P.n >= (int64_t)1 << 31) throw std::invalid_argument("n >= 2^31 not supported");
     R.n = P.n; R.p = P.p; R.m = P.m; R.Q = P.p + P.m;
-    check_csc(P.A, P.p, P.n, base, "A");
+    const bool dense = P.M_dense != nullptr;
+    if (!dense) check_csc(P.A, P.p, P.n, base, "A");
+    else if (P.reduce_fn != nullptr)
+        throw std::invalid_argument("A_dense cannot be combined with a block-sharded solve (reduce_fn)");
     check_csc(P.G, P.m, P.n, base, "G");
     if ((P.p > 0 && !P.b) || (P.m > 0 && !P.h) || (P.n > 0 && !P.c))
         throw std::invalid_argument("b, h or c is NULL");
@@ -132,8 +140,15 @@ inline Prep prepare(const proxsdp_problem& P) {
         R.c[k] = R.offdiag[k] ? v * cte : v;
     }
 
-    // ---- M = vcat(A, G) with reordered columns
-    int64_t nnzA = P.n > 0 ? P.A.colptr[P.n] - base : 0;
+    if (dense) {
+        for (int64_t k = 0; k < P.n; ++k)
+            if (R.ord[k] != k)
+                throw std::invalid_argument("A_dense requires the variables in solver order (cone variables first, in cone order)");
+        R.Mdense = P.M_dense;
+        R.Mdense_on_device = P.M_dense_on_device != 0;
+    }
+    // ---- M = vcat(A, G) with reordered columns (a dense A stays out of the sparse structures)
+    int64_t nnzA = (P.n > 0 && !dense) ? P.A.colptr[P.n] - base : 0;
     int64_t nnzG = P.n > 0 ? P.G.colptr[P.n] - base : 0;
     R.nnz = nnzA + nnzG;
     if (R.nnz >= ((int64_t)1 << 31) - 1) throw std::invalid_argument("nnz(M) >= 2^31 not supported by the sparse path");
@@ -145,7 +160,7 @@ inline Prep prepare(const proxsdp_problem& P) {
         const int64_t j = R.ord[k];
         const double sc = R.offdiag[k] ? cte : 1.0;
         R.colptr[k] = w;
-        for (int64_t q = P.A.colptr[j] - base; q < P.A.colptr[j + 1] - base; ++q, ++w) {
+        for (int64_t q = dense ? 0 : P.A.colptr[j] - base; q < (dense ? 0 : P.A.colptr[j + 1] - base); ++q, ++w) {
             R.rowidx[w] = (int32_t)(P.A.rowval[q] - base);
             R.val_orig[w] = P.A.nzval[q];
             R.val[w] = P.A.nzval[q] * sc;

@@ -245,8 +245,14 @@ private:
     void project_block(int idx, const double* xin, double* xout, bool fuse);
     void setup_support();
     int  linesearch_residual_support();
+    void setup_dense();
+    int  linesearch_dense();
+    void dense_mv(const double* x, double* y, bool scaled);
+    void dense_mtv(int nc, const double* Y, long long ystride, bool scaled, double* OUT, long long ostride,
+                   const double* old, const double* addc, double* normpart, long long cstride);
     void full_eig_project(int idx, const double* xp_in, double* xp_out, bool fuse);
     void spmv(const double* x, double* y);
+    void spmv_sparse(const double* x, double* y);
     int  linesearch();
     void dual_step_plain();
     void residual_and_gap();
@@ -267,6 +273,12 @@ private:
     DevBuf<int> supp_d;
     DevBuf<unsigned> mask_d;
     DevBuf<double> cS_d, xsave_d, MtyS_cur, MtyS_cand, ycand_d, respart_d, bpart, bscal;
+    // dense constraint matrix (proxsdp_problem.M_dense): borrowed device pointer or own upload
+    const double* Md = nullptr;
+    DevBuf<double> Md_own, dmv_part, Mtycand_d;
+    DevBuf<unsigned char> offdiag_d;
+    int dmv_slices = 1, dmv_qpad = 0;
+    long long dense_passes_seen = 0;
     std::vector<double> hbscal;
 };
 

@@ -54,6 +54,10 @@ class Problem:
     max_sense: bool = False
     objective_constant: float = 0.0
     name: str = ""
+    # optional dense A (row-major p x n): a C-contiguous float64 numpy array (host) or a torch
+    # tensor living on the solve's GPU (proxsdp_problem.M_dense); the sparse A then only
+    # carries the shape (no stored entries), G stays sparse
+    M_dense: object = None
 
     @property
     def p(self):
@@ -145,10 +149,11 @@ def maxcut(n, seed=0, avg_degree=12.0):
 
 
 # --------------------------------------------------------------------------- randSDP
-def randsdp(n, m, seed=0, varbounds=True):
+def randsdp(n, m, seed=0, varbounds=True, dense=False):
     """test/base_randsdp.jl:4-23 with test/moi_randsdp.jl's model: m dense
     equality constraints <A_k,X> = b_k, optional -10 <= X[k] <= 10 on the first n
-    scalar variables, min <C,X>."""
+    scalar variables, min <C,X>.  dense=True hands the m x N coefficient matrix over as
+    `M_dense` (row-major) instead of a CSC with every entry stored."""
     rng = np.random.default_rng(seed)
     R = rng.random((n, n))
     C = R @ R.T
@@ -162,7 +167,7 @@ def randsdp(n, m, seed=0, varbounds=True):
         Ak = Rk @ Rk.T
         rowsA[k] = _sym_coeff_vector(Ak)
         b[k] = float(np.sum(Ak * Xbar))
-    A = sp.csc_matrix(rowsA)
+    A = sp.csc_matrix((m, N)) if dense else sp.csc_matrix(rowsA)
     if varbounds:
         # for k in 1:n: (-X[k] <= 10) then (X[k] <= 10), interleaved (moi_randsdp.jl:33-45)
         r = np.arange(2 * n)
@@ -173,7 +178,44 @@ def randsdp(n, m, seed=0, varbounds=True):
     else:
         G, h = _empty(N), np.zeros(0)
     return Problem(n=N, A=A, b=b, G=G, h=h, c=_sym_coeff_vector(C),
-                   psd=[np.arange(N, dtype=np.int64)], name=f"randsdp-n{n}-m{m}-s{seed}")
+                   psd=[np.arange(N, dtype=np.int64)], name=f"randsdp-n{n}-m{m}-s{seed}",
+                   M_dense=rowsA if dense else None)
+
+
+def randsdp_device(n, m, seed=0, varbounds=True, device="cuda:0"):
+    """The same model generated ON THE GPU (torch RNG, so not the numpy instance of
+    `randsdp`): at the BASELINE size n=2000, m=4000 the coefficient matrix is
+    4000 x 2 001 000 doubles = 64 GB, which is only ever materialised in HBM.
+    Returns a Problem whose `M_dense` is a torch tensor on `device`."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    f64 = torch.float64
+    N = sympackedlen(n)
+    jj = torch.repeat_interleave(torch.arange(n, device=device), torch.arange(1, n + 1, device=device))
+    ii = torch.arange(N, device=device) - jj * (jj + 1) // 2
+    w = torch.where(ii == jj, 1.0, 2.0).to(f64)          # 2x on off-diagonal triangle variables
+    R = torch.rand((n, n), dtype=f64, device=device, generator=g)
+    C = R @ R.T
+    Gm = torch.randn((n, n), dtype=f64, device=device, generator=g)
+    Xbar = Gm @ Gm.T
+    M = torch.empty((m, N), dtype=f64, device=device)
+    b = torch.empty(m, dtype=f64, device=device)
+    for k in range(m):
+        Rk = torch.rand((n, n), dtype=f64, device=device, generator=g)
+        Ak = Rk @ Rk.T
+        M[k] = Ak[ii, jj] * w
+        b[k] = (Ak * Xbar).sum()
+    c = (C[ii, jj] * w).cpu().numpy()
+    if varbounds:
+        r = np.arange(2 * n)
+        cidx = np.repeat(np.arange(n), 2)
+        G = sp.csc_matrix((np.tile([-1.0, 1.0], n), (r, cidx)), shape=(2 * n, N))
+        h = np.full(2 * n, 10.0)
+    else:
+        G, h = _empty(N), np.zeros(0)
+    return Problem(n=N, A=sp.csc_matrix((m, N)), b=b.cpu().numpy(), G=G, h=h, c=c,
+                   psd=[np.arange(N, dtype=np.int64)], name=f"randsdp-gpu-n{n}-m{m}-s{seed}", M_dense=M)
 
 
 # --------------------------------------------------------------------------- MIMO

@@ -16,6 +16,14 @@ GOLDEN = ROOT / "tests" / "golden"
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
     config.addinivalue_line("markers", "slow: long CPU test")
+    # torch's bundled HIP runtime must initialise before libproxsdp_hip.so's (see binding.lib):
+    # some GPU tests hand torch device tensors to the library
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
 
 
 @pytest.fixture(scope="session")

@@ -420,6 +420,53 @@ def test_randsdp_config_against_oracle():
     assert sol.stats["full_eigs"] == sol.iter
 
 
+def test_randsdp_dense_matrix_entry_matches_sparse_and_oracle():
+    """proxsdp_problem.M_dense (host pointer): the dense A streamed as a row-major array must
+    reproduce the CSC path (same data, summation order differs) and the oracle's trace."""
+    pr_s = P.randsdp(60, 40, seed=3)
+    pr_d = P.randsdp(60, 40, seed=3, dense=True)
+    assert pr_d.A.nnz == 0 and pr_d.M_dense.shape == (40, 1830)
+    s_s = Optimizer(max_iter=300).optimize(pr_s, trace_capacity=300)
+    s_d = Optimizer(max_iter=300).optimize(pr_d, trace_capacity=300)
+    assert s_d.status == s_s.status and s_d.iter == s_s.iter
+    cols = [1, 2, 3, 4, 5, 6, 7, 11]
+    assert np.array_equal(s_d.trace[:, 11], s_s.trace[:, 11])
+    assert np.allclose(s_d.trace[:60, cols], s_s.trace[:60, cols], rtol=1e-7, atol=1e-10)
+    assert np.allclose(s_d.trace[:, 1:3], s_s.trace[:, 1:3], rtol=1e-4, atol=1e-6 * np.abs(s_s.trace[:, 1:3]).max())
+    assert np.allclose(s_d.primal, s_s.primal, rtol=1e-4, atol=1e-6 * np.abs(s_s.primal).max())
+    assert np.allclose(s_d.slack_eq, s_s.slack_eq, atol=1e-6 * (1 + np.abs(pr_s.b).max()))
+    assert np.allclose(s_d.dual_cone, s_s.dual_cone, rtol=1e-4, atol=1e-6 * np.abs(s_s.dual_cone).max())
+    assert s_d.stats["dense_passes"] >= 2 * s_d.iter            # one A x and >= one batched A'y per iteration
+    o = Options()
+    o.max_iter = 300
+    ref = oracle.solve(pr_s, o, trace=True)
+    G = _trace_cols(ref.trace)
+    assert np.allclose(s_d.trace[:60, [1, 2, 3, 4, 7, 11]], G[:60], rtol=1e-7, atol=1e-10)
+
+
+def test_randsdp_dense_matrix_on_device_lanczos_size():
+    """M_dense as a DEVICE pointer (generated on the GPU, as the 64 GB BASELINE size must be),
+    n = 150 so the Lanczos path runs; checked against the CSC path fed the same numbers and
+    against the solver's own optimality measures."""
+    import torch
+    pr_d = P.randsdp_device(150, 120, seed=5, device="cuda:0")
+    M = pr_d.M_dense.cpu().numpy()
+    import scipy.sparse as sp
+    pr_s = P.Problem(n=pr_d.n, A=sp.csc_matrix(M), b=pr_d.b, G=pr_d.G, h=pr_d.h, c=pr_d.c, psd=pr_d.psd)
+    kw = dict(max_iter=600)                  # (PDHG needs > 20 000 iterations on this family)
+    s_d = Optimizer(**kw).optimize(pr_d, trace_capacity=600)
+    s_s = Optimizer(**kw).optimize(pr_s, trace_capacity=600)
+    assert s_d.status == s_s.status == 3 and s_d.iter == s_s.iter == 600
+    assert np.array_equal(s_d.trace[:, 11], s_s.trace[:, 11])          # same linesearch decisions
+    sc = np.abs(s_s.trace[:, 1:5]).max(axis=0)
+    assert np.allclose(s_d.trace[:40, 1:5], s_s.trace[:40, 1:5], rtol=1e-6, atol=1e-9 * sc)
+    assert np.allclose(s_d.trace[:, 1:3], s_s.trace[:, 1:3], rtol=1e-3, atol=1e-5 * sc[:2])
+    assert np.allclose(s_d.primal, s_s.primal, rtol=1e-3, atol=1e-5 * np.abs(s_s.primal).max())
+    assert np.allclose(s_d.slack_eq, s_s.slack_eq, rtol=1e-3, atol=1e-6 * (1 + np.abs(pr_d.b).max()))
+    assert s_d.stats["lanczos_matvecs"] > 0
+    assert torch.equal(pr_d.M_dense.cpu(), torch.from_numpy(M))        # borrowed matrix untouched
+
+
 @pytest.mark.parametrize("fname,iters", [("maxG51", 40), ("gpp500-1", 40)])
 def test_sdplib_full_eig_fallback_config(fname, iters, golden_dir):
     """BASELINE config 'SDPLIB maxG51 / gpp500-1, full-rank fallback eig path'

@@ -27,7 +27,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert len(names) >= 14
     for name in names:
         assert hasattr(L, name), f"{name} declared in include/proxsdp_hip.h but not exported"
-    assert L.proxsdp_hip_abi_version() == 1
+    assert L.proxsdp_hip_abi_version() == 2
 
 
 def test_options_struct_layout_and_defaults_match_reference_options():
@@ -158,3 +158,21 @@ def test_preprocess_reorders_cone_variables_first():
     assert list(inv) == [5, 6, 1, 2, 0, 3, 4]
     s = np.sqrt(2) / 2
     assert np.allclose(c_scaled, [4, 2 * s, 3, 5, 6, 0, 1])
+
+
+def test_dense_matrix_entry_validation():
+    """proxsdp_problem.M_dense (include/proxsdp_hip.h): accepted only with the variables in
+    solver order; the sparse structures then hold G alone."""
+    pr = P.randsdp(5, 4, seed=2, dense=True)
+    assert pr.A.nnz == 0 and pr.M_dense.shape == (4, 15)
+    order, inv, c_scaled, fro = B.host_preprocess(pr)
+    assert np.array_equal(order, np.arange(15)) and np.array_equal(inv, np.arange(15))
+    assert fro == pytest.approx(np.sqrt(2 * (1 + .5 + 1 + .5 + .5)))    # the +-1 bound rows of G only (off-diagonals x sqrt(2)/2)
+    # a free variable placed BEFORE the cone variables is not in solver order
+    bad = P.Problem(n=4, A=sp.csc_matrix((1, 4)), b=np.ones(1), G=sp.csc_matrix((0, 4)), h=np.zeros(0),
+                    c=np.ones(4), psd=[np.array([1, 2, 3])], M_dense=np.ones((1, 4)))
+    with pytest.raises(B.ProxSDPHipError, match="solver order"):
+        B.host_preprocess(bad)
+    with pytest.raises(ValueError, match="wrong shape"):
+        B._Marshalled(P.Problem(n=4, A=sp.csc_matrix((1, 4)), b=np.ones(1), G=sp.csc_matrix((0, 4)),
+                                h=np.zeros(0), c=np.ones(4), M_dense=np.ones((2, 4))))
