@@ -50,9 +50,12 @@ def main():
                     help="max_target_rank_krylov_eigs for the time-to-tol leg (metric: rank ~ sqrt(n))")
     ap.add_argument("--profile-every", type=int, default=16)
     ap.add_argument("--support-path", type=int, default=-1, help="-1 auto, 0 dense vector passes, 1 support-aware")
-    ap.add_argument("--workload", choices=["maxcut", "mimo"], default="maxcut",
+    ap.add_argument("--workload", choices=["maxcut", "mimo", "randsdp"], default="maxcut",
                     help="maxcut: the metric's instance, replicas for N>1; mimo: BASELINE config 4, a block-diagonal "
-                         "model of --blocks MIMO n=512 instances, PSD blocks sharded over the ranks")
+                         "model of --blocks MIMO n=512 instances, PSD blocks sharded over the ranks; randsdp: BASELINE "
+                         "config 3, dense equality rows generated in HBM (--rand-n 2000 --rand-m 4000 = 64 GB)")
+    ap.add_argument("--rand-n", type=int, default=2000)
+    ap.add_argument("--rand-m", type=int, default=4000)
     ap.add_argument("--blocks", type=int, default=8)
     ap.add_argument("--mimo-n", type=int, default=512)
     args = ap.parse_args()
@@ -73,6 +76,8 @@ def main():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     if args.workload == "mimo":
         return bench_mimo(args, torch, dist, rank, world, dev_id, backend)
+    if args.workload == "randsdp":
+        return bench_randsdp(args, torch, dist, rank, world, dev_id, backend)
     n = args.n
     K, W = args.steps, args.warmup
     pr = problems.maxcut(n, seed=replicas.replica_seed(args.seed, rank))
@@ -164,6 +169,65 @@ def main():
                                "wall_s": time.time() - tc}
     if rank == 0:
         print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def bench_randsdp(args, torch, dist, rank, world, dev_id, backend):
+    """BASELINE config 3: randSDP (test/base_randsdp.jl:4-23 + the bounds of test/moi_randsdp.jl),
+    every A_k dense.  At n=2000, m=4000 the coefficient matrix is 4000 x 2 001 000 doubles = 64 GB:
+    generated in HBM and handed to the library as a borrowed device pointer (M_dense).  Each PDHG
+    iteration streams it twice (A x, and A'[y1 y2 y3] for the batched linesearch candidates); a
+    single PSD block does not shard, so N > 1 runs replicas."""
+    from proxsdp_jl_amd import problems, replicas
+    from proxsdp_jl_amd.optimizer import Optimizer
+    K, W = args.steps, args.warmup
+    n, m = args.rand_n, args.rand_m
+    torch.cuda.set_device(dev_id)
+    t_gen = time.time()
+    pr = problems.randsdp_device(n, m, seed=replicas.replica_seed(args.seed, rank), device="cuda:%d" % dev_id)
+    torch.cuda.synchronize()
+    t_gen = time.time() - t_gen
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    opt = Optimizer(max_iter=W + K, device_id=dev_id)
+    sync()
+    t0 = time.time()
+    sol = opt.optimize(pr, trace_capacity=W + K)
+    sync()
+    wall = time.time() - t0
+    tr = sol.trace
+    if len(tr) < W + K:
+        raise SystemExit(f"solve stopped after {len(tr)} iterations (< warmup+steps): status {sol.status}")
+    t_steps = float(tr[W + K - 1, 12] - (tr[W - 1, 12] if W > 0 else 0.0))
+    total_steps, t_steps = replicas.aggregate(dist, K, t_steps, device="cuda" if dist is not None else "cpu")
+    if rank == 0:
+        st = sol.stats
+        N = n * (n + 1) // 2
+        bytes_pass = 8.0 * m * N
+        pass_ms = st["dense_ms"] / max(1, st["dense_passes"])
+        print(json.dumps({
+            "metric": "PDHG iterations/sec, randSDP n=%d m=%d (dense A, %.1f GB)" % (n, m, bytes_pass / 1e9),
+            "value": total_steps / t_steps, "unit": "iterations/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": 1e3 * t_steps / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "randSDP n=%d, m=%d dense equality rows + %d bound rows, Nx=%d; A generated in HBM "
+                                   "(torch), borrowed by the library" % (n, m, 2 * n, N),
+                       "parallelism": "replicas x%d (single PSD block does not shard)" % world,
+                       "dense_passes_per_step": st["dense_passes"] / max(1, int(sol.iter)),
+                       "linesearch_trials_per_step": st["linesearch_trials"] / max(1, int(sol.iter)),
+                       "lanczos_matvecs_per_step": st["lanczos_matvecs"] / max(1, int(sol.iter)),
+                       "full_eigs": int(st["full_eigs"]), "target_rank": int(tr[W + K - 1, 10])},
+            "roofline": {"bound": "hbm", "kernel": "k_dense_mtv / k_dense_mv (one pass over A)",
+                         "achieved": bytes_pass / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else None, "peak": 8000.0,
+                         "unit": "GB/s", "frac": (bytes_pass / (pass_ms * 1e-3) / 1e9 / 8000.0) if pass_ms > 0 else None,
+                         "traffic": None, "bytes_per_launch": bytes_pass, "avg_launch_ms": pass_ms,
+                         "launches": int(st["dense_passes"])},
+            "generate_s": t_gen, "solve_wall_s": wall, "init_s": st["init_time"], "exit_s": st["exit_time"]}))
     if dist is not None:
         dist.destroy_process_group()
 

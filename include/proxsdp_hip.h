@@ -191,6 +191,7 @@ typedef struct proxsdp_stats {
     double  exit_time;           /* s: cache_solution                                */
     double  t_primal, t_psd, t_linesearch, t_residual;   /* s, host wall incl. syncs */
     int64_t dense_passes;        /* passes over a dense A (A x or batched A' y), 8*p*n bytes each */
+    double  dense_ms;            /* their summed durations (HIP events on the solve stream)    */
 } proxsdp_stats;
 
 /* Result (structs.jl:60-81).  Arrays are caller-allocated with the stated

@@ -1113,10 +1113,11 @@ k_combine(const double* __restrict__ part, int stride, int cnt, int nq, unsigned
 // borrowed matrix is never modified or copied.  Both products stream M once:
 // 8*Q*n bytes, HBM-bound.
 // ---------------------------------------------------------------------------
-constexpr int DMV_ROWS = 4;          // rows per workgroup in M x (x is re-used from registers)
-constexpr int DMV_UNR = 4;           // column strips in flight per thread
+// DMV_ROWS rows per workgroup in M x (x is re-used from registers), DMV_UNR column strips in
+// flight per thread
 
 // part[cs][r] = sum over the column slice cs of M[r, j] * s_j * x_j   (grid: row groups x slices)
+template <int DMV_ROWS, int DMV_UNR>
 __global__ void __launch_bounds__(TPB)
 k_dense_mv(const double* __restrict__ M, long long ld, int Q, long long n, const double* __restrict__ x,
            const unsigned char* __restrict__ offdiag, double scale, double* __restrict__ part, int qpad) {
@@ -1176,8 +1177,9 @@ k_dense_mv_fin(const double* __restrict__ part, int qpad, int nslice, int Q, dou
 // (the linesearch candidates tau, 3/4 tau, (3/4)^2 tau share the 8*Q*n bytes), plus the
 // partials of |OUT_c - old|^2 (pdhg.jl:556-563) when `old` != NULL, plus `addc` (c_orig for
 // the exit path's dual cone).  Thread = column; the loop over rows keeps DMT_UNR loads in flight.
-constexpr int DMT_UNR = 8;
-template <int NC>
+// CPT columns per thread (TPB apart: a workgroup reads CPT * 2 KB contiguous bytes of every
+// row), DMT_UNR rows in flight.
+template <int NC, int CPT, int DMT_UNR>
 __global__ void __launch_bounds__(TPB)
 k_dense_mtv(const double* __restrict__ M, long long ld, int Q, long long n, const double* __restrict__ Y,
             long long ystride, const unsigned char* __restrict__ offdiag, double scale,
@@ -1188,30 +1190,48 @@ k_dense_mtv(const double* __restrict__ M, long long ld, int Q, long long n, cons
     double ss[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) ss[c] = 0.0;
-    const long long nchunk = (n + TPB - 1) / TPB;
+    const long long span = (long long)TPB * CPT;
+    const long long nchunk = (n + span - 1) / span;
     for (long long b = blockIdx.x; b < nchunk; b += gridDim.x) {
-        const long long j = b * TPB + threadIdx.x;
-        const long long jc = (j < n) ? j : n - 1;
-        const double* col = M + jc;
-        double acc[NC];
+        const double* col[CPT];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+        for (int t = 0; t < CPT; ++t) {
+            const long long j = b * span + (long long)t * TPB + threadIdx.x;
+            col[t] = M + ((j < n) ? j : n - 1);
+        }
+        double acc[NC][CPT];
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int t = 0; t < CPT; ++t) acc[c][t] = 0.0;
         int k = 0;
         for (; k + DMT_UNR <= Q; k += DMT_UNR) {
-            double mv[DMT_UNR];
-#pragma unroll
-            for (int u = 0; u < DMT_UNR; ++u) mv[u] = col[(long long)(k + u) * ld];
+            double mv[DMT_UNR][CPT];
 #pragma unroll
             for (int u = 0; u < DMT_UNR; ++u)
 #pragma unroll
-                for (int c = 0; c < NC; ++c) acc[c] += mv[u] * Y[c * ystride + k + u];
+                for (int t = 0; t < CPT; ++t) mv[u][t] = col[t][(long long)(k + u) * ld];
+#pragma unroll
+            for (int u = 0; u < DMT_UNR; ++u)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const double yv = Y[c * ystride + k + u];
+#pragma unroll
+                    for (int t = 0; t < CPT; ++t) acc[c][t] += mv[u][t] * yv;
+                }
         }
         for (; k < Q; ++k) {
-            const double mvk = col[(long long)k * ld];
 #pragma unroll
-            for (int c = 0; c < NC; ++c) acc[c] += mvk * Y[c * ystride + k];
+            for (int t = 0; t < CPT; ++t) {
+                const double mvk = col[t][(long long)k * ld];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[c][t] += mvk * Y[c * ystride + k];
+            }
         }
-        if (j < n) {
+#pragma unroll
+        for (int t = 0; t < CPT; ++t) {
+            const long long j = b * span + (long long)t * TPB + threadIdx.x;
+            if (j >= n) continue;
             const double sc = (offdiag != nullptr && offdiag[j]) ? scale : 1.0;
             const double o = (old != nullptr) ? old[j] : 0.0;
             const double ad = (addc != nullptr) ? addc[j] : 0.0;
@@ -1224,7 +1244,7 @@ k_dense_mtv(const double* __restrict__ M, long long ld, int Q, long long n, cons
                     for (int c = 0; c < NC; ++c) spv[c] += sp_val[q] * Y[c * ystride + sp_row[q]];
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                const double v = acc[c] * sc + spv[c] + ad;
+                const double v = acc[c][t] * sc + spv[c] + ad;
                 OUT[c * ostride + j] = v;
                 const double d = v - o;
                 ss[c] += d * d;

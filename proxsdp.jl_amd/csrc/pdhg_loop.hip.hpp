@@ -375,9 +375,9 @@ inline void Solver::setup_dense() {
     offdiag_d.alloc(P.n);
     offdiag_d.upload(P.offdiag.data(), P.n, stream);
     // M x: row groups x column slices; enough workgroups to fill 256 CUs several times over
-    const int rg = ceil_div((int)std::max<int64_t>(P.p, 1), dev::DMV_ROWS);
+    const int rg = ceil_div((int)std::max<int64_t>(P.p, 1), DMV_ROWS);
     dmv_slices = std::max(1, std::min(64, ceil_div(2048, rg)));
-    const long long chunks = ((long long)P.n + dev::TPB * dev::DMV_UNR - 1) / (dev::TPB * dev::DMV_UNR);
+    const long long chunks = ((long long)P.n + dev::TPB * DMV_UNR - 1) / (dev::TPB * DMV_UNR);
     dmv_slices = (int)std::min<long long>(dmv_slices, std::max<long long>(chunks, 1));
     dmv_qpad = (int)std::max<int64_t>(P.p, 1);
     dmv_part.alloc((size_t)dmv_slices * dmv_qpad);
@@ -397,15 +397,44 @@ inline void Solver::setup_dense() {
     g_frob = std::sqrt(ss + P.frob * P.frob);            // + the sparse rows (G)
 }
 
+// every pass over the dense A is bracketed by events (8 ms each at the BASELINE size: the
+// bracketing is free); harvested after the iteration's last synchronisation
+inline void Solver::dense_ev_begin() {
+    if (dense_ev_used == dense_ev.size()) {
+        hipEvent_t a, b;
+        PX_HIP(hipEventCreate(&a)); PX_HIP(hipEventCreate(&b));
+        dense_ev.emplace_back(a, b);
+    }
+    PX_HIP(hipEventRecord(dense_ev[dense_ev_used].first, stream));
+}
+inline void Solver::dense_ev_end() {
+    PX_HIP(hipEventRecord(dense_ev[dense_ev_used].second, stream));
+    ++dense_ev_used;
+}
+inline void Solver::dense_ev_harvest() {
+    for (size_t i = 0; i < dense_ev_used; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, dense_ev[i].first, dense_ev[i].second) == hipSuccess) st.dense_ms += ms;
+    }
+    dense_ev_used = 0;
+}
+
 // y = M (s o x)  (scaled = the solver's M) or M x (the caller's M, exit path)
 inline void Solver::dense_mv(const double* x, double* y, bool scaled) {
     if (P.p == 0) return;
-    const int rg = ceil_div((int)P.p, dev::DMV_ROWS);
-    hipLaunchKernelGGL(dev::k_dense_mv, dim3(rg, dmv_slices), dim3(dev::TPB), 0, stream,
-                       Md, (long long)P.n, (int)P.p, (long long)P.n, x, scaled ? offdiag_d.p : nullptr,
-                       std::sqrt(2.0) / 2.0, dmv_part.p, dmv_qpad);
+    const int rg = ceil_div((int)P.p, DMV_ROWS);
+    dense_ev_begin();
+    auto lmv = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(rg, dmv_slices), dim3(dev::TPB), 0, stream,
+                           Md, (long long)P.n, (int)P.p, (long long)P.n, x, scaled ? offdiag_d.p : nullptr,
+                           std::sqrt(2.0) / 2.0, dmv_part.p, dmv_qpad);
+    };
+    // shape sweep at n=2000, m=4000 (tools/gpurun_dense_tune.py): <4,4> 6.41, <8,4> 6.55, <4,8> 6.20,
+    // <2,8> 6.20, <8,2> 6.51 TB/s
+    lmv(dev::k_dense_mv<DMV_ROWS, DMV_UNR>);
     hipLaunchKernelGGL(dev::k_dense_mv_fin, dim3(ceil_div((int)P.p, dev::TPB)), dim3(dev::TPB), 0, stream,
                        dmv_part.p, dmv_qpad, dmv_slices, (int)P.p, y);
+    dense_ev_end();
     st.dense_passes += 1;
 }
 
@@ -420,9 +449,11 @@ inline void Solver::dense_mtv(int nc, const double* Y, long long ystride, bool s
                            Y, ystride, od, sc, OUT, ostride, old, addc, normpart, cstride,
                            scaled && P.nnz > 0 ? csc_ptr.p : nullptr, csc_row.p, csc_val.p);
     };
-    if (nc == 1) launch(dev::k_dense_mtv<1>);
-    else if (nc == 2) launch(dev::k_dense_mtv<2>);
-    else launch(dev::k_dense_mtv<3>);
+    dense_ev_begin();
+    if (nc == 1) launch(dev::k_dense_mtv<1, 1, 8>);
+    else if (nc == 2) launch(dev::k_dense_mtv<2, 1, 8>);
+    else launch(dev::k_dense_mtv<3, 1, 8>);      // <3,1,16> 6.41, <3,2,8> 6.39, <3,4,4> 6.47, <3,2,4> 6.37 TB/s: flat
+    dense_ev_end();
     st.dense_passes += 1;
 }
 
@@ -838,6 +869,7 @@ inline void Solver::run() {
             double bb = 8.0 * (double)P.n * (11.0 + 3.0 * t) + 12.0 * (double)P.nnz * (1.0 + t) +
                         8.0 * (double)P.Q * (8.0 + 6.0 * t);
             if (P.dense()) {                             // M x + one M'y pass per candidate batch
+                dense_ev_harvest();
                 bb += 8.0 * (double)P.p * (double)P.n * (double)(st.dense_passes - dense_passes_seen);
                 dense_passes_seen = st.dense_passes;
             }

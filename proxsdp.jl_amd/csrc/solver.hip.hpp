@@ -161,6 +161,7 @@ public:
         if (warm.joinable()) warm.join();
         for (auto e : ev.e0) (void)hipEventDestroy(e);
         for (auto e : ev.e1) (void)hipEventDestroy(e);
+        for (auto& pr : dense_ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
         if (blas) (void)rocblas_destroy_handle(blas);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -278,7 +279,13 @@ private:
     DevBuf<double> Md_own, dmv_part, Mtycand_d;
     DevBuf<unsigned char> offdiag_d;
     int dmv_slices = 1, dmv_qpad = 0;
+    static constexpr int DMV_ROWS = 8, DMV_UNR = 4;       // k_dense_mv shape (rows per workgroup, strips in flight)
     long long dense_passes_seen = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> dense_ev;   // one pair per pass of the current iteration
+    size_t dense_ev_used = 0;
+    void dense_ev_begin();
+    void dense_ev_end();
+    void dense_ev_harvest();
     std::vector<double> hbscal;
 };
 
