@@ -46,6 +46,11 @@ struct Problem                   # proxsdp_problem
     index_base::Int32
     reserved0::Int32
     eig_resid::Ptr{Float64}
+    reduce_ctx::Ptr{Cvoid}       # block-sharded solves only (INTEGRATION.md); C_NULL otherwise
+    reduce_fn::Ptr{Cvoid}
+    M_dense::Ptr{Float64}        # optional dense A (row-major p x n); C_NULL = use the CSC A
+    M_dense_on_device::Int32
+    reserved1::Int32
 end
 
 struct Stats                     # proxsdp_stats
@@ -67,6 +72,8 @@ struct Stats                     # proxsdp_stats
     t_psd::Float64
     t_linesearch::Float64
     t_residual::Float64
+    dense_passes::Int64
+    dense_ms::Float64
 end
 
 mutable struct CResult           # proxsdp_result
@@ -145,7 +152,8 @@ function chambolle_pock_hip(aff, con, options; ResultType = Main.ProxSDP.Result)
         prob = Problem(n, p, m, _csc(A), _csc(G), pointer(aff.b), pointer(aff.h), pointer(aff.c),
                        length(con.sdpcone), pointer(psd_ptr), pointer(psd_idx),
                        length(con.socone), pointer(soc_ptr), pointer(soc_idx),
-                       Int32(1), Int32(0), Ptr{Float64}(C_NULL))        # Julia indices are 1-based
+                       Int32(1), Int32(0), Ptr{Float64}(C_NULL),         # Julia indices are 1-based
+                       C_NULL, C_NULL, Ptr{Float64}(C_NULL), Int32(0), Int32(0))
         res.primal = pointer(primal); res.dual_cone = pointer(dual_cone)
         res.dual_eq = pointer(dual_eq); res.dual_in = pointer(dual_in)
         res.slack_eq = pointer(slack_eq); res.slack_in = pointer(slack_in)

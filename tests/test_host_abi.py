@@ -176,3 +176,38 @@ def test_dense_matrix_entry_validation():
     with pytest.raises(ValueError, match="wrong shape"):
         B._Marshalled(P.Problem(n=4, A=sp.csc_matrix((1, 4)), b=np.ones(1), G=sp.csc_matrix((0, 4)),
                                 h=np.zeros(0), c=np.ones(4), M_dense=np.ones((2, 4))))
+
+
+def _c_struct_fields(header, name):
+    import re
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), header, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    out = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        fp = re.search(r"\(\*(\w+)\)", decl)                  # function pointer member
+        if fp:
+            out.append(fp.group(1))
+            continue
+        for part in decl.split(","):
+            out.append(re.findall(r"(\w+)\s*(?:\[\w+\])?$", part.strip())[0])
+    return out
+
+
+@pytest.mark.parametrize("cname,jname,cls", [("proxsdp_problem", "Problem", "Problem"),
+                                             ("proxsdp_stats", "Stats", "Stats"),
+                                             ("proxsdp_result", "CResult", "Result")])
+def test_bindings_mirror_the_header_field_by_field(cname, jname, cls):
+    """The ctypes structures and the Julia shim's structs (julia/ProxSDPHip.jl, which cannot be
+    executed here) must list exactly the header's members, in order."""
+    import re
+    header = B.HEADER_PATH.read_text()
+    cf = _c_struct_fields(header, cname)
+    pyf = [f for f, _ in getattr(B, cls)._fields_]
+    assert pyf == cf
+    jl = (B.HEADER_PATH.parent.parent / "julia" / "ProxSDPHip.jl").read_text()
+    body = re.search(r"struct %s\b.*?\n(.*?)\n(?:    \w+\(\) = new\(\)\n)?end" % jname, jl, re.S).group(1)
+    jf = [re.match(r"\s*(\w+)::", ln).group(1) for ln in body.splitlines() if re.match(r"\s*\w+::", ln)]
+    assert jf == cf
