@@ -556,7 +556,7 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev) {
                 for (int r = 0; r < K; ++r) Tw[(size_t)c * K + r] = T[(size_t)c * ld + r];
             std::vector<double> Dasc(K);
             const double te0 = now_s();
-            symeig_dense(K, Tw.data(), Dasc.data());
+            symeig_dense(K, Tw.data(), Dasc.data(), kfirst == 0);
             st.t_primal += now_s() - te0;            // (field reused: host K x K eigensolves)
             U.assign((size_t)K * K, 0.0);
             for (int c = 0; c < K; ++c) {                // :LR -> descending
