@@ -125,7 +125,7 @@ def main():
                    "timed_iterations": [W + 1, W + K],
                    "lanczos_matvecs_per_step": mv_timed / K, "linesearch_trials_per_step": trials_timed / K,
                    "target_rank": int(tr[W + K - 1, 10])},
-        "roofline": {"bound": "hbm", "kernel": "k_symv_packed", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": "k_symv_finish / k_symv_packed (packed symmetric mat-vec tiles)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": "profiles/r01_pmc_fetch_write_symv.md (2*FETCH_SIZE + WRITE_SIZE, isolated kernel)",
                      "bytes_per_launch": symv_bytes, "avg_launch_ms": symv_ms,
