@@ -225,7 +225,10 @@ def bench_randsdp(args, torch, dist, rank, world, dev_id, backend):
             "roofline": {"bound": "hbm", "kernel": "k_dense_mtv / k_dense_mv (one pass over A)",
                          "achieved": bytes_pass / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else None, "peak": 8000.0,
                          "unit": "GB/s", "frac": (bytes_pass / (pass_ms * 1e-3) / 1e9 / 8000.0) if pass_ms > 0 else None,
-                         "traffic": None, "bytes_per_launch": bytes_pass, "avg_launch_ms": pass_ms,
+                         "traffic": None,
+                         "traffic_note": "rocprofv3 --pmc FETCH_SIZE segfaults at this size; on a 962 MB instance of the same "
+                                         "kernels traffic/algorithmic = 1.005 (A'y) and 1.018 (A x): profiles/r01_pmc_dense.md",
+                         "bytes_per_launch": bytes_pass, "avg_launch_ms": pass_ms,
                          "launches": int(st["dense_passes"])},
             "generate_s": t_gen, "solve_wall_s": wall, "init_s": st["init_time"], "exit_s": st["exit_time"]}))
     if dist is not None:

@@ -1192,7 +1192,13 @@ k_dense_mtv(const double* __restrict__ M, long long ld, int Q, long long n, cons
     for (int c = 0; c < NC; ++c) ss[c] = 0.0;
     const long long span = (long long)TPB * CPT;
     const long long nchunk = (n + span - 1) / span;
-    for (long long b = blockIdx.x; b < nchunk; b += gridDim.x) {
+    // XCD-aware chunk order (workgroup b runs on XCD b % 8): within every sweep of gridDim.x
+    // chunks XCD x walks a contiguous range, so the 128-byte lines that neighbouring 2 KB row
+    // segments share (rows start at arbitrary 8-byte alignment) are found in the same L2
+    // (PMC: 1.057x -> see profiles/r01_pmc_dense.md).  gridDim.x is a multiple of 8 or < 8.
+    const int gx8 = (gridDim.x >= 8 && (gridDim.x & 7) == 0) ? gridDim.x >> 3 : 0;
+    const long long bmine = gx8 ? (long long)(blockIdx.x & 7) * gx8 + (blockIdx.x >> 3) : blockIdx.x;
+    for (long long b = bmine; b < nchunk; b += gridDim.x) {
         const double* col[CPT];
 #pragma unroll
         for (int t = 0; t < CPT; ++t) {

@@ -441,7 +441,8 @@ inline void Solver::dense_mv(const double* x, double* y, bool scaled) {
 // OUT_c = s o (M' Y_c) [+ addc], c < nc <= 3, one pass over M
 inline void Solver::dense_mtv(int nc, const double* Y, long long ystride, bool scaled, double* OUT, long long ostride,
                               const double* old, const double* addc, double* normpart, long long cstride) {
-    const int gx = std::min(PSTRIDE, grid_for(P.n));
+    int gx = std::min(PSTRIDE, grid_for(P.n));
+    if (gx >= 8) gx &= ~7;                               // multiple of 8: XCD-aware chunk order in the kernel
     const unsigned char* od = scaled ? offdiag_d.p : nullptr;
     const double sc = std::sqrt(2.0) / 2.0;
     auto launch = [&](auto kern) {

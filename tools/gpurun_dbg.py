@@ -1,5 +1,5 @@
 import numpy as np, sys
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))); sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))), 'tests'))
 from helpers import planted_packed, smat
 from proxsdp_jl_amd import binding as B
 for n, nev, top in [(101, 2, [40.0, 25.0, 9.0, 4.0]), (257, 4, [90.0, 60.0, 33.0, 12.0, 5.0]),

@@ -1,5 +1,5 @@
 """Shape sweep of the dense-A kernels at the BASELINE randSDP size (PROXSDP_DMV / PROXSDP_DMT)."""
-import os, sys; sys.path.insert(0, ".")
+import os, sys; sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import torch
 torch.cuda.init()
 from proxsdp_jl_amd import problems as P

@@ -1,4 +1,4 @@
-import sys, time; sys.path.insert(0,'.'); sys.path.insert(0,'tests')
+import sys, time; sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))); sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))), 'tests'))
 import numpy as np, math
 from proxsdp_jl_amd import binding as B
 n, r = 4000, 24

@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0,'.'); sys.path.insert(0,'tests')
+import sys; sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))); sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))), 'tests'))
 import numpy as np, time
 from proxsdp_jl_amd import binding as B
 for n in (1000, 2000, 4000, 8000):

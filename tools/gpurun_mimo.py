@@ -1,4 +1,4 @@
-import sys, json; sys.path.insert(0,'.')
+import sys, json; sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np
 from proxsdp_jl_amd import problems as P
 from proxsdp_jl_amd.optimizer import Optimizer

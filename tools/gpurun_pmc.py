@@ -1,7 +1,7 @@
 # torch-free driver for PMC passes: one short dense-path solve (k_primal_update = calibration
 # kernel with known traffic: reads 3*8*Nx, writes 8*Nx with 8-byte-per-lane accesses) and
 # isolated symv launches.
-import sys; sys.path.insert(0,'.')
+import sys; sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np
 from proxsdp_jl_amd import binding as B, problems as P
 from proxsdp_jl_amd.optimizer import Optimizer

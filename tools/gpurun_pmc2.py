@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0,'.')
+import sys; sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np
 from proxsdp_jl_amd import binding as B
 n=4000; rng=np.random.default_rng(0)

@@ -1,5 +1,5 @@
 """Do torch's bundled HIP runtime and the system runtime behind libproxsdp_hip.so coexist in one process?"""
-import sys; sys.path.insert(0, ".")
+import sys; sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np
 order = sys.argv[1]
 from proxsdp_jl_amd import problems as P

@@ -1,5 +1,5 @@
 """time-to-tol run with the stats that split the Lanczos time (host K x K eigensolves = t_primal)."""
-import sys, time; sys.path.insert(0, ".")
+import sys, time; sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from proxsdp_jl_amd import problems as P
 from proxsdp_jl_amd.optimizer import Optimizer
 pr = P.maxcut(4000, seed=0)

@@ -1,5 +1,5 @@
 import json, sys, numpy as np
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))); sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))), 'tests'))
 from pathlib import Path
 from proxsdp_jl_amd import problems as P
 from proxsdp_jl_amd.optimizer import Optimizer
