@@ -68,7 +68,9 @@ def main():
     backend = os.environ.get("PROXSDP_BENCH_BACKEND", "nccl")       # "gloo" only for 1-GPU validation runs
     ndev = max(1, torch.cuda.device_count())
     dev_id = local_rank % ndev
-    if world > 1:
+    # PROXSDP_BENCH_FORCE_DIST=1: build the process group even for one rank (validates the
+    # RCCL barrier / reductions next to the library on a 1-GPU box)
+    if world > 1 or os.environ.get("PROXSDP_BENCH_FORCE_DIST") == "1":
         torch.cuda.set_device(dev_id)
         dist = replicas.init(backend, rank, world, device=torch.device("cuda", dev_id) if backend == "nccl" else None)
 
