@@ -165,6 +165,11 @@ typedef struct proxsdp_options {
     int32_t profile_symv_every;/* >0: bracket every k-th symv launch with HIP events  */
     int32_t support_path;      /* -1 auto (default), 0 dense vector passes, 1 force the
                                 * support-aware passes when legal */
+    int32_t lanczos_operator;  /* mat-vec inside the Lanczos projection: 0 = packed triangle of the
+                                * iterate (what dsymv('U') reads, 8 N bytes), 1 = operator form
+                                * x_prev(low rank) + sparse update when available (support path;
+                                * DESIGN.md section 4), -1 auto = 1 (default) */
+    int32_t reserved2;
 } proxsdp_options;
 
 #define PROXSDP_TRACE_COLS 14
@@ -192,6 +197,7 @@ typedef struct proxsdp_stats {
     double  t_primal, t_psd, t_linesearch, t_residual;   /* s, host wall incl. syncs */
     int64_t dense_passes;        /* passes over a dense A (A x or batched A' y), 8*p*n bytes each */
     double  dense_ms;            /* their summed durations (HIP events on the solve stream)    */
+    int64_t fop_projections;     /* projections whose Lanczos mat-vecs ran in operator form     */
 } proxsdp_stats;
 
 /* Result (structs.jl:60-81).  Arrays are caller-allocated with the stated

@@ -74,6 +74,7 @@ struct Stats                     # proxsdp_stats
     t_residual::Float64
     dense_passes::Int64
     dense_ms::Float64
+    fop_projections::Int64
 end
 
 mutable struct CResult           # proxsdp_result

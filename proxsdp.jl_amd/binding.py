@@ -100,6 +100,7 @@ def _opt_fields():
     a("equilibration_lb", f64); a("equilibration_ub", f64); a("equilibration_limit", f64)
     a("equilibration_force", i32); a("approx_norm", i32)
     a("device_id", i32); a("trace_capacity", i32); a("profile_symv_every", i32); a("support_path", i32)
+    a("lanczos_operator", i32); a("pad7", i32)
     return F
 
 
@@ -113,7 +114,7 @@ class Stats(C.Structure):
                 ("symv_launches", i64), ("symv_profiled", i64), ("symv_profiled_ms", f64),
                 ("symv_bytes", f64), ("algorithmic_bytes", f64), ("init_time", f64),
                 ("loop_time", f64), ("exit_time", f64), ("t_primal", f64), ("t_psd", f64),
-                ("t_linesearch", f64), ("t_residual", f64), ("dense_passes", i64), ("dense_ms", f64)]
+                ("t_linesearch", f64), ("t_residual", f64), ("dense_passes", i64), ("dense_ms", f64), ("fop_projections", i64)]
 
 
 class Result(C.Structure):

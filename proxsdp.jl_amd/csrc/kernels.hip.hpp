@@ -411,15 +411,30 @@ __device__ __forceinline__ double fold16_all(double (&t)[16], int lane) {
     fold_stage<1>(t, lane);
     return add_xor32(add_xor16(t[0]));               // lane holds column (lane & 15)
 }
-template <int NCH>
+// Operator-form inputs of k_lz_orth / k_fop* (see "Operator-form mat-vec" below)
+struct FopArgs {
+    const double* Vp;        // previous projection's Ritz vectors, column c at Vp + c*ldv
+    const double* lam;       // their (positive) eigenvalues
+    int rp;                  // how many (0: x_prev = 0 off the support)
+    const double* tpart;     // [rp][pld] partial dots Vp' v written by k_fop*
+    const double* ebuf;      // (E v)_i
+    const double* apart;     // [pld] partials of v' E v
+};
+// NCHP = 0: the mat-vec came from the packed tiles (Ppart / Apart).  NCHP > 0: it is rebuilt from
+// the operator-form pieces (16*NCHP*4 >= rp): A v = Vp (lam o (Vp' v)) + E v.
+template <int NCH, int NCHP>
 __global__ void __launch_bounds__(TPB)
 k_lz_orth(const double* __restrict__ Ppart, int nt, int npad, const double* __restrict__ V, int ldv, int k,
           double* __restrict__ wbuf, const double* __restrict__ hpart_prev, double* __restrict__ hpart_out, int pld,
           double* __restrict__ hsum_out, const LanczosCtl* __restrict__ ctl,
           const double* __restrict__ alphas, const double* __restrict__ betas,
-          const double* __restrict__ Apart, int napart, int first, const double* __restrict__ arrow, int keep) {
+          const double* __restrict__ Apart, int napart, int first, const double* __restrict__ arrow, int keep,
+          FopArgs fo) {
     if (ctl->stop) return;
     constexpr int NC = 16 * NCH;
+    constexpr int NCP = 16 * (NCHP > 0 ? NCHP : 1);
+    __shared__ double s_t[4 * NCP];
+    __shared__ double s_u[4 * NCP];
     __shared__ double s_h[4 * NC];
     __shared__ double s_q[4 * NC];
     __shared__ double s_acc[NWAVE][LZ_ROWS];
@@ -429,11 +444,24 @@ k_lz_orth(const double* __restrict__ Ppart, int nt, int npad, const double* __re
     const int i = blockIdx.x * LZ_ROWS + lane;       // < npad always; rows >= n carry zeros
     // ---- all loads
     double pv[16];                                   // mat-vec partial slots wv, wv+4, ...
-#pragma unroll
-    for (int u = 0; u < 16; ++u) pv[u] = Ppart[(long long)min(wv + u * NWAVE, nt - 1) * npad + i];
     double av[8];                                    // per-tile shares of w' P~ w'
+    double vrp[NCP], tp[NCP], eb = 0.0, ap = 0.0;    // operator form: Vp columns, Vp'v partials, (E v)_i, v'Ev partials
+    if constexpr (NCHP == 0) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) av[u] = Apart[min((int)threadIdx.x + u * TPB, napart - 1)];
+        for (int u = 0; u < 16; ++u) pv[u] = Ppart[(long long)min(wv + u * NWAVE, nt - 1) * npad + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) av[u] = Apart[min((int)threadIdx.x + u * TPB, napart - 1)];
+    } else {
+        const int gl0 = min(lane, pld - 1);
+#pragma unroll
+        for (int c = 0; c < NCP; ++c) {
+            const int cc = min(wv + 4 * c, max(fo.rp - 1, 0));
+            vrp[c] = fo.Vp[(long long)cc * ldv + i];
+            tp[c] = fo.tpart[(long long)cc * pld + gl0];
+        }
+        eb = fo.ebuf[i];
+        ap = fo.apart[gl0];
+    }
     double vr[NC];                                   // basis columns of this wave (column k included)
 #pragma unroll
     for (int c = 0; c < NC; ++c) vr[c] = V[(long long)min(wv + 4 * c, k) * ldv + i];
@@ -443,18 +471,40 @@ k_lz_orth(const double* __restrict__ Ppart, int nt, int npad, const double* __re
     for (int c = 0; c < NC; ++c) hp[c] = hpart_prev[(long long)min(wv + 4 * c, MAXK - 1) * pld + gl];
     const double binv = first ? 1.0 : 1.0 / betas[k - 1];
     // ---- reductions
+    if constexpr (NCHP == 0) {
 #pragma unroll
-    for (int u = 0; u < 16; ++u) if (wv + u * NWAVE >= nt) pv[u] = 0.0;
-    double acc = (((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]))) +
-                 (((pv[8] + pv[9]) + (pv[10] + pv[11])) + ((pv[12] + pv[13]) + (pv[14] + pv[15])));
-    for (int s = wv + 16 * NWAVE; s < nt; s += NWAVE) acc += Ppart[(long long)s * npad + i];      // n > 4096
-    s_acc[wv][lane] = acc;
+        for (int u = 0; u < 16; ++u) if (wv + u * NWAVE >= nt) pv[u] = 0.0;
+        double acc = (((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]))) +
+                     (((pv[8] + pv[9]) + (pv[10] + pv[11])) + ((pv[12] + pv[13]) + (pv[14] + pv[15])));
+        for (int s = wv + 16 * NWAVE; s < nt; s += NWAVE) acc += Ppart[(long long)s * npad + i];      // n > 4096
+        s_acc[wv][lane] = acc;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) if ((int)threadIdx.x + u * TPB >= napart) av[u] = 0.0;
-    double a = ((av[0] + av[1]) + (av[2] + av[3])) + ((av[4] + av[5]) + (av[6] + av[7]));
-    for (int t = threadIdx.x + 8 * TPB; t < napart; t += TPB) a += Apart[t];                      // n > 4096
-    a = wave_sum(a);
-    if (lane == 0) s_red[wv] = a;
+        for (int u = 0; u < 8; ++u) if ((int)threadIdx.x + u * TPB >= napart) av[u] = 0.0;
+        double a = ((av[0] + av[1]) + (av[2] + av[3])) + ((av[4] + av[5]) + (av[6] + av[7]));
+        for (int t = threadIdx.x + 8 * TPB; t < napart; t += TPB) a += Apart[t];                      // n > 4096
+        a = wave_sum(a);
+        if (lane == 0) s_red[wv] = a;
+    } else {
+        // t = Vp' v (sum of the workgroup partials), v'Ev
+#pragma unroll
+        for (int c = 0; c < NCP; ++c) {
+            const int cc = wv + 4 * c;
+            if (lane >= pld || cc >= fo.rp) tp[c] = 0.0;
+            else for (int g = lane + WAVE; g < pld; g += WAVE) tp[c] += fo.tpart[(long long)cc * pld + g];   // n > 4096
+        }
+#pragma unroll
+        for (int ch = 0; ch < NCHP; ++ch) {
+            double t[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) t[c] = tp[16 * ch + c];
+            const double ts = fold16_all(t, lane);
+            if (lane < 16) s_t[wv + 4 * (16 * ch + lane)] = ts;          // zero for c >= rp
+        }
+        if (lane >= pld) ap = 0.0;
+        else for (int g = lane + WAVE; g < pld; g += WAVE) ap += fo.apart[g];
+        ap = wave_sum(ap);
+        if (lane == 0) s_red[wv] = (wv == 0) ? ap : 0.0;
+    }
     if (!first) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -473,8 +523,19 @@ k_lz_orth(const double* __restrict__ Ppart, int nt, int npad, const double* __re
     }
     __syncthreads();
     // ---- coefficients: s_q[j], j < k, over V_{k-1}; s_q[k] = coefficient of v_k
-    const double alpha = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) * INV_SQRT2 * binv * binv;
-    const double wi = ((s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane])) * (INV_SQRT2 * binv);
+    double alpha, wi;
+    if constexpr (NCHP == 0) {
+        alpha = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) * INV_SQRT2 * binv * binv;
+        wi = ((s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane])) * (INV_SQRT2 * binv);
+    } else {
+        // v'Av = t' Lam t + v'Ev;   u = Lam t for the row-wise rebuild below
+        double tl = 0.0;
+        for (int c = lane; c < fo.rp; c += WAVE) { const double tc = s_t[c]; tl += fo.lam[c] * tc * tc; }
+        tl = wave_sum(tl);
+        alpha = (tl + s_red[0]) * binv * binv;
+        wi = eb * binv;                              // + Vp u / beta, folded into the exchange below
+        for (int c = threadIdx.x; c < 4 * NCP; c += TPB) s_u[c] = (c < fo.rp) ? fo.lam[c] * s_t[c] : 0.0;
+    }
     double ck = alpha;
     const int j = threadIdx.x;
     if (first) {
@@ -510,7 +571,17 @@ k_lz_orth(const double* __restrict__ Ppart, int nt, int npad, const double* __re
         if (j0 <= k) d0 += vr[c] * s_q[j0];
         if (j1 <= k) d1 += vr[c + 1] * s_q[j1];
     }
-    s_acc[wv][lane] = d0 + d1;                        // (all reads of s_acc for wi precede the barrier above)
+    double dsub = d0 + d1;
+    if constexpr (NCHP > 0) {                         // (A v)_i = e_i + sum_c Vp[i,c] u_c
+        double u0 = 0.0, u1 = 0.0;
+#pragma unroll
+        for (int c = 0; c < NCP; c += 2) {
+            u0 += vrp[c] * s_u[wv + 4 * c];           // s_u = 0 beyond rp
+            u1 += vrp[c + 1] * s_u[wv + 4 * (c + 1)];
+        }
+        dsub -= (u0 + u1) * binv;
+    }
+    s_acc[wv][lane] = dsub;                           // (all reads of s_acc for wi precede the barrier above)
     __syncthreads();
     const double wp = wi - ((s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane]));
     if (wv == 0) {
@@ -610,6 +681,101 @@ k_symv_finish(const double* __restrict__ xp, int n, int nt, int npad, double* __
                        s_a, s_b, &s_beta);
     else
         symv_tiles(xp, n, npad, nt * (nt + 1) / 2, wbuf, Ppart, (int)blockIdx.x - nt, (int)gridDim.x - nt, s_a, s_b, Apart);
+}
+
+// ---------------------------------------------------------------------------
+// Operator-form mat-vec.  On the support path the matrix handed to the projection is
+//     X = x_prev - tau (M'y + c)   with  x_prev = Vp Lam Vp'  (the previous projection, rank rp)
+// and the update supported on S (Max-Cut n = 4000: 32 000 of 8.0e6 entries).  So
+//     A v = Vp (Lam (Vp' v)) + E v,      E = smat of the update, sparse symmetric,
+// costs 16 n rp + O(|S|) bytes instead of the 8 N bytes of the packed triangle (64 MB -> 2 MB),
+// and needs no tile kernel: the row-local pieces (Vp'v partials, E v, v'Ev partials) are produced
+// by the workgroups below, the global sums are taken by k_lz_orth<., NCHP>.  The dense iterate
+// is still written by the reconstruction (residuals, M x), only the Lanczos operator changes.
+// E is kept in ELL form per PSD block: entry k of row i at [k*npad + i]: column, index into the
+// support-value array (-1 = padding); off-diagonal values carry the svec sqrt(2).
+// ---------------------------------------------------------------------------
+template <int NCHP>
+__device__ __forceinline__ void fop_body(const double* __restrict__ v, const double* __restrict__ Vp, int ldv, int rp,
+                                         const int* __restrict__ ell_col, const int* __restrict__ ell_sidx, int ell_w,
+                                         int npad, const double* __restrict__ esv, double* __restrict__ tpart, int pld,
+                                         double* __restrict__ ebuf, double* __restrict__ apart, int g,
+                                         double* __restrict__ s_e /* NWAVE*64 */) {
+    constexpr int NCP = 16 * NCHP;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i = g * LZ_ROWS + lane;
+    const double vi = v[i];
+    double vrp[NCP];
+#pragma unroll
+    for (int c = 0; c < NCP; ++c) vrp[c] = Vp[(long long)min(wv + 4 * c, max(rp - 1, 0)) * ldv + i];
+    // E v: the waves split the ELL entries of the row
+    double e = 0.0;
+    for (int k0 = wv; k0 < ell_w; k0 += 4 * NWAVE) {
+        int col[4], sx[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = min(k0 + u * NWAVE, ell_w - 1);
+            col[u] = ell_col[(long long)k * npad + i];
+            sx[u] = (k0 + u * NWAVE < ell_w) ? ell_sidx[(long long)k * npad + i] : -1;
+        }
+        double ev[4], xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { ev[u] = esv[max(sx[u], 0)]; xv[u] = v[col[u]]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (sx[u] >= 0) e += ((col[u] == i) ? ev[u] : ev[u] * INV_SQRT2) * xv[u];
+    }
+    s_e[wv * LZ_ROWS + lane] = e;
+    // Vp' v partials of this workgroup's rows
+#pragma unroll
+    for (int ch = 0; ch < NCHP; ++ch) {
+        double t[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) t[c] = vrp[16 * ch + c] * vi;
+        const double ts = fold16_all(t, lane);
+        const int cc = wv + 4 * (16 * ch + lane);
+        if (lane < 16 && cc < rp) tpart[(long long)cc * pld + g] = ts;
+    }
+    __syncthreads();
+    if (wv == 0) {
+        const double ei = (s_e[lane] + s_e[LZ_ROWS + lane]) + (s_e[2 * LZ_ROWS + lane] + s_e[3 * LZ_ROWS + lane]);
+        ebuf[i] = ei;
+        const double a = wave_sum(vi * ei);
+        if (lane == 0) apart[g] = a;
+    }
+}
+// first mat-vec of a cycle (on the normalised v_k); grid = nt
+template <int NCHP>
+__global__ void __launch_bounds__(TPB)
+k_fop(const double* __restrict__ v, const double* __restrict__ Vp, int ldv, int rp,
+      const int* __restrict__ ell_col, const int* __restrict__ ell_sidx, int ell_w, int npad,
+      const double* __restrict__ esv, double* __restrict__ tpart, int pld, double* __restrict__ ebuf,
+      double* __restrict__ apart, const LanczosCtl* __restrict__ ctl) {
+    if (ctl != nullptr && ctl->stop) return;
+    __shared__ double s_e[NWAVE * LZ_ROWS];
+    fop_body<NCHP>(v, Vp, ldv, rp, ell_col, ell_sidx, ell_w, npad, esv, tpart, pld, ebuf, apart, blockIdx.x, s_e);
+}
+// closing work of step k (workgroups [0, nt)) + operator rows of step k+1 on w' ([nt, 2 nt))
+template <int NCHP>
+__global__ void __launch_bounds__(TPB)
+k_fop_finish(const double* __restrict__ wbuf, double* __restrict__ V, int ldv, int k,
+             const double* __restrict__ hpart_in, int pld, const double* __restrict__ h1,
+             double* __restrict__ alphas, double* __restrict__ betas, LanczosCtl* __restrict__ ctl, double tol,
+             int use_carry, int nt, const double* __restrict__ Vp, int rp,
+             const int* __restrict__ ell_col, const int* __restrict__ ell_sidx, int ell_w, int npad,
+             const double* __restrict__ esv, double* __restrict__ tpart, double* __restrict__ ebuf,
+             double* __restrict__ apart) {
+    if (ctl->stop) return;
+    __shared__ double s_a[2 * NWAVE * TILE];
+    __shared__ double s_b[NWAVE * LZ_ROWS];
+    __shared__ double s_beta;
+    if ((int)blockIdx.x < nt)
+        lz_finish_body(wbuf, V, ldv, k, hpart_in, pld, h1, alphas, betas, ctl, tol, use_carry, blockIdx.x,
+                       s_a, s_b, &s_beta);
+    else
+        fop_body<NCHP>(wbuf, Vp, ldv, rp, ell_col, ell_sidx, ell_w, npad, esv, tpart, pld, ebuf, apart,
+                       (int)blockIdx.x - nt, s_b);
 }
 
 // out[:, c] = sum_j V[:, j] U[j, c]  (basis rotation at a thick restart and the final Ritz
@@ -951,13 +1117,20 @@ k_residual_y(const double* __restrict__ y, const double* __restrict__ yold,
 // xsave = x[S];  x[S] -= tau*(MtyS + cS)   (in place: x becomes the matrix to project)
 __global__ void __launch_bounds__(TPB)
 k_primal_update_S(double* __restrict__ x, const int* __restrict__ supp, const double* __restrict__ MtyS,
-                  const double* __restrict__ cS, double tau, double* __restrict__ xsave, int ns) {
+                  const double* __restrict__ cS, double tau, double* __restrict__ xsave, int ns,
+                  double* __restrict__ esv) {
     const int s = blockIdx.x * TPB + threadIdx.x;
     if (s >= ns) return;
     const int i = supp[s];
     const double xi = x[i];
     xsave[s] = xi;
-    x[i] = xi - tau * (MtyS[s] + cS[s]);
+    const double upd = tau * (MtyS[s] + cS[s]);
+    const double xn = xi - upd;
+    x[i] = xn;
+    // support values of E for the operator-form mat-vec: [0, ns) the update itself (x_prev held
+    // in factored form), [ns, 2 ns) the whole entry (x_prev without factors, zero off the support)
+    esv[s] = -upd;
+    esv[ns + s] = xn;
 }
 
 struct TrialBatch {                 // up to 4 linesearch candidates per launch

@@ -33,11 +33,23 @@ inline void Solver::project_block(int idx, const double* xin, double* xout, bool
     current_rank[idx] = 0;
     const bool krylov = !opt.full_eig_decomp && target_rank[idx] <= opt.max_target_rank_krylov_eigs &&
                         W.n > opt.min_size_krylov_eigs && (iter % opt.full_eig_freq) > opt.full_eig_len;
-    if (!krylov) { full_eig_project(idx, xp, xo, fuse); return; }
+    // operator-form mat-vec: legal when this block's x_prev is known in factored form (or is
+    // zero off the support) and the update is the sparse support update of this iteration
+    W.use_fop = fuse && use_support && opt.lanczos_operator != 0 && W.fop_ok && krylov &&
+                (W.have_factors || W.x_prev_sparse);
+    if (W.use_fop) {
+        if (!W.have_factors) { W.F_r = 0; W.F_first = 0; }
+        W.esv = esv_d.p + (W.have_factors ? 0 : ns);
+    }
+    const bool used_fop = W.use_fop;
+    if (!krylov) { W.have_factors = false; W.x_prev_sparse = false; W.use_fop = false; full_eig_project(idx, xp, xo, fuse); return; }
     const int nev = (int)target_rank[idx];
     lanczos(W, xp, nev);
+    W.use_fop = false;
+    if (used_fop) st.fop_projections++;
     if (!W.converged) {                       // prox_operators.jl:55-57
         st.krylov_fallbacks++;
+        W.have_factors = false; W.x_prev_sparse = false;
         full_eig_project(idx, xp, xo, fuse);
         return;
     }
@@ -57,6 +69,12 @@ inline void Solver::project_block(int idx, const double* xin, double* xout, bool
     launch_reconstruct(W, W.Z.p + (size_t)first * W.npad, W.npad, W.lam.p, npos, xo,
                        fuse ? xp : nullptr, fuse ? idx : -1);
     recon_r_iter += npos;
+    if (W.fop_ok) {                           // x_new = Z[:, first..] diag(lam) Z': keep the factors
+        std::swap(W.Z.p, W.F.p);
+        W.F_first = first; W.F_r = npos;
+        if (npos > 0) PX_HIP(hipMemcpyAsync(W.Flam.p, W.lam.p, (size_t)npos * 8, hipMemcpyDeviceToDevice, stream));
+        W.have_factors = true; W.x_prev_sparse = false;
+    }
 }
 
 inline void Solver::psd_projection(double* x) {
@@ -78,7 +96,7 @@ inline void Solver::primal_step_dev() {
         double* xcur = xbuf[xc].p;
         double* xnew = xbuf[1 - xc].p;
         hipLaunchKernelGGL(dev::k_primal_update_S, dim3(ceil_div(std::max(ns, 1), dev::TPB)), dim3(dev::TPB), 0, stream,
-                           xcur, supp_d.p, MtyS_cur.p, cS_d.p, primal_step, xsave_d.p, ns);
+                           xcur, supp_d.p, MtyS_cur.p, cS_d.p, primal_step, xsave_d.p, ns, esv_d.p);
         std::fill(min_eig.begin(), min_eig.end(), 0.0);
         double t0 = now_s();
         for (size_t idx = 0; idx < P.blocks.size(); ++idx) project_block((int)idx, xcur, xnew, true);
@@ -551,6 +569,51 @@ inline void Solver::setup_support() {
     bpart.alloc((size_t)4 * 11 * PSTRIDE); bpart.zero(stream);
     bscal.alloc(64); bscal.zero(stream);
     hbscal.assign(64, 0.0);
+    // operator-form mat-vec: the support update as a symmetric sparse matrix per block (ELL)
+    esv_d.alloc((size_t)2 * std::max(ns, 1)); esv_d.zero(stream);
+    if (opt.lanczos_operator != 0) {
+        size_t s0 = 0;
+        for (size_t idx = 0; idx < P.blocks.size(); ++idx) {
+            const BlockInfo& B = P.blocks[idx];
+            EigWork& W = eig[idx];
+            size_t s1 = s0;
+            while (s1 < supp.size() && supp[s1] < B.off + B.N) ++s1;     // supp is ascending
+            if (B.n < 2 || W.npad == 0) { s0 = s1; continue; }
+            std::vector<int> cnt(W.npad, 0);
+            std::vector<std::array<int, 3>> ent;                 // row, col, s
+            ent.reserve(2 * (s1 - s0));
+            for (size_t sidx = s0; sidx < s1; ++sidx) {
+                const int64_t k = supp[sidx] - B.off;
+                int64_t j = (int64_t)((std::sqrt(8.0 * (double)k + 1.0) - 1.0) / 2.0);
+                while ((j + 1) * (j + 2) / 2 <= k) ++j;
+                while (j * (j + 1) / 2 > k) --j;
+                const int i = (int)(k - j * (j + 1) / 2);
+                ent.push_back({i, (int)j, (int)sidx}); cnt[i]++;
+                if (i != (int)j) { ent.push_back({(int)j, i, (int)sidx}); cnt[j]++; }
+            }
+            s0 = s1;
+            int w = 1;
+            for (int c : cnt) w = std::max(w, c);
+            if (w > 64) continue;                                 // a hub row: keep the packed mat-vec
+            std::vector<int> col((size_t)w * W.npad), sx((size_t)w * W.npad, -1);
+            for (int k = 0; k < w; ++k) for (int i = 0; i < W.npad; ++i) col[(size_t)k * W.npad + i] = i;
+            std::fill(cnt.begin(), cnt.end(), 0);
+            for (const auto& e : ent) {
+                const size_t at = (size_t)cnt[e[0]]++ * W.npad + e[0];
+                col[at] = e[1]; sx[at] = e[2];
+            }
+            W.ell_w = w;
+            W.ell_col.alloc(col.size()); W.ell_sidx.alloc(sx.size());
+            W.ell_col.upload(col.data(), col.size(), stream); W.ell_sidx.upload(sx.data(), sx.size(), stream);
+            W.F.alloc((size_t)W.npad * W.cap); W.F.zero(stream);
+            W.Flam.alloc(dev::MAXK); W.Flam.zero(stream);
+            W.tpart.alloc((size_t)dev::MAXK * W.pld); W.tpart.zero(stream);
+            W.ebuf.alloc(W.npad); W.ebuf.zero(stream);
+            W.apartf.alloc(W.pld); W.apartf.zero(stream);
+            PX_HIP(hipStreamSynchronize(stream));                 // host vectors go out of scope
+            W.fop_ok = true;
+        }
+    }
     PX_HIP(hipStreamSynchronize(stream));
     use_support = true;
 }

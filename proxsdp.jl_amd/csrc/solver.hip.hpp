@@ -9,6 +9,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <array>
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 
@@ -138,6 +139,15 @@ struct EigWork {
     std::vector<double> vals;
     int count = 0, converged_eigs = 0, numiter = 0, prev_numiter = 1;
     bool converged = false;
+    // operator-form mat-vec (kernels.hip.hpp "Operator-form mat-vec")
+    DevBuf<double> F, Flam, tpart, ebuf, apartf;   // F: npad x cap, the previous projection's Ritz vectors (swapped with Z)
+    DevBuf<int> ell_col, ell_sidx;                 // E in ELL form, [k * npad + row]
+    int ell_w = 0, F_first = 0, F_r = 0;
+    bool fop_ok = false;                           // structures built (support path, narrow rows)
+    bool have_factors = false;                     // x_prev of this block is F[:, F_first .. +F_r) diag(Flam) F'
+    bool x_prev_sparse = true;                     // x_prev is zero off the support (initial iterate)
+    bool use_fop = false;                          // the projection in progress uses the operator form
+    const double* esv = nullptr;                   // support values of E for the projection in progress
 };
 
 struct EigEvents {                  // optional profiling of the dominant kernel
@@ -275,6 +285,7 @@ private:
     DevBuf<int> supp_d;
     DevBuf<unsigned> mask_d;
     DevBuf<double> cS_d, xsave_d, MtyS_cur, MtyS_cand, ycand_d, respart_d, bpart, bscal;
+    DevBuf<double> esv_d;            // [2][ns]: support values of E (update only | whole entry), k_primal_update_S
     // dense constraint matrix (proxsdp_problem.M_dense): borrowed device pointer or own upload
     const double* Md = nullptr;
     DevBuf<double> Md_own, dmv_part, Mtycand_d;
@@ -372,6 +383,14 @@ inline void Solver::start_rocsolver_warmup() {
 }
 
 // ------------------------------------------------------------------ kernels launch helpers
+// launch helper: profiled launches carry their own start/stop events (the dispatch's
+// timestamps, i.e. the kernel alone, as rocprofv3 reports it)
+template <typename K, typename... Args>
+static inline void launch_prof(bool prof, hipEvent_t e0, hipEvent_t e1, K kern, dim3 grid, hipStream_t stream, Args... args) {
+    if (prof) hipExtLaunchKernelGGL(kern, grid, dim3(dev::TPB), 0, stream, e0, e1, 0, args...);
+    else hipLaunchKernelGGL(kern, grid, dim3(dev::TPB), 0, stream, args...);
+}
+
 inline void Solver::launch_symv(EigWork& W, const double* xp, const double* v, bool use_ctl) {
     const int ntile = 8 * ceil_div(W.nt * (W.nt + 1) / 2, 8);     // one workgroup per 64x64 tile, padded to 8 XCDs
     bool prof = opt.profile_symv_every > 0 && (st.symv_launches % opt.profile_symv_every) == 0;
@@ -386,12 +405,17 @@ inline void Solver::launch_symv(EigWork& W, const double* xp, const double* v, b
     }
     // profiled launches carry their own start/stop events (the dispatch's timestamps, i.e. the
     // kernel alone, as rocprofv3 reports it -- not the gaps to the neighbouring launches)
-    if (prof)
-        hipExtLaunchKernelGGL(dev::k_symv_packed, dim3(ntile), dim3(dev::TPB), 0, stream, ev.e0[slot], ev.e1[slot], 0,
-                              xp, W.n, W.nt, W.npad, v, W.Ppart.p, use_ctl ? W.ctl_p : nullptr, W.Apart.p);
-    else
-    hipLaunchKernelGGL(dev::k_symv_packed, dim3(ntile), dim3(dev::TPB), 0, stream,
-                       xp, W.n, W.nt, W.npad, v, W.Ppart.p, use_ctl ? W.ctl_p : nullptr, W.Apart.p);
+    hipEvent_t e0 = prof ? ev.e0[slot] : nullptr, e1 = prof ? ev.e1[slot] : nullptr;
+    if (W.use_fop) {
+        auto kern = (W.F_r <= 64) ? dev::k_fop<1> : dev::k_fop<2>;
+        launch_prof(prof, e0, e1, kern, dim3(W.nt), stream,
+                    v, (const double*)(W.F.p + (size_t)W.F_first * W.npad), W.npad, W.F_r,
+                    (const int*)W.ell_col.p, (const int*)W.ell_sidx.p, W.ell_w, W.npad, W.esv, W.tpart.p, W.pld,
+                    W.ebuf.p, W.apartf.p, (const dev::LanczosCtl*)(use_ctl ? W.ctl_p : nullptr));
+    } else {
+        launch_prof(prof, e0, e1, dev::k_symv_packed, dim3(ntile), stream,
+                    xp, W.n, W.nt, W.npad, v, W.Ppart.p, (const dev::LanczosCtl*)(use_ctl ? W.ctl_p : nullptr), W.Apart.p);
+    }
     st.symv_launches++;
     st.symv_bytes += 8.0 * (double)W.N + 16.0 * (double)W.n;
 }
@@ -414,14 +438,21 @@ inline void Solver::launch_symv_finish(EigWork& W, const double* xp, int kclose,
         }
         slot = ev.used++;
     }
-    if (prof)
-        hipExtLaunchKernelGGL(dev::k_symv_finish, dim3(W.nt + ntile), dim3(dev::TPB), 0, stream, ev.e0[slot], ev.e1[slot], 0,
-                              xp, W.n, W.nt, W.npad, W.Ppart.p, W.w.p, W.V.p, W.npad, kclose, lz_hpart(W, kclose), W.pld,
-                              W.hsum1.p, W.alphas_p, W.betas_p, W.ctl_p, tol, use_carry ? 1 : 0, W.Apart.p);
-    else
-    hipLaunchKernelGGL(dev::k_symv_finish, dim3(W.nt + ntile), dim3(dev::TPB), 0, stream,
-                       xp, W.n, W.nt, W.npad, W.Ppart.p, W.w.p, W.V.p, W.npad, kclose, lz_hpart(W, kclose), W.pld,
-                       W.hsum1.p, W.alphas_p, W.betas_p, W.ctl_p, tol, use_carry ? 1 : 0, W.Apart.p);
+    hipEvent_t e0 = prof ? ev.e0[slot] : nullptr, e1 = prof ? ev.e1[slot] : nullptr;
+    if (W.use_fop) {
+        auto kern = (W.F_r <= 64) ? dev::k_fop_finish<1> : dev::k_fop_finish<2>;
+        launch_prof(prof, e0, e1, kern, dim3(2 * W.nt), stream,
+                    (const double*)W.w.p, W.V.p, W.npad, kclose, (const double*)lz_hpart(W, kclose), W.pld,
+                    (const double*)W.hsum1.p, W.alphas_p, W.betas_p, W.ctl_p, tol, use_carry ? 1 : 0, W.nt,
+                    (const double*)(W.F.p + (size_t)W.F_first * W.npad), W.F_r,
+                    (const int*)W.ell_col.p, (const int*)W.ell_sidx.p, W.ell_w, W.npad, W.esv, W.tpart.p, W.ebuf.p,
+                    W.apartf.p);
+    } else {
+        launch_prof(prof, e0, e1, dev::k_symv_finish, dim3(W.nt + ntile), stream,
+                    xp, W.n, W.nt, W.npad, W.Ppart.p, (const double*)W.w.p, W.V.p, W.npad, kclose,
+                    (const double*)lz_hpart(W, kclose), W.pld, (const double*)W.hsum1.p, W.alphas_p, W.betas_p, W.ctl_p,
+                    tol, use_carry ? 1 : 0, W.Apart.p);
+    }
     st.symv_launches++;
     st.symv_bytes += 8.0 * (double)W.N + 16.0 * (double)W.n;
 }
@@ -505,11 +536,32 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev) {
             // recurrence, predicted correction and the measured full pass in one launch;
             // the partial-dot buffers alternate by step parity (read k-1, write k)
             double* hp[2] = {W.hpart1.p, W.hpart2.p};
-            auto orth = (k + 1 <= 64) ? dev::k_lz_orth<1> : (k + 1 <= 128) ? dev::k_lz_orth<2> : dev::k_lz_orth<3>;
-            hipLaunchKernelGGL(orth, dim3(W.nt), dim3(dev::TPB), 0, stream,
-                               W.Ppart.p, W.nt, W.npad, W.V.p, W.npad, k, W.w.p, hp[(k + 1) & 1], hp[k & 1], W.pld,
-                               W.hsum1.p, W.ctl_p, W.alphas_p, W.betas_p, W.Apart.p, W.napart,
-                               k == kfirst ? 1 : 0, W.arrow.p, kfirst);
+            dev::FopArgs fo{};
+            if (W.use_fop) {
+                fo.Vp = W.F.p + (size_t)W.F_first * W.npad; fo.lam = W.Flam.p; fo.rp = W.F_r;
+                fo.tpart = W.tpart.p; fo.ebuf = W.ebuf.p; fo.apart = W.apartf.p;
+            }
+            const int nch = (k + 1 <= 64) ? 1 : (k + 1 <= 128) ? 2 : 3;
+            const int nchp = !W.use_fop ? 0 : (W.F_r <= 64 ? 1 : 2);
+            auto launch_orth = [&](auto kern) {
+                hipLaunchKernelGGL(kern, dim3(W.nt), dim3(dev::TPB), 0, stream,
+                                   (const double*)W.Ppart.p, W.nt, W.npad, (const double*)W.V.p, W.npad, k, W.w.p,
+                                   (const double*)hp[(k + 1) & 1], hp[k & 1], W.pld, W.hsum1.p,
+                                   (const dev::LanczosCtl*)W.ctl_p, (const double*)W.alphas_p, (const double*)W.betas_p,
+                                   (const double*)W.Apart.p, W.napart, k == kfirst ? 1 : 0, (const double*)W.arrow.p,
+                                   kfirst, fo);
+            };
+            switch (nch * 3 + nchp) {
+                case 3: launch_orth(dev::k_lz_orth<1, 0>); break;
+                case 4: launch_orth(dev::k_lz_orth<1, 1>); break;
+                case 5: launch_orth(dev::k_lz_orth<1, 2>); break;
+                case 6: launch_orth(dev::k_lz_orth<2, 0>); break;
+                case 7: launch_orth(dev::k_lz_orth<2, 1>); break;
+                case 8: launch_orth(dev::k_lz_orth<2, 2>); break;
+                case 9: launch_orth(dev::k_lz_orth<3, 0>); break;
+                case 10: launch_orth(dev::k_lz_orth<3, 1>); break;
+                default: launch_orth(dev::k_lz_orth<3, 2>); break;
+            }
         }
         hipLaunchKernelGGL(dev::k_lz_finish, dim3(W.nt), dim3(dev::TPB), 0, stream,
                            W.w.p, W.n, W.V.p, W.npad, krylovdim - 1, lz_hpart(W, krylovdim - 1), W.pld, W.hsum1.p,

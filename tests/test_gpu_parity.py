@@ -398,6 +398,62 @@ def test_support_and_dense_paths_agree_on_maxcut():
     assert abs(a.objval - b.objval) <= 1e-3 * (1 + abs(a.objval))
 
 
+@pytest.mark.parametrize("case", ["maxcut", "two_blocks", "periodic_full_eig"])
+def test_operator_form_matvec_matches_packed_matvec(case):
+    """lanczos_operator=1 (A v = Vp Lam Vp' v + E v from the previous projection's factors and the
+    sparse support update) against lanczos_operator=0 (the packed triangle, what dsymv('U')
+    reads) and against the oracle: same linesearch decisions, same mat-vec counts, iterates equal
+    to rounding until the first Lanczos restart, same optimum.  'periodic_full_eig' interleaves
+    full_eig! iterations (full_eig_freq/len), after which no factors exist and the packed
+    mat-vec must take over for one iteration."""
+    kw = dict(max_iter=160, support_path=1)
+    if case == "maxcut":
+        pr = P.maxcut(300, seed=2)
+    elif case == "two_blocks":
+        pr = P.block_diag_problems([P.maxcut(180, seed=1), P.maxcut(130, seed=4)])
+    else:
+        pr = P.maxcut(220, seed=3)
+        kw.update(full_eig_freq=12, full_eig_len=1)
+    sols = [Optimizer(lanczos_operator=op, **kw).optimize(pr, trace_capacity=160) for op in (0, 1)]
+    a, b = sols
+    assert a.iter == b.iter == 160
+    assert a.stats["fop_projections"] == 0 and b.stats["fop_projections"] > 0
+    nblk = len(pr.psd)
+    if case == "periodic_full_eig":
+        assert 0 < b.stats["full_eigs"] and b.stats["fop_projections"] < b.stats["lanczos_calls"]
+    else:
+        assert b.stats["fop_projections"] == b.stats["lanczos_calls"] == 160 * nblk
+    assert np.array_equal(a.trace[:, 11], b.trace[:, 11])                 # linesearch trials
+    mv = a.trace[:, 13]
+    tight = max(3, int(np.argmax(mv > 25 * nblk)) if np.any(mv > 25 * nblk) else 160)
+    assert np.array_equal(a.trace[:tight, 13], b.trace[:tight, 13])       # mat-vecs per iteration
+    for col in (1, 2, 3, 4, 5, 6, 7, 9):
+        assert np.allclose(a.trace[:tight, col], b.trace[:tight, col], rtol=1e-9, atol=1e-12), col
+    assert abs(a.objval - b.objval) <= 1e-3 * (1 + abs(a.objval))
+    if case == "maxcut":
+        o = Options()
+        o.max_iter = 160
+        ref = oracle.solve(pr, o, trace=True)
+        G = _trace_cols(ref.trace)
+        assert np.allclose(b.trace[:tight, [1, 2, 3, 4, 7, 11]], G[:tight], rtol=1e-7, atol=1e-10)
+
+
+def test_operator_form_converges_to_the_same_optimum():
+    """Full solves (tol 1e-4) of a Max-Cut instance with both operators: same status, objectives
+    within the solver's own gap measure, iterate feasible by the solver's own criterion
+    (residuals.jl:2-35) and PSD."""
+    pr = P.maxcut(400, seed=7)
+    kw = dict(tol_gap=1e-4, tol_feasibility=1e-4, support_path=1)
+    a = Optimizer(lanczos_operator=0, **kw).optimize(pr)
+    b = Optimizer(lanczos_operator=1, **kw).optimize(pr)
+    assert a.status == b.status == 1
+    assert abs(a.objval - b.objval) <= 2e-4 * (1 + abs(a.objval))
+    assert abs(a.iter - b.iter) <= 0.25 * a.iter
+    assert b.stats["fop_projections"] == b.stats["lanczos_calls"] and b.stats["full_eigs"] == 0
+    X = P.unpack_psd(b.primal, 400)
+    assert np.abs(np.diag(X) - 1).max() <= 1e-4 * (1 + np.sqrt(400.0)) and np.linalg.eigvalsh(X).min() >= -1e-6
+
+
 def _trace_cols(ref_trace):
     return np.array([[t["prim_obj"], t["dual_obj"], t["gap"], t["feas"], t["primal_step"], t["trials"]]
                      for t in ref_trace])
