@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline sample budget")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-packed-leg", action="store_true",
+                    help="skip the extra window with lanczos_operator=0 (packed-triangle mat-vec)")
+    ap.add_argument("--lanczos-operator", type=int, default=-1, help="-1 auto (operator form), 0 packed triangle")
     ap.add_argument("--no-time-to-tol", action="store_true",
                     help="skip the full solve to tol 1e-4 (time_to_tol object)")
     ap.add_argument("--krylov-rank", type=int, default=64,
@@ -91,7 +94,7 @@ def main():
         torch.cuda.synchronize()
 
     opt = Optimizer(max_iter=W + K, device_id=dev_id, profile_symv_every=args.profile_every,
-                    support_path=args.support_path)
+                    support_path=args.support_path, lanczos_operator=args.lanczos_operator)
     sync()
     t0 = time.time()
     sol = opt.optimize(pr, trace_capacity=W + K)
@@ -106,14 +109,35 @@ def main():
     value = total_steps / t_steps
 
     st = sol.stats
-    symv_ms = st["symv_profiled_ms"] / max(1, st["symv_profiled"])
     symv_bytes = 8.0 * N + 16.0 * n                       # algorithmic bytes of one mat-vec
-    achieved = symv_bytes / (symv_ms * 1e-3) / 1e9 if symv_ms > 0 else 0.0
-    # HBM traffic per launch from PMC counters: bench.py cannot run rocprofv3 on itself (and
-    # `rocprofv3 --pmc` segfaults on the full solve in this image), so the figure is the one
-    # measured on the isolated kernel at n = 4000 with separate --pmc FETCH_SIZE / WRITE_SIZE
-    # passes and the gfx950 x2 FETCH correction: profiles/r01_pmc_fetch_write_symv.md
-    traffic = (2 * 31492.7 + 1984.5) * 1024 if n == 4000 else None
+
+    def matvec_roofline(stats, packed):
+        """roofline object of the Lanczos mat-vec launches of one solve.  `achieved` is the
+        ALGORITHMIC figure of SURVEY section 8d (the 8N+16n bytes the reference's dsymv('U')
+        reads per mat-vec) over the mean launch duration (kernel-only HIP events on the solve
+        stream, every --profile-every-th launch).  HBM traffic from PMC counters cannot be
+        taken by bench.py itself (and `rocprofv3 --pmc` segfaults on n = 4000 solves in this
+        image): the figures are from separate --pmc FETCH_SIZE / WRITE_SIZE passes, see
+        traffic_source."""
+        ms = stats["symv_profiled_ms"] / max(1, stats["symv_profiled"])
+        ach = symv_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+             "bytes_per_launch": symv_bytes, "avg_launch_ms": ms, "launches_profiled": int(stats["symv_profiled"]),
+             "launches": int(stats["symv_launches"])}
+        if packed:
+            r["kernel"] = "k_symv_finish / k_symv_packed (tiles of the packed triangle)"
+            r["traffic"] = (2 * 31492.7 + 1984.5) * 1024 if n == 4000 else None
+            r["traffic_source"] = "profiles/r01_pmc_fetch_write_symv.md (2*FETCH_SIZE + WRITE_SIZE, isolated kernel)"
+        else:
+            r["kernel"] = "k_fop_finish / k_fop (operator-form mat-vec: previous factors + sparse update)"
+            r["traffic"] = None
+            r["traffic_source"] = ("operator form reads ~16 n r + O(|S|) bytes instead of the triangle, so the algorithmic "
+                                   "figure can exceed the HBM peak; PMC at n = 2000: 2*FETCH_SIZE = 1.5 MB per launch vs "
+                                   "16.0 MB algorithmic (profiles/r01_pmc_operator_form.md)")
+        return r
+
+    roof = matvec_roofline(st, packed=st["fop_projections"] == 0)
+    roof["loop_algorithmic_GBs"] = st["algorithmic_bytes"] / max(st["loop_time"], 1e-9) / 1e9
     mv_timed = float(tr[W:W + K, 13].sum())
     trials_timed = float(tr[W:W + K, 11].sum())
     out = {
@@ -127,14 +151,20 @@ def main():
                    "timed_iterations": [W + 1, W + K],
                    "lanczos_matvecs_per_step": mv_timed / K, "linesearch_trials_per_step": trials_timed / K,
                    "target_rank": int(tr[W + K - 1, 10])},
-        "roofline": {"bound": "hbm", "kernel": "k_symv_finish / k_symv_packed (packed symmetric mat-vec tiles)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_source": "profiles/r01_pmc_fetch_write_symv.md (2*FETCH_SIZE + WRITE_SIZE, isolated kernel)",
-                     "bytes_per_launch": symv_bytes, "avg_launch_ms": symv_ms,
-                     "launches_profiled": int(st["symv_profiled"]), "launches": int(st["symv_launches"]),
-                     "loop_algorithmic_GBs": st["algorithmic_bytes"] / max(st["loop_time"], 1e-9) / 1e9},
+        "roofline": roof,
         "solve_wall_s": wall, "init_s": st["init_time"], "exit_s": st["exit_time"],
     }
+
+    if rank == 0 and world == 1 and st["fop_projections"] > 0 and not args.no_packed_leg:
+        # the same window with the reference's operator: every mat-vec streams the packed triangle
+        # (HBM-bound tile kernel); kept beside the headline so the kernel-level roofline stays visible
+        o1 = Optimizer(max_iter=W + K, device_id=dev_id, profile_symv_every=args.profile_every,
+                       support_path=args.support_path, lanczos_operator=0)
+        s1 = o1.optimize(pr, trace_capacity=W + K)
+        t1 = float(s1.trace[W + K - 1, 12] - (s1.trace[W - 1, 12] if W > 0 else 0.0))
+        out["packed_operator"] = {"value": K / t1, "unit": "iterations/s", "ms_per_step": 1e3 * t1 / K,
+                                  "options": {"lanczos_operator": 0},
+                                  "roofline": matvec_roofline(s1.stats, packed=True)}
 
     if rank == 0 and world == 1 and not args.no_time_to_tol:
         # second half of the metric: wall time to status OPTIMAL at tol_gap = tol_feasibility = 1e-4.

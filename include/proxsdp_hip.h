@@ -198,6 +198,7 @@ typedef struct proxsdp_stats {
     int64_t dense_passes;        /* passes over a dense A (A x or batched A' y), 8*p*n bytes each */
     double  dense_ms;            /* their summed durations (HIP events on the solve stream)    */
     int64_t fop_projections;     /* projections whose Lanczos mat-vecs ran in operator form     */
+    int64_t exit_matvecs;        /* mat-vecs of the exit path's lambda_min(dual cone) Lanczos   */
 } proxsdp_stats;
 
 /* Result (structs.jl:60-81).  Arrays are caller-allocated with the stated

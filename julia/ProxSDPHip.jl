@@ -75,6 +75,7 @@ struct Stats                     # proxsdp_stats
     dense_passes::Int64
     dense_ms::Float64
     fop_projections::Int64
+    exit_matvecs::Int64
 end
 
 mutable struct CResult           # proxsdp_result

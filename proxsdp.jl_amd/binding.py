@@ -114,7 +114,7 @@ class Stats(C.Structure):
                 ("symv_launches", i64), ("symv_profiled", i64), ("symv_profiled_ms", f64),
                 ("symv_bytes", f64), ("algorithmic_bytes", f64), ("init_time", f64),
                 ("loop_time", f64), ("exit_time", f64), ("t_primal", f64), ("t_psd", f64),
-                ("t_linesearch", f64), ("t_residual", f64), ("dense_passes", i64), ("dense_ms", f64), ("fop_projections", i64)]
+                ("t_linesearch", f64), ("t_residual", f64), ("dense_passes", i64), ("dense_ms", f64), ("fop_projections", i64), ("exit_matvecs", i64)]
 
 
 class Result(C.Structure):

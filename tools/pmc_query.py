@@ -8,5 +8,5 @@ for f in glob.glob(sys.argv[1] + "/**/*.db", recursive=True):
         print("no counters_collection view; have", tabs[:12]); continue
     cols = [r[1] for r in c.execute("pragma table_info(counters_collection)")]
     kn = "kernel_name" if "kernel_name" in cols else [x for x in cols if "name" in x][0]
-    q = f"select substr({kn},1,46), counter_name, count(*), avg(value) from counters_collection group by {kn}, counter_name order by 4 desc limit 10"
+    q = f"select substr({kn},1,46), counter_name, count(*), avg(value) from counters_collection group by {kn}, counter_name order by 4 desc limit 40"
     for r in c.execute(q): print("  %-48s %-11s n=%4d avg %.1f" % r)
