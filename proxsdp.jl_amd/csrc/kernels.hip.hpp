@@ -430,7 +430,7 @@ k_lz_orth(const double* __restrict__ Ppart, int nt, int npad, const double* __re
           const double* __restrict__ alphas, const double* __restrict__ betas,
           const double* __restrict__ Apart, int napart, int first, const double* __restrict__ arrow, int keep,
           FopArgs fo) {
-    if (ctl->stop) return;
+    const int stop = ctl->stop;                      // tested after the loads below are in flight
     constexpr int NC = 16 * NCH;
     constexpr int NCP = 16 * (NCHP > 0 ? NCHP : 1);
     __shared__ double s_t[4 * NCP];
@@ -469,7 +469,21 @@ k_lz_orth(const double* __restrict__ Ppart, int nt, int npad, const double* __re
     const int gl = min(lane, pld - 1);
 #pragma unroll
     for (int c = 0; c < NC; ++c) hp[c] = hpart_prev[(long long)min(wv + 4 * c, MAXK - 1) * pld + gl];
-    const double binv = first ? 1.0 : 1.0 / betas[k - 1];
+    // coefficient data of the prediction (thread j <-> basis column j; lane-indexed copies for
+    // the two short dot products): issued with everything else, used after the first barrier
+    const int j = threadIdx.x;
+    const int jc = min(j, MAXK - 1);
+    const double al_j = alphas[jc], be_j = betas[jc], be_jm = betas[max(jc - 1, 0)];
+    const double f_j = arrow[jc], d_j = arrow[MAXK + jc];
+    const double be_km = betas[max(k - 1, 0)];
+    const double f_l0 = arrow[lane], f_l1 = arrow[lane + WAVE];
+    double lam_j = 0.0, lam_l0 = 0.0, lam_l1 = 0.0;
+    if constexpr (NCHP > 0) {
+        lam_j = fo.lam[jc]; lam_l0 = fo.lam[lane];
+        if constexpr (NCHP > 1) lam_l1 = fo.lam[lane + WAVE];
+    }
+    if (stop) return;
+    const double binv = first ? 1.0 : 1.0 / be_km;
     // ---- reductions
     if constexpr (NCHP == 0) {
 #pragma unroll
@@ -529,36 +543,37 @@ k_lz_orth(const double* __restrict__ Ppart, int nt, int npad, const double* __re
         wi = ((s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane])) * (INV_SQRT2 * binv);
     } else {
         // v'Av = t' Lam t + v'Ev;   u = Lam t for the row-wise rebuild below
-        double tl = 0.0;
-        for (int c = lane; c < fo.rp; c += WAVE) { const double tc = s_t[c]; tl += fo.lam[c] * tc * tc; }
+        double tl = (lane < fo.rp) ? lam_l0 * s_t[lane] * s_t[lane] : 0.0;
+        if constexpr (NCHP > 1) if (lane + WAVE < fo.rp) tl += lam_l1 * s_t[lane + WAVE] * s_t[lane + WAVE];
         tl = wave_sum(tl);
         alpha = (tl + s_red[0]) * binv * binv;
         wi = eb * binv;                              // + Vp u / beta, folded into the exchange below
-        for (int c = threadIdx.x; c < 4 * NCP; c += TPB) s_u[c] = (c < fo.rp) ? fo.lam[c] * s_t[c] : 0.0;
+        if (j < 4 * NCP) s_u[j] = (j < fo.rp) ? lam_j * s_t[j] : 0.0;
     }
     double ck = alpha;
-    const int j = threadIdx.x;
     if (first) {
-        if (j < keep) s_q[j] = arrow[j];
+        if (j < keep) s_q[j] = f_j;
     } else {
         ck -= s_h[k - 1];
         double fh = 0.0;
         if (keep > 0 && k > keep) {                   // f'h (row `keep` of the arrow)
-            for (int jj = lane; jj < keep; jj += WAVE) fh += arrow[jj] * s_h[jj];
+            if (lane < keep) fh = f_l0 * s_h[lane];
+            if (lane + WAVE < keep) fh += f_l1 * s_h[lane + WAVE];
+            for (int jj = lane + 2 * WAVE; jj < keep; jj += WAVE) fh += arrow[jj] * s_h[jj];
             fh = wave_sum(fh);
         }
         if (j < k) {
             const double hj = s_h[j];
             double t;
             if (j < keep) {
-                t = arrow[MAXK + j] * hj + (k > keep ? arrow[j] * s_h[keep] : 0.0);
+                t = d_j * hj + (k > keep ? f_j * s_h[keep] : 0.0);
             } else {
-                t = alphas[j] * hj;
-                if (j + 1 < k) t += betas[j] * s_h[j + 1];
+                t = al_j * hj;
+                if (j + 1 < k) t += be_j * s_h[j + 1];
                 if (j == keep) t += fh;                               // fh = 0 when keep == 0
-                else if (j > 0) t += betas[j - 1] * s_h[j - 1];
+                else if (j > 0) t += be_jm * s_h[j - 1];
             }
-            s_q[j] = t * binv + (j == k - 1 ? betas[k - 1] : 0.0);
+            s_q[j] = t * binv + (j == k - 1 ? be_km : 0.0);
         }
     }
     if (j == k) s_q[k] = ck;
@@ -700,21 +715,31 @@ __device__ __forceinline__ void fop_body(const double* __restrict__ v, const dou
                                          const int* __restrict__ ell_col, const int* __restrict__ ell_sidx, int ell_w,
                                          int npad, const double* __restrict__ esv, double* __restrict__ tpart, int pld,
                                          double* __restrict__ ebuf, double* __restrict__ apart, int g,
-                                         double* __restrict__ s_e /* NWAVE*64 */) {
+                                         double* __restrict__ s_e /* NWAVE*64 */, const LanczosCtl* __restrict__ ctl) {
     constexpr int NCP = 16 * NCHP;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = g * LZ_ROWS + lane;
+    const int stop = (ctl != nullptr) ? ctl->stop : 0;   // tested once the first loads are in flight
     const double vi = v[i];
     double vrp[NCP];
 #pragma unroll
     for (int c = 0; c < NCP; ++c) vrp[c] = Vp[(long long)min(wv + 4 * c, max(rp - 1, 0)) * ldv + i];
-    // E v: the waves split the ELL entries of the row
+    // E v: the waves split the ELL entries of the row (first 4 entries per wave prefetched)
+    int col0[4], sx0[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int k = min(wv + u * NWAVE, ell_w - 1);
+        col0[u] = ell_col[(long long)k * npad + i];
+        sx0[u] = (wv + u * NWAVE < ell_w) ? ell_sidx[(long long)k * npad + i] : -1;
+    }
+    if (stop) return;
     double e = 0.0;
     for (int k0 = wv; k0 < ell_w; k0 += 4 * NWAVE) {
         int col[4], sx[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+            if (k0 == wv) { col[u] = col0[u]; sx[u] = sx0[u]; continue; }
             const int k = min(k0 + u * NWAVE, ell_w - 1);
             col[u] = ell_col[(long long)k * npad + i];
             sx[u] = (k0 + u * NWAVE < ell_w) ? ell_sidx[(long long)k * npad + i] : -1;
@@ -752,9 +777,8 @@ k_fop(const double* __restrict__ v, const double* __restrict__ Vp, int ldv, int 
       const int* __restrict__ ell_col, const int* __restrict__ ell_sidx, int ell_w, int npad,
       const double* __restrict__ esv, double* __restrict__ tpart, int pld, double* __restrict__ ebuf,
       double* __restrict__ apart, const LanczosCtl* __restrict__ ctl) {
-    if (ctl != nullptr && ctl->stop) return;
     __shared__ double s_e[NWAVE * LZ_ROWS];
-    fop_body<NCHP>(v, Vp, ldv, rp, ell_col, ell_sidx, ell_w, npad, esv, tpart, pld, ebuf, apart, blockIdx.x, s_e);
+    fop_body<NCHP>(v, Vp, ldv, rp, ell_col, ell_sidx, ell_w, npad, esv, tpart, pld, ebuf, apart, blockIdx.x, s_e, ctl);
 }
 // closing work of step k (workgroups [0, nt)) + operator rows of step k+1 on w' ([nt, 2 nt))
 template <int NCHP>
@@ -766,16 +790,17 @@ k_fop_finish(const double* __restrict__ wbuf, double* __restrict__ V, int ldv, i
              const int* __restrict__ ell_col, const int* __restrict__ ell_sidx, int ell_w, int npad,
              const double* __restrict__ esv, double* __restrict__ tpart, double* __restrict__ ebuf,
              double* __restrict__ apart) {
-    if (ctl->stop) return;
     __shared__ double s_a[2 * NWAVE * TILE];
     __shared__ double s_b[NWAVE * LZ_ROWS];
     __shared__ double s_beta;
-    if ((int)blockIdx.x < nt)
+    if ((int)blockIdx.x < nt) {
+        if (ctl->stop) return;
         lz_finish_body(wbuf, V, ldv, k, hpart_in, pld, h1, alphas, betas, ctl, tol, use_carry, blockIdx.x,
                        s_a, s_b, &s_beta);
-    else
+    } else {
         fop_body<NCHP>(wbuf, Vp, ldv, rp, ell_col, ell_sidx, ell_w, npad, esv, tpart, pld, ebuf, apart,
-                       (int)blockIdx.x - nt, s_b);
+                       (int)blockIdx.x - nt, s_b, ctl);
+    }
 }
 
 // out[:, c] = sum_j V[:, j] U[j, c]  (basis rotation at a thick restart and the final Ritz
