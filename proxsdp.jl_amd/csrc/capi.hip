@@ -146,6 +146,7 @@ int proxsdp_hip_psd_project(const double* packed_in, int64_t n, int32_t target_r
         PX_HIP(hipStreamSynchronize(S.stream));
         if (out_rank) *out_rank = (int32_t)S.test_rank();
         if (out_min_eig) *out_min_eig = S.test_min_eig();
+        S.merge_block_stats();
         if (out_nmatvec) *out_nmatvec = S.st.lanczos_matvecs;
         if (out_converged) *out_converged = S.eig[0].converged_eigs;
         if (out_fell_back) *out_fell_back = (int32_t)S.st.krylov_fallbacks;
@@ -176,6 +177,7 @@ int proxsdp_hip_eigsolve(const double* packed, int64_t n, int32_t nev, const pro
                                hipMemcpyDeviceToHost));
         if (out_count) *out_count = W.count;
         if (out_converged) *out_converged = W.converged_eigs;
+        S.merge_block_stats();
         if (out_nmatvec) *out_nmatvec = S.st.lanczos_matvecs;
         if (out_numiter) *out_numiter = W.numiter;
         return 0;

@@ -46,9 +46,9 @@ inline void Solver::project_block(int idx, const double* xin, double* xout, bool
     const int nev = (int)target_rank[idx];
     lanczos(W, xp, nev);
     W.use_fop = false;
-    if (used_fop) st.fop_projections++;
+    if (used_fop) W.lst.fop_projections++;
     if (!W.converged) {                       // prox_operators.jl:55-57
-        st.krylov_fallbacks++;
+        W.lst.krylov_fallbacks++;
         W.have_factors = false; W.x_prev_sparse = false;
         full_eig_project(idx, xp, xo, fuse);
         return;
@@ -68,7 +68,7 @@ inline void Solver::project_block(int idx, const double* xin, double* xout, bool
     if (npos > 0) W.lam.upload(W.vals.data() + first, npos, stream);
     launch_reconstruct(W, W.Z.p + (size_t)first * W.npad, W.npad, W.lam.p, npos, xo,
                        fuse ? xp : nullptr, fuse ? idx : -1);
-    recon_r_iter += npos;
+    W.recon_r += npos;
     if (W.fop_ok) {                           // x_new = Z[:, first..] diag(lam) Z': keep the factors
         std::swap(W.Z.p, W.F.p);
         W.F_first = first; W.F_r = npos;
@@ -84,8 +84,7 @@ inline void Solver::psd_projection(double* x) {
                            x, one_off.p, (int)one_blocks.size(), one_min.p);
         for (int idx : one_blocks) current_rank[idx] = 0;
     }
-    for (size_t idx = 0; idx < P.blocks.size(); ++idx)
-        if (P.blocks[idx].n > 1) project_block((int)idx, x, x, false);
+    run_blocks(big_blocks, [this, x](int idx) { project_block(idx, x, x, false); });
 }
 
 // primal_step! (pdhg.jl:611-637)
@@ -99,7 +98,7 @@ inline void Solver::primal_step_dev() {
                            xcur, supp_d.p, MtyS_cur.p, cS_d.p, primal_step, xsave_d.p, ns, esv_d.p);
         std::fill(min_eig.begin(), min_eig.end(), 0.0);
         double t0 = now_s();
-        for (size_t idx = 0; idx < P.blocks.size(); ++idx) project_block((int)idx, xcur, xnew, true);
+        run_blocks(big_blocks, [this, xcur, xnew](int idx) { project_block(idx, xcur, xnew, true); });
         st.t_psd += now_s() - t0;
         if (P.sdplen < P.n)
             hipLaunchKernelGGL(dev::k_tail_copy_res, dim3(n_res_wg - tile_base.back()), dim3(dev::TPB), 0, stream,
@@ -305,16 +304,16 @@ inline double Solver::dual_feas_host(const std::vector<double>& y, const std::ve
                 std::vector<double> neg(dc.begin() + B.off, dc.begin() + B.off + B.N);
                 for (double& v : neg) v = -v;
                 tmp.upload(neg.data(), B.N, stream);
-                const proxsdp_stats keep_st = st;
-                const long long keep_mv = lz_matvec_iter;
+                const proxsdp_stats keep_st = W.lst;
+                const long long keep_mv = W.mv_iter;
                 const int keep_prev = W.prev_numiter, keep_num = W.numiter;
                 W.use_fop = false;
                 lanczos(W, tmp.p, 1);
                 if (W.converged && W.converged_eigs >= 1 && !W.vals.empty()) { mn = -W.vals[0]; have_mn = true; }
-                const long long mv = st.lanczos_matvecs - keep_st.lanczos_matvecs;
-                st = keep_st;                                  // exit-path work is not a projection
+                const long long mv = W.lst.lanczos_matvecs - keep_st.lanczos_matvecs;
+                W.lst = keep_st;                               // exit-path work is not a projection
                 st.exit_matvecs += mv;
-                lz_matvec_iter = keep_mv;
+                W.mv_iter = keep_mv;
                 W.prev_numiter = keep_prev; W.numiter = keep_num;
                 PX_HIP(hipStreamSynchronize(stream));          // `neg` goes out of scope
             }
@@ -876,6 +875,7 @@ inline void Solver::run() {
             const BlockInfo& B = P.blocks[idx];
             if (B.n == 1) { one_blocks.push_back((int)idx); offs.push_back(B.off); if (ur) ur += 1; continue; }
             EigWork& W = eig[idx];
+            big_blocks.push_back((int)idx);
             const int max_nev = std::min<int>(std::max<int>(opt.max_target_rank_krylov_eigs, 2), B.n);
             alloc_eigwork(W, B.n, max_nev);
             W.resid_host.resize(W.npad, 0.0);
@@ -887,6 +887,24 @@ inline void Solver::run() {
             if (!(nr > 0.0)) throw std::invalid_argument("Lanczos start vector has zero norm");
             for (int i = 0; i < B.n; ++i) W.resid_host[i] /= nr;
             W.resid.upload(W.resid_host.data(), W.npad, stream);
+        }
+        // several eigensolver-sized blocks: project them concurrently, one worker thread and one
+        // stream per block (the per-block Lanczos chains are launch-latency-bound, so they overlap
+        // almost perfectly: MIMO n=512 x 8 on one GPU).  PROXSDP_HIP_BLOCK_THREADS=0 disables.
+        {
+            const char* e = std::getenv("PROXSDP_HIP_BLOCK_THREADS");
+            int nthreads = e ? atoi(e) : 8;
+            nthreads = std::min<int>(nthreads, (int)big_blocks.size());
+            if (nthreads >= 2) {
+                for (int idx : big_blocks) {
+                    PX_HIP(hipStreamCreate(&eig[idx].stream));
+                    PX_HIP(hipEventCreateWithFlags(&eig[idx].done, hipEventDisableTiming));
+                }
+                PX_HIP(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming));
+                PX_HIP(hipStreamSynchronize(stream));           // workspace zero-fills precede any block-stream work
+                start_workers(nthreads);
+                parallel_blocks = true;
+            }
         }
         if (!offs.empty()) {
             one_off.alloc(offs.size()); one_min.alloc(offs.size());

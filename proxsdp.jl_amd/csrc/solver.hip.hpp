@@ -10,6 +10,10 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <array>
+#include <mutex>
+#include <condition_variable>
+#include <functional>
+#include <exception>
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 
@@ -116,6 +120,20 @@ struct CircularVector {
 };
 
 // ------------------------------------------------------------------ per-block Lanczos workspace
+struct EigEvents {                  // optional profiling of the dominant kernel
+    std::vector<hipEvent_t> e0, e1;
+    size_t used = 0;
+};
+
+// The solver's stream.  Block workers (one host thread per PSD block while the blocks are
+// projected concurrently) override it for their thread with the block's own stream, so every
+// launch / copy / synchronisation inside the per-block code lands on that stream.
+struct StreamRef {
+    hipStream_t main = nullptr;
+    static inline thread_local hipStream_t tl = nullptr;
+    operator hipStream_t() const { return tl ? tl : main; }
+};
+
 struct EigWork {
     int n = 0, nt = 0, npad = 0, nwg = 0, cap = 0, pld = 0;   // cap = columns of V (krylovdim_max + 1)
     int64_t N = 0;
@@ -148,12 +166,14 @@ struct EigWork {
     bool x_prev_sparse = true;                     // x_prev is zero off the support (initial iterate)
     bool use_fop = false;                          // the projection in progress uses the operator form
     const double* esv = nullptr;                   // support values of E for the projection in progress
+    // per-block execution context: counters are merged into the solver's after the projections
+    hipStream_t stream = nullptr;                  // own stream (concurrent block projections)
+    hipEvent_t done = nullptr;
+    proxsdp_stats lst{};
+    long long mv_iter = 0, recon_r = 0;
+    EigEvents ev;
 };
 
-struct EigEvents {                  // optional profiling of the dominant kernel
-    std::vector<hipEvent_t> e0, e1;
-    size_t used = 0;
-};
 
 class Solver {
 public:
@@ -170,11 +190,17 @@ public:
     }
     ~Solver() {
         if (warm.joinable()) warm.join();
-        for (auto e : ev.e0) (void)hipEventDestroy(e);
-        for (auto e : ev.e1) (void)hipEventDestroy(e);
+        stop_workers();
+        for (EigWork& W : eig) {
+            for (auto e : W.ev.e0) (void)hipEventDestroy(e);
+            for (auto e : W.ev.e1) (void)hipEventDestroy(e);
+            if (W.done) (void)hipEventDestroy(W.done);
+            if (W.stream) (void)hipStreamDestroy(W.stream);
+        }
+        if (ev_main) (void)hipEventDestroy(ev_main);
         for (auto& pr : dense_ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
         if (blas) (void)rocblas_destroy_handle(blas);
-        if (stream) (void)hipStreamDestroy(stream);
+        if (stream.main) (void)hipStreamDestroy(stream.main);
     }
     void run();
 
@@ -198,7 +224,7 @@ public:
     proxsdp_options opt;
     proxsdp_result& res;
     Prep P;
-    hipStream_t stream = nullptr;
+    StreamRef stream;
     rocblas_handle blas = nullptr;
     std::vector<EigWork> eig;
     EigEvents ev;
@@ -219,6 +245,23 @@ public:
     bool g_conic = false, g_not_converged_rank = false, g_any_below_full = false;
     double g_elapsed = 0;
     std::thread warm;               // loads rocSOLVER's code objects while the loop runs
+    // concurrent block projections: one worker thread per PSD block (up to 8), each driving its
+    // block's Lanczos on the block's own stream
+    std::mutex blas_mutex;
+    std::vector<std::thread> workers;
+    std::mutex pool_mu;
+    std::condition_variable pool_cv, pool_done_cv;
+    std::vector<int> pool_queue;               // block indices waiting for a worker
+    int pool_pending = 0;
+    bool pool_stop = false;
+    std::exception_ptr pool_error;
+    std::function<void(int)> pool_job;
+    hipEvent_t ev_main = nullptr;
+    bool parallel_blocks = false;
+    void start_workers(int nthreads);
+    void stop_workers();
+    void run_blocks(const std::vector<int>& blocks, const std::function<void(int)>& job);
+    void merge_block_stats();
     void start_rocsolver_warmup();
 
 private:
@@ -231,6 +274,7 @@ private:
     DevBuf<double> one_min, soc_gap_d;
     int xc = 0, mtyc = 0, yc = 0, mxc = 0;     // index of the "current" buffer of each ping-pong pair
     std::vector<int> one_blocks;               // indices of 1x1 PSD blocks
+    std::vector<int> big_blocks;               // indices of the blocks that are projected by an eigensolver
     std::vector<double> hscal;
     bool csr_wave = false;
 
@@ -344,7 +388,7 @@ inline void Solver::setup_device() {
     if (ndev <= 0) throw HipError("no HIP device available");
     if (opt.device_id < 0 || opt.device_id >= ndev) throw std::invalid_argument("device_id out of range");
     PX_HIP(hipSetDevice(opt.device_id));
-    PX_HIP(hipStreamCreate(&stream));
+    PX_HIP(hipStreamCreate(&stream.main));
     PX_ROC(rocblas_create_handle(&blas));
     PX_ROC(rocblas_set_stream(blas, stream));
 }
@@ -393,19 +437,19 @@ static inline void launch_prof(bool prof, hipEvent_t e0, hipEvent_t e1, K kern, 
 
 inline void Solver::launch_symv(EigWork& W, const double* xp, const double* v, bool use_ctl) {
     const int ntile = 8 * ceil_div(W.nt * (W.nt + 1) / 2, 8);     // one workgroup per 64x64 tile, padded to 8 XCDs
-    bool prof = opt.profile_symv_every > 0 && (st.symv_launches % opt.profile_symv_every) == 0;
+    bool prof = opt.profile_symv_every > 0 && (W.lst.symv_launches % opt.profile_symv_every) == 0;
     size_t slot = 0;
     if (prof) {
-        if (ev.used == ev.e0.size()) {
+        if (W.ev.used == W.ev.e0.size()) {
             hipEvent_t a, b;
             PX_HIP(hipEventCreate(&a)); PX_HIP(hipEventCreate(&b));
-            ev.e0.push_back(a); ev.e1.push_back(b);
+            W.ev.e0.push_back(a); W.ev.e1.push_back(b);
         }
-        slot = ev.used++;
+        slot = W.ev.used++;
     }
     // profiled launches carry their own start/stop events (the dispatch's timestamps, i.e. the
     // kernel alone, as rocprofv3 reports it -- not the gaps to the neighbouring launches)
-    hipEvent_t e0 = prof ? ev.e0[slot] : nullptr, e1 = prof ? ev.e1[slot] : nullptr;
+    hipEvent_t e0 = prof ? W.ev.e0[slot] : nullptr, e1 = prof ? W.ev.e1[slot] : nullptr;
     if (W.use_fop) {
         auto kern = (W.F_r <= 64) ? dev::k_fop<1> : dev::k_fop<2>;
         launch_prof(prof, e0, e1, kern, dim3(W.nt), stream,
@@ -416,8 +460,8 @@ inline void Solver::launch_symv(EigWork& W, const double* xp, const double* v, b
         launch_prof(prof, e0, e1, dev::k_symv_packed, dim3(ntile), stream,
                     xp, W.n, W.nt, W.npad, v, W.Ppart.p, (const dev::LanczosCtl*)(use_ctl ? W.ctl_p : nullptr), W.Apart.p);
     }
-    st.symv_launches++;
-    st.symv_bytes += 8.0 * (double)W.N + 16.0 * (double)W.n;
+    W.lst.symv_launches++;
+    W.lst.symv_bytes += 8.0 * (double)W.N + 16.0 * (double)W.n;
 }
 
 // partial-dot buffer written by the orthogonalisation of step k
@@ -428,17 +472,17 @@ inline double* lz_hpart(EigWork& W, int k) {
 // k_symv_finish: closes Lanczos step `kclose` and runs the mat-vec of step kclose+1 on w'
 inline void Solver::launch_symv_finish(EigWork& W, const double* xp, int kclose, double tol, bool use_carry) {
     const int ntile = 8 * ceil_div(W.nt * (W.nt + 1) / 2, 8);
-    bool prof = opt.profile_symv_every > 0 && (st.symv_launches % opt.profile_symv_every) == 0;
+    bool prof = opt.profile_symv_every > 0 && (W.lst.symv_launches % opt.profile_symv_every) == 0;
     size_t slot = 0;
     if (prof) {
-        if (ev.used == ev.e0.size()) {
+        if (W.ev.used == W.ev.e0.size()) {
             hipEvent_t a, b;
             PX_HIP(hipEventCreate(&a)); PX_HIP(hipEventCreate(&b));
-            ev.e0.push_back(a); ev.e1.push_back(b);
+            W.ev.e0.push_back(a); W.ev.e1.push_back(b);
         }
-        slot = ev.used++;
+        slot = W.ev.used++;
     }
-    hipEvent_t e0 = prof ? ev.e0[slot] : nullptr, e1 = prof ? ev.e1[slot] : nullptr;
+    hipEvent_t e0 = prof ? W.ev.e0[slot] : nullptr, e1 = prof ? W.ev.e1[slot] : nullptr;
     if (W.use_fop) {
         auto kern = (W.F_r <= 64) ? dev::k_fop_finish<1> : dev::k_fop_finish<2>;
         launch_prof(prof, e0, e1, kern, dim3(2 * W.nt), stream,
@@ -453,8 +497,8 @@ inline void Solver::launch_symv_finish(EigWork& W, const double* xp, int kclose,
                     (const double*)lz_hpart(W, kclose), W.pld, (const double*)W.hsum1.p, W.alphas_p, W.betas_p, W.ctl_p,
                     tol, use_carry ? 1 : 0, W.Apart.p);
     }
-    st.symv_launches++;
-    st.symv_bytes += 8.0 * (double)W.N + 16.0 * (double)W.n;
+    W.lst.symv_launches++;
+    W.lst.symv_bytes += 8.0 * (double)W.N + 16.0 * (double)W.n;
 }
 
 inline void Solver::launch_reconstruct(EigWork& W, const double* Z, int ldz, const double* lam, int r, double* xp_out,
@@ -510,7 +554,7 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev) {
     if (!arpack && opt.krylovkit_eager) throw std::invalid_argument("krylovkit_eager=true is not implemented");
     W.prev_numiter = std::max(W.numiter, 1);
     W.converged = false; W.count = 0; W.converged_eigs = 0; W.numiter = 0; W.vals.clear();
-    st.lanczos_calls++;
+    W.lst.lanczos_calls++;
     if (arpack && (!(0 < nev && nev < W.n) || krylovdim > W.n)) return;   // dsaupd info=-1/-3 -> error -> fallback
 
     const double step_tol = arpack ? 0.0 : tol;       // invariant-subspace test inside the recurrence
@@ -527,7 +571,7 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev) {
         for (int k = kfirst; k < krylovdim; ++k) {
             if (k == kfirst) {
                 if (!presymv) launch_symv(W, xp, W.V.p + (size_t)k * W.npad, true);   // v_k is ready (start)
-                else { st.symv_launches++; st.symv_bytes += 8.0 * (double)W.N + 16.0 * (double)W.n; }
+                else { W.lst.symv_launches++; W.lst.symv_bytes += 8.0 * (double)W.N + 16.0 * (double)W.n; }
                 presymv = false;               // after a restart the mat-vec of v_keep is already in Ppart
             } else {
                 // close step k-1 and run the mat-vec of step k in one launch
@@ -573,30 +617,30 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev) {
         const bool speculate = W.prev_numiter > 1 || numiter > 1;
         if (speculate) {
             launch_symv(W, xp, W.V.p + (size_t)krylovdim * W.npad, true);
-            st.symv_launches--; st.symv_bytes -= 8.0 * (double)W.N + 16.0 * (double)W.n;   // counted when used
+            W.lst.symv_launches--; W.lst.symv_bytes -= 8.0 * (double)W.N + 16.0 * (double)W.n;   // counted when used
         }
         PX_HIP(hipMemcpyAsync(W.rec_host, W.rec.p, EigWork::REC_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, stream));
         PX_HIP(hipStreamSynchronize(stream));
         std::copy(W.rec_host, W.rec_host + krylovdim, al.begin());
         std::copy(W.rec_host + dev::MAXK, W.rec_host + dev::MAXK + krylovdim, be.begin());
         std::memcpy(&hctl, W.rec_host + 2 * dev::MAXK, sizeof(hctl));
-        if (ev.used) {                                   // harvest profiled symv launches
-            for (size_t s = 0; s < ev.used; ++s) {
+        if (W.ev.used) {                                   // harvest profiled symv launches
+            for (size_t s = 0; s < W.ev.used; ++s) {
                 float ms = 0.f;
-                if (hipEventElapsedTime(&ms, ev.e0[s], ev.e1[s]) == hipSuccess) {
-                    st.symv_profiled_ms += ms; st.symv_profiled++;
+                if (hipEventElapsedTime(&ms, W.ev.e0[s], W.ev.e1[s]) == hipSuccess) {
+                    W.lst.symv_profiled_ms += ms; W.lst.symv_profiled++;
                 }
             }
-            ev.used = 0;
+            W.ev.used = 0;
         }
         const int Kend = hctl.stop ? hctl.kstop : krylovdim;
         // launches after the stop flag are no-ops; count the mat-vecs that did work
         {
             long long skipped = (long long)(krylovdim - Kend);
-            st.lanczos_matvecs += (Kend - kfirst);
-            st.symv_launches -= skipped;
-            st.symv_bytes -= skipped * (8.0 * (double)W.N + 16.0 * (double)W.n);
-            lz_matvec_iter += (Kend - kfirst);
+            W.lst.lanczos_matvecs += (Kend - kfirst);
+            W.lst.symv_launches -= skipped;
+            W.lst.symv_bytes -= skipped * (8.0 * (double)W.N + 16.0 * (double)W.n);
+            W.mv_iter += (Kend - kfirst);
         }
         for (int k = kfirst; k < Kend; ++k) {
             T[(size_t)k * ld + k] = al[k];
@@ -617,7 +661,7 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev) {
             std::vector<double> Dasc(K);
             const double te0 = now_s();
             symeig_dense(K, Tw.data(), Dasc.data(), kfirst == 0);
-            st.t_primal += now_s() - te0;            // (field reused: host K x K eigensolves)
+            W.lst.t_primal += now_s() - te0;            // (field reused: host K x K eigensolves)
             U.assign((size_t)K * K, 0.0);
             for (int c = 0; c < K; ++c) {                // :LR -> descending
                 D[c] = Dasc[K - 1 - c];
@@ -654,7 +698,7 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev) {
         kfirst = keep;
         presymv = speculate;
         ++numiter;
-        st.lanczos_restarts++;
+        W.lst.lanczos_restarts++;
     }
     W.numiter = numiter;
     if (arpack) {
@@ -689,6 +733,8 @@ inline void Solver::full_eig_values(EigWork& W, const double* xp, double offscal
     }
     const int ntile = W.nt * (W.nt + 1) / 2;
     hipLaunchKernelGGL(dev::k_unpack_upper, dim3(ntile), dim3(dev::TPB), 0, stream, xp, n, W.A.p, n, offscale);
+    std::lock_guard<std::mutex> lk(blas_mutex);          // one rocBLAS handle: dense fallbacks run one at a time
+    PX_ROC(rocblas_set_stream(blas, (hipStream_t)stream));
     PX_ROC(rocsolver_dsyevd(blas, vectors ? rocblas_evect_original : rocblas_evect_none, rocblas_fill_upper,
                             n, W.A.p, n, W.D.p, W.E.p, W.info.p));
     Dhost.resize(n);
@@ -704,7 +750,7 @@ inline void Solver::full_eig_project(int idx, const double* xp_in, double* xp_ou
     EigWork& W = eig[idx];
     std::vector<double> D;
     full_eig_values(W, xp_in, dev::INV_SQRT2, true, D);
-    st.full_eigs++;
+    W.lst.full_eigs++;
     const int n = W.n;
     int npos = 0, rank = 0;
     for (int i = 0; i < n; ++i) { if (D[i] > 0.0) ++npos; if (D[i] > opt.tol_psd) ++rank; }
@@ -713,7 +759,88 @@ inline void Solver::full_eig_project(int idx, const double* xp_in, double* xp_ou
     // ascending order: the positive eigenpairs are the trailing npos columns
     launch_reconstruct(W, W.A.p + (size_t)(n - npos) * n, n, W.D.p + (n - npos), npos, xp_out,
                        fuse ? xp_in : nullptr, fuse ? idx : -1);
-    recon_r_iter += npos;
+    W.recon_r += npos;
+}
+
+// ---- worker pool for concurrent block projections
+inline void Solver::start_workers(int nthreads) {
+    const int dev_id = opt.device_id;
+    for (int t = 0; t < nthreads; ++t)
+        workers.emplace_back([this, dev_id]() {
+            (void)hipSetDevice(dev_id);
+            for (;;) {
+                int idx;
+                {
+                    std::unique_lock<std::mutex> lk(pool_mu);
+                    pool_cv.wait(lk, [this]() { return pool_stop || !pool_queue.empty(); });
+                    if (pool_stop) return;
+                    idx = pool_queue.back();
+                    pool_queue.pop_back();
+                }
+                try {
+                    StreamRef::tl = eig[idx].stream;
+                    PX_HIP(hipStreamWaitEvent(eig[idx].stream, ev_main, 0));
+                    pool_job(idx);
+                    PX_HIP(hipEventRecord(eig[idx].done, eig[idx].stream));
+                } catch (...) {
+                    std::lock_guard<std::mutex> lk(pool_mu);
+                    if (!pool_error) pool_error = std::current_exception();
+                }
+                StreamRef::tl = nullptr;
+                {
+                    std::lock_guard<std::mutex> lk(pool_mu);
+                    if (--pool_pending == 0) pool_done_cv.notify_all();
+                }
+            }
+        });
+}
+inline void Solver::stop_workers() {
+    {
+        std::lock_guard<std::mutex> lk(pool_mu);
+        pool_stop = true;
+    }
+    pool_cv.notify_all();
+    for (std::thread& t : workers) if (t.joinable()) t.join();
+    workers.clear();
+}
+// run job(idx) for every listed block: concurrently on the blocks' streams when the pool is
+// up, otherwise in sequence on the solver's stream.  Returns after all host work is done and
+// the solver's stream has been made to wait for the block streams.
+inline void Solver::run_blocks(const std::vector<int>& blocks, const std::function<void(int)>& job) {
+    if (!parallel_blocks || blocks.size() < 2) {
+        for (int idx : blocks) job(idx);
+        merge_block_stats();
+        return;
+    }
+    PX_HIP(hipEventRecord(ev_main, stream.main));
+    {
+        std::lock_guard<std::mutex> lk(pool_mu);
+        pool_job = job;
+        pool_queue.assign(blocks.rbegin(), blocks.rend());
+        pool_pending = (int)blocks.size();
+        pool_error = nullptr;
+    }
+    pool_cv.notify_all();
+    {
+        std::unique_lock<std::mutex> lk(pool_mu);
+        pool_done_cv.wait(lk, [this]() { return pool_pending == 0; });
+    }
+    if (pool_error) std::rethrow_exception(pool_error);
+    for (int idx : blocks) PX_HIP(hipStreamWaitEvent(stream.main, eig[idx].done, 0));
+    merge_block_stats();
+}
+inline void Solver::merge_block_stats() {
+    for (EigWork& W : eig) {
+        proxsdp_stats& a = W.lst;
+        st.lanczos_matvecs += a.lanczos_matvecs; st.lanczos_restarts += a.lanczos_restarts;
+        st.lanczos_calls += a.lanczos_calls; st.full_eigs += a.full_eigs;
+        st.krylov_fallbacks += a.krylov_fallbacks; st.symv_launches += a.symv_launches;
+        st.symv_profiled += a.symv_profiled; st.symv_profiled_ms += a.symv_profiled_ms;
+        st.symv_bytes += a.symv_bytes; st.t_primal += a.t_primal; st.fop_projections += a.fop_projections;
+        a = proxsdp_stats{};
+        lz_matvec_iter += W.mv_iter; recon_r_iter += W.recon_r;
+        W.mv_iter = 0; W.recon_r = 0;
+    }
 }
 
 }  // namespace proxsdp
