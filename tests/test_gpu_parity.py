@@ -438,6 +438,30 @@ def test_operator_form_matvec_matches_packed_matvec(case):
         assert np.allclose(b.trace[:tight, [1, 2, 3, 4, 7, 11]], G[:tight], rtol=1e-7, atol=1e-10)
 
 
+def test_blocks_wider_than_64_workgroups():
+    """n = 4200 -> 66 row groups: the per-workgroup partial arrays no longer fit one wave-wide
+    load (pld = 128) and the `n > 4096` branches of the Lanczos kernels run.  Eigenpairs against
+    LAPACK, and the three solver configurations (dense vector passes / support path with the
+    packed mat-vec / support path with the operator form) against each other."""
+    n = 4200
+    x = planted_packed(n, 5, [90.0, 70.0, 55.0, 30.0], bulk=(-4.0, 1.0))
+    vals, vecs, info = B.eigsolve(x, n, 3)
+    X = smat(x, n)
+    ref = np.sort(np.linalg.eigvalsh(X))[::-1]
+    assert info["converged"] >= 3
+    assert np.allclose(vals[:3], ref[:3], rtol=0, atol=1e-11 * ref[0])
+    assert np.allclose(vecs.T @ vecs, np.eye(vecs.shape[1]), atol=1e-10)
+    pr = P.maxcut(n, seed=1)
+    runs = [Optimizer(max_iter=40, **kw).optimize(pr, trace_capacity=40)
+            for kw in (dict(support_path=0), dict(support_path=1, lanczos_operator=0), dict(support_path=1, lanczos_operator=1))]
+    a = runs[0]
+    for b in runs[1:]:
+        assert np.array_equal(a.trace[:, 11], b.trace[:, 11]) and np.array_equal(a.trace[:, 13], b.trace[:, 13])
+        for col in (1, 2, 3, 4, 5, 6, 7, 9):
+            assert np.allclose(a.trace[:, col], b.trace[:, col], rtol=1e-8, atol=1e-11), col
+    assert runs[2].stats["fop_projections"] == 40 and runs[1].stats["fop_projections"] == 0
+
+
 def test_operator_form_converges_to_the_same_optimum():
     """Full solves (tol 1e-4) of a Max-Cut instance with both operators: same status, objectives
     within the solver's own gap measure, iterate feasible by the solver's own criterion
