@@ -155,7 +155,10 @@ typedef struct proxsdp_options {
     double  krylovkit_tol; int32_t krylovkit_max_iter; int32_t krylovkit_eager; int32_t krylovkit_verbose;
     int32_t reduce_rank; int32_t rank_slack; int32_t pad6;
     int64_t full_eig_freq; int64_t full_eig_len;
-    /* equilibration (off by default; =1 is PROXSDP_E_UNSUPP) */
+    /* equilibration (equilibration.jl, pdhg.jl:64-92): off by default; `equilibration` alone
+     * survives only if min(M)/max(M) > equilibration_limit, `equilibration_force` always.
+     * approx_norm = 0: step size from sigma_max(M) instead of ||M||_F (pdhg.jl:108-119).
+     * Neither is available with a dense A or a block-sharded solve. */
     int32_t equilibration; int32_t equilibration_iters;
     double  equilibration_lb, equilibration_ub, equilibration_limit;
     int32_t equilibration_force; int32_t approx_norm;

@@ -487,10 +487,56 @@ def dual_feas(y, cones, aff, c, A, G, a):
     return dual_feas_parts(dual_in, dual_cone, cones, a)
 
 
-def cache_solution(st, res, cones, aff, p, opt, c, A, b, G, h, var_ordering, a):
+def equilibrate(M, aff, opt):
+    """equilibrate! (equilibration.jl:1-72): projected-gradient row/column scaling.  NB the
+    reference replaces v by its mean in every iteration (:56-58), so D is a multiple of the
+    identity; reproduced as written.  Returns the diagonals (E over rows, D over columns)."""
+    M = sp.csc_matrix(M)
+    nQ, n = aff.m + aff.p, aff.n
+    alpha = (n / nQ) ** 0.25
+    beta = (nQ / n) ** 0.25
+    alpha2, beta2 = alpha ** 2, beta ** 2
+    gamma = 0.1
+    u, v = np.zeros(nQ), np.zeros(n)
+    u_, v_ = np.zeros(nQ), np.zeros(n)
+    rows = M.indices
+    cols = np.repeat(np.arange(n), np.diff(M.indptr))
+    for it in range(1, opt.equilibration_iters + 1):
+        Ed, Dd = np.exp(u), np.exp(v)
+        d2 = (M.data * Dd[cols] * Ed[rows]) ** 2
+        step_size = 2.0 / (gamma * (it + 1.0))
+        row_norms = np.bincount(rows, weights=d2, minlength=nQ)
+        col_norms = np.bincount(cols, weights=d2, minlength=n)
+        u_grad = row_norms - alpha2 + gamma * u
+        v_grad = col_norms - beta2 + gamma * v
+        u = np.clip(u - step_size * u_grad, opt.equilibration_lb, opt.equilibration_ub)
+        v = v - step_size * v_grad
+        v = np.full(n, np.sum(v) / n)
+        v = np.clip(v, 0.0, opt.equilibration_ub)
+        u_ = 2 * u / (it + 2) + it * u_ / (it + 2)
+        v_ = 2 * v / (it + 2) + it * v_ / (it + 2)
+    return np.exp(u_), np.exp(v_)
+
+
+def _sparse_extrema(M):
+    """maximum(M), minimum(M) of a SparseMatrixCSC: implicit zeros count (pdhg.jl:68-69)."""
+    M = sp.csc_matrix(M)
+    has_zero = M.nnz < M.shape[0] * M.shape[1]
+    if M.nnz == 0:
+        return 0.0, 0.0
+    hi, lo = float(M.data.max()), float(M.data.min())
+    if has_zero:
+        hi, lo = max(hi, 0.0), min(lo, 0.0)
+    return hi, lo
+
+
+def cache_solution(st, res, cones, aff, p, opt, c, A, b, G, h, var_ordering, a, ED=None):
     """cache_solution (pdhg.jl:745-787).  NB: mutates st.x in place exactly as
     the reference does (fix_diag_scaling on pair.x)."""
     fix_diag_scaling(st.x, cones, math.sqrt(2.0))
+    if opt.equilibration and ED is not None:     # "Remove equilibrating" (pdhg.jl:751-755); the scaled
+        st.x = ED[1] * st.x                      # iterates replace pair.x / pair.y, as in the reference
+        st.y = ED[0] * st.y
     slack_eq = A @ st.x - b
     slack_in = G @ st.x - h
     dual_eq, dual_in, dual_cone = get_duals(st.y, cones, aff, c, A, G)
@@ -561,8 +607,24 @@ def chambolle_pock(aff_in, cones, opt_in=None, *, eig_resid=None, trace=False,
     c_orig, var_ordering = preprocess(aff, cones)
     A_orig, b_orig = aff.A.copy(), aff.b.copy()
     G_orig, h_orig = aff.G.copy(), aff.h.copy()
-    if opt.equilibration or opt.equilibration_force:
-        raise NotImplementedError("equilibration (off by default, out of scope: SURVEY.md section 2 row 10)")
+    # Diagonal preconditioning (pdhg.jl:64-92)
+    ED = None
+    if opt.equilibration:
+        UB, LB = _sparse_extrema(sp.vstack([aff.A, aff.G]))
+        if UB == 0.0 or LB / UB <= opt.equilibration_limit:
+            opt.equilibration = False
+    if opt.equilibration_force:
+        opt.equilibration = True
+    if opt.equilibration:
+        M0 = sp.vstack([aff.A, aff.G], format="csc")
+        Ed, Dd = equilibrate(M0, aff, opt)
+        Ms = sp.csc_matrix(sp.diags(Ed) @ M0 @ sp.diags(Dd))
+        aff.A = sp.csc_matrix(Ms[:aff.p, :])
+        aff.G = sp.csc_matrix(Ms[aff.p:, :])
+        rhs = Ed * np.concatenate([b_orig, h_orig])
+        aff.b, aff.h = rhs[:aff.p].copy(), rhs[aff.p:].copy()
+        aff.c = Dd * aff.c
+        ED = (Ed, Dd)
     norm_scaling(aff, cones)
 
     st = _State()
@@ -576,9 +638,17 @@ def chambolle_pock(aff_in, cones, opt_in=None, *, eig_resid=None, trace=False,
 
     M = sp.vstack([aff.A, aff.G], format="csr")
     Mt = M.T.tocsr()
-    if not opt.approx_norm:
-        raise NotImplementedError("approx_norm=false (Arpack.svds), off by default")
-    spectral_norm = float(np.sqrt(np.sum(M.data ** 2)))          # LinearAlgebra.norm(M)
+    if not opt.approx_norm:                                       # pdhg.jl:108-119
+        if min(M.shape) >= 2:
+            try:
+                import scipy.sparse.linalg as spla
+                spectral_norm = float(spla.svds(M.astype(float), k=1, return_singular_vectors=False)[0])
+            except Exception:
+                spectral_norm = float(np.sqrt(np.sum(M.data ** 2)))
+        else:
+            spectral_norm = float(np.linalg.svd(M.toarray(), compute_uv=False).max()) if M.shape[0] * M.shape[1] else 0.0
+    else:
+        spectral_norm = float(np.sqrt(np.sum(M.data ** 2)))      # LinearAlgebra.norm(M)
     if spectral_norm < 1e-10:
         spectral_norm = 1.0
     p.primal_step = 1.0 / spectral_norm
@@ -713,7 +783,7 @@ def chambolle_pock(aff_in, cones, opt_in=None, *, eig_resid=None, trace=False,
 
         def _cache():
             return cache_solution(st, res, cones, aff, p, opt, c_orig, A_orig, b_orig,
-                                  G_orig, h_orig, var_ordering, a)
+                                  G_orig, h_orig, var_ordering, a, ED)
 
         def _cert_infeas():            # certificate_infeasibility (pdhg.jl:655-668)
             aff.c[:] = 0.0
@@ -816,7 +886,7 @@ def chambolle_pock(aff_in, cones, opt_in=None, *, eig_resid=None, trace=False,
 
     def _final_cache(cvec):
         return cache_solution(st, res, cones, aff, p, opt, cvec, A_orig, b_orig,
-                              G_orig, h_orig, var_ordering, a)
+                              G_orig, h_orig, var_ordering, a, ED)
 
     if opt.certificate_search and p.certificate_search:
         assert len(sol) == 1

@@ -1504,6 +1504,12 @@ k_combine_multi(const double* __restrict__ part, int stride, int cnt, unsigned l
     if (threadIdx.x == 0) out[q] = r;
 }
 
+// v .*= d (removing the equilibration at the exit path, pdhg.jl:751-755)
+__global__ void __launch_bounds__(TPB)
+k_scale_by(double* __restrict__ v, const double* __restrict__ d, long long n) {
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long long)gridDim.x * TPB) v[i] *= d[i];
+}
+
 // v[offdiag] *= s over all PSD blocks (fix_diag_scaling, pdhg.jl:734-743) -- used
 // on the exit path and when a certificate search snapshots the solution.
 __global__ void __launch_bounds__(TPB)

@@ -353,6 +353,15 @@ inline void Solver::cache_solution(const std::vector<double>& cvec) {
         hipLaunchKernelGGL(dev::k_scale_offdiag, dim3(nt * (nt + 1) / 2), dim3(dev::TPB), 0, stream,
                            xbuf[xc].p + B.off, B.n, inv);
     }
+    if (P.equilibrated) {                                    // pair.x = D*pair.x; pair.y = E*pair.y (pdhg.jl:751-755)
+        if (Ddiag_d.n == 0) {
+            Ddiag_d.alloc(P.n); Ediag_d.alloc(std::max<int64_t>(P.Q, 1));
+            Ddiag_d.upload(P.Ddiag.data(), P.n, stream); Ediag_d.upload(P.Ediag.data(), P.Q, stream);
+        }
+        hipLaunchKernelGGL(dev::k_scale_by, dim3(grid_for(P.n)), dim3(dev::TPB), 0, stream, xbuf[xc].p, Ddiag_d.p, (long long)P.n);
+        hipLaunchKernelGGL(dev::k_scale_by, dim3(grid_for(std::max<int64_t>(P.Q, 1))), dim3(dev::TPB), 0, stream,
+                           ybuf[yc].p, Ediag_d.p, (long long)P.Q);
+    }
     std::vector<double> x(P.n), y(P.Q);
     xbuf[xc].download(x.data(), P.n, stream);
     ybuf[yc].download(y.data(), P.Q, stream);
@@ -384,8 +393,8 @@ inline void Solver::cache_solution(const std::vector<double>& cvec) {
     if (res.dual_cone) for (int64_t i = 0; i < P.n; ++i) res.dual_cone[i] = dcone[P.inv[i]];
     if (res.dual_eq)   for (int64_t i = 0; i < P.p; ++i) res.dual_eq[i] = deq[i];
     if (res.dual_in)   for (int64_t i = 0; i < P.m; ++i) res.dual_in[i] = din[i];
-    if (res.slack_eq)  for (int64_t i = 0; i < P.p; ++i) res.slack_eq[i] = slack[i] - P.b[i];
-    if (res.slack_in)  for (int64_t i = 0; i < P.m; ++i) res.slack_in[i] = slack[P.p + i] - P.h[i];
+    if (res.slack_eq)  for (int64_t i = 0; i < P.p; ++i) res.slack_eq[i] = slack[i] - P.b_orig[i];
+    if (res.slack_in)  for (int64_t i = 0; i < P.m; ++i) res.slack_in[i] = slack[P.p + i] - P.h_orig[i];
     res.primal_residual = equa_feasibility;
     res.dual_residual = ineq_feasibility;
     res.objval = h_pobj.at(iter);
@@ -799,9 +808,8 @@ inline void Solver::test_spmv(bool transpose, const double* in, double* out) {
 // chambolle_pock (pdhg.jl:1-530)
 inline void Solver::run() {
     const double t_init0 = now_s();
-    if (opt.equilibration || opt.equilibration_force)
-        throw std::domain_error("equilibration is not implemented (off by default in the reference)");
-    if (!opt.approx_norm) throw std::domain_error("approx_norm=false (svds) is not implemented");
+    if (!opt.approx_norm && (P.dense() || sharded()))
+        throw std::domain_error("approx_norm=false with a dense A or a block-sharded solve is not implemented");
     if (P.n <= 0) throw std::invalid_argument("problem has no variables");
     if (opt.convergence_window <= 0) throw std::invalid_argument("convergence_window must be positive");
     theta = opt.initial_theta; adapt_level = opt.initial_adapt_level; beta = opt.initial_beta;
@@ -926,6 +934,8 @@ inline void Solver::run() {
     if (sharded() && !use_support)
         throw std::domain_error("block-sharded solve needs the support-aware path (no SOC / 1x1 cones)");
     double spectral_norm = g_frob;                       // LinearAlgebra.norm(M), pdhg.jl:121
+    if (!opt.approx_norm)                                // Arpack.svds(M, nsv=1), pdhg.jl:108-119
+        spectral_norm = spectral_norm_host(P, [](int K, double* T, double* d) { return symeig_dense(K, T, d, true); });
     if (spectral_norm < 1e-10) spectral_norm = 1.0;
     primal_step = 1.0 / spectral_norm;
     primal_step_old = primal_step;

@@ -5,6 +5,7 @@
 //   (pdhg.jl:104) in both orientations, ||M||_F (pdhg.jl:121), data norms
 //   (pdhg.jl:14-16), cone layout (util.jl:2-16).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <stdexcept>
@@ -29,7 +30,11 @@ struct Prep {
     std::vector<int64_t> rowptr;       // Q+1
     std::vector<int32_t> colidx;
     std::vector<double> rval;
-    std::vector<double> b, h, c, c_orig;   // c: reordered+scaled; c_orig: reordered, unscaled
+    std::vector<double> b, h, c, c_orig;   // b, h: as used in the loop (row-scaled when equilibrated); c: reordered+scaled; c_orig: reordered, unscaled
+    std::vector<double> b_orig, h_orig;    // the caller's b, h (exit path: slacks)
+    // equilibration (pdhg.jl:64-92, equilibration.jl): M <- E M D, [b;h] <- E [b;h], c <- D c
+    bool equilibrated = false;
+    std::vector<double> Ediag, Ddiag;
     std::vector<uint8_t> offdiag;          // per new position: 1 if off-diagonal PSD entry
     std::vector<BlockInfo> blocks;
     std::vector<SocInfo> socs;
@@ -65,7 +70,46 @@ inline void check_csc(const proxsdp_csc& M, int64_t rows, int64_t cols, int base
     }
 }
 
-inline Prep prepare(const proxsdp_problem& P) {
+// equilibrate! (equilibration.jl:1-72) on the reordered, unscaled M (CSC).  The reference
+// replaces v by its mean in every iteration (:56-58), so D comes out as a multiple of the
+// identity; reproduced as written.
+inline void equilibrate_host(const Prep& R, const proxsdp_options& opt, std::vector<double>& Ed, std::vector<double>& Dd) {
+    const int64_t nQ = R.Q, n = R.n;
+    const double alpha = std::pow((double)n / (double)nQ, 0.25), beta = std::pow((double)nQ / (double)n, 0.25);
+    const double alpha2 = alpha * alpha, beta2 = beta * beta, gamma = 0.1;
+    std::vector<double> u(nQ, 0.0), v(n, 0.0), u_(nQ, 0.0), v_(n, 0.0), rn(nQ), cn(n);
+    Ed.assign(nQ, 1.0); Dd.assign(n, 1.0);
+    for (int64_t it = 1; it <= opt.equilibration_iters; ++it) {
+        for (int64_t r = 0; r < nQ; ++r) Ed[r] = std::exp(u[r]);
+        for (int64_t k = 0; k < n; ++k) Dd[k] = std::exp(v[k]);
+        std::fill(rn.begin(), rn.end(), 0.0);
+        for (int64_t k = 0; k < n; ++k) {
+            double cs = 0.0;
+            for (int64_t q = R.colptr[k]; q < R.colptr[k + 1]; ++q) {
+                const double m = (R.val_orig[q] * Dd[k]) * Ed[R.rowidx[q]];
+                rn[R.rowidx[q]] += m * m;
+                cs += m * m;
+            }
+            cn[k] = cs;
+        }
+        const double step = 2.0 / (gamma * ((double)it + 1.0));
+        for (int64_t r = 0; r < nQ; ++r) {
+            const double g = rn[r] - alpha2 + gamma * u[r];
+            u[r] = std::min(opt.equilibration_ub, std::max(u[r] - step * g, opt.equilibration_lb));
+        }
+        double sv = 0.0;
+        for (int64_t k = 0; k < n; ++k) { v[k] -= step * (cn[k] - beta2 + gamma * v[k]); sv += v[k]; }
+        const double vm = std::min(opt.equilibration_ub, std::max(sv / (double)n, 0.0));
+        for (int64_t k = 0; k < n; ++k) v[k] = vm;
+        const double a = 2.0 / ((double)it + 2.0), b = (double)it / ((double)it + 2.0);
+        for (int64_t r = 0; r < nQ; ++r) u_[r] = a * u[r] + b * u_[r];
+        for (int64_t k = 0; k < n; ++k) v_[k] = a * v[k] + b * v_[k];
+    }
+    for (int64_t r = 0; r < nQ; ++r) Ed[r] = std::exp(u_[r]);
+    for (int64_t k = 0; k < n; ++k) Dd[k] = std::exp(v_[k]);
+}
+
+inline Prep prepare(const proxsdp_problem& P, const proxsdp_options* opt = nullptr) {
     Prep R;
     const int base = P.index_base;
     if (base != 0 && base != 1) throw std::invalid_argument("index_base must be 0 or 1");
@@ -129,6 +173,7 @@ inline Prep prepare(const proxsdp_problem& P) {
     // ---- vectors
     R.b.assign(P.b, P.b + P.p);
     R.h.assign(P.h, P.h + P.m);
+    R.b_orig = R.b; R.h_orig = R.h;
     R.norm_b = norm2(P.b, P.p);
     R.norm_h = norm2(P.h, P.m);
     R.norm_c = norm2(P.c, P.n);
@@ -155,25 +200,51 @@ inline Prep prepare(const proxsdp_problem& P) {
     R.colptr.assign(P.n + 1, 0);
     R.rowidx.resize(R.nnz); R.val.resize(R.nnz); R.val_orig.resize(R.nnz);
     int64_t w = 0;
-    double ss = 0.0;
     for (int64_t k = 0; k < P.n; ++k) {
         const int64_t j = R.ord[k];
-        const double sc = R.offdiag[k] ? cte : 1.0;
         R.colptr[k] = w;
         for (int64_t q = dense ? 0 : P.A.colptr[j] - base; q < (dense ? 0 : P.A.colptr[j + 1] - base); ++q, ++w) {
             R.rowidx[w] = (int32_t)(P.A.rowval[q] - base);
             R.val_orig[w] = P.A.nzval[q];
-            R.val[w] = P.A.nzval[q] * sc;
-            ss += R.val[w] * R.val[w];
         }
         for (int64_t q = P.G.colptr[j] - base; q < P.G.colptr[j + 1] - base; ++q, ++w) {
             R.rowidx[w] = (int32_t)(P.G.rowval[q] - base + P.p);
             R.val_orig[w] = P.G.nzval[q];
-            R.val[w] = P.G.nzval[q] * sc;
-            ss += R.val[w] * R.val[w];
         }
     }
     R.colptr[P.n] = w;
+    // ---- diagonal preconditioning (pdhg.jl:64-92): only ever active when forced, or when the
+    // smallest and largest entries of M (implicit zeros included) are within `equilibration_limit`
+    bool equil = opt != nullptr && opt->equilibration != 0;
+    if (equil) {
+        double hi = 0.0, lo = 0.0;
+        if (R.nnz > 0) {
+            hi = lo = R.val_orig[0];
+            for (double v : R.val_orig) { hi = std::max(hi, v); lo = std::min(lo, v); }
+            if (R.nnz < R.Q * R.n) { hi = std::max(hi, 0.0); lo = std::min(lo, 0.0); }
+        }
+        if (hi == 0.0 || lo / hi <= opt->equilibration_limit) equil = false;
+    }
+    if (opt != nullptr && opt->equilibration_force) equil = true;
+    if (equil) {
+        if (dense || P.reduce_fn != nullptr) throw std::domain_error("equilibration with a dense A or a block-sharded solve is not implemented");
+        if (R.Q == 0 || R.n == 0) throw std::invalid_argument("equilibration needs a non-empty M");
+        equilibrate_host(R, *opt, R.Ediag, R.Ddiag);
+        R.equilibrated = true;
+        for (int64_t i = 0; i < R.p; ++i) R.b[i] *= R.Ediag[i];
+        for (int64_t i = 0; i < R.m; ++i) R.h[i] *= R.Ediag[R.p + i];
+        for (int64_t k = 0; k < P.n; ++k) R.c[k] *= R.Ddiag[k];       // (c already carries the sqrt(2)/2 factor: it commutes)
+    }
+    double ss = 0.0;
+    for (int64_t k = 0; k < P.n; ++k) {
+        const double sc = R.offdiag[k] ? cte : 1.0;
+        for (int64_t q = R.colptr[k]; q < R.colptr[k + 1]; ++q) {
+            double v = R.val_orig[q];
+            if (equil) v = R.Ediag[R.rowidx[q]] * v * R.Ddiag[k];
+            R.val[q] = v * sc;
+            ss += R.val[q] * R.val[q];
+        }
+    }
     R.frob = std::sqrt(ss);
 
     // ---- CSR of the scaled M (counting sort; column order inside a row ascending)
@@ -189,6 +260,52 @@ inline Prep prepare(const proxsdp_problem& P) {
             R.rval[d] = R.val[q];
         }
     return R;
+}
+
+// sigma_max of the scaled M (approx_norm = false; the reference calls Arpack.svds(M, nsv=1),
+// pdhg.jl:108-119): Lanczos with full re-orthogonalisation on M'M from a fixed start vector,
+// stopped when the Ritz residual is below 1e-14 relative.  `symeig` = host_util's symeig_dense.
+template <typename SymEig>
+inline double spectral_norm_host(const Prep& R, SymEig symeig) {
+    const int64_t n = R.n, Q = R.Q;
+    if (n == 0 || Q == 0 || R.nnz == 0) return 0.0;
+    const int kmax = (int)std::min<int64_t>(std::min(n, Q), 120);
+    std::vector<std::vector<double>> V;
+    std::vector<double> al, be, v(n, 1.0 / std::sqrt((double)n)), u(Q), w(n);
+    double sigma2 = 0.0;
+    for (int k = 0; k < kmax; ++k) {
+        V.push_back(v);
+        std::fill(u.begin(), u.end(), 0.0);
+        for (int64_t c = 0; c < n; ++c)
+            for (int64_t q = R.colptr[c]; q < R.colptr[c + 1]; ++q) u[R.rowidx[q]] += R.val[q] * v[c];
+        for (int64_t c = 0; c < n; ++c) {
+            double acc = 0.0;
+            for (int64_t q = R.colptr[c]; q < R.colptr[c + 1]; ++q) acc += R.val[q] * u[R.rowidx[q]];
+            w[c] = acc;
+        }
+        double a = 0.0;
+        for (int64_t c = 0; c < n; ++c) a += w[c] * v[c];
+        al.push_back(a);
+        for (int pass = 0; pass < 2; ++pass)
+            for (const std::vector<double>& vj : V) {
+                double h = 0.0;
+                for (int64_t c = 0; c < n; ++c) h += vj[c] * w[c];
+                for (int64_t c = 0; c < n; ++c) w[c] -= h * vj[c];
+            }
+        double b = 0.0;
+        for (int64_t c = 0; c < n; ++c) b += w[c] * w[c];
+        b = std::sqrt(b);
+        const int K = k + 1;
+        std::vector<double> T((size_t)K * K, 0.0), d(K);
+        for (int i = 0; i < K; ++i) { T[(size_t)i * K + i] = al[i]; if (i + 1 < K) T[(size_t)i * K + i + 1] = T[(size_t)(i + 1) * K + i] = be[i]; }
+        symeig(K, T.data(), d.data());
+        sigma2 = d[K - 1];
+        const double resid = std::fabs(b * T[(size_t)(K - 1) * K + (K - 1)]);     // beta * last component of the top Ritz vector
+        if (b <= 1e-14 * std::max(1.0, std::fabs(sigma2)) || resid <= 1e-14 * std::fabs(sigma2)) break;
+        be.push_back(b);
+        for (int64_t c = 0; c < n; ++c) v[c] = w[c] / b;
+    }
+    return std::sqrt(std::max(sigma2, 0.0));
 }
 
 }  // namespace proxsdp

@@ -178,7 +178,7 @@ struct EigWork {
 class Solver {
 public:
     Solver(const proxsdp_problem& prob, const proxsdp_options& opt_in, proxsdp_result& res_out)
-        : opt(opt_in), res(res_out), P(prepare(prob)) {
+        : opt(opt_in), res(res_out), P(prepare(prob, &opt_in)) {
         time0 = now_s();
         user_resid = prob.eig_resid;
         reduce_fn = prob.reduce_fn;
@@ -329,6 +329,7 @@ private:
     DevBuf<int> supp_d;
     DevBuf<unsigned> mask_d;
     DevBuf<double> cS_d, xsave_d, MtyS_cur, MtyS_cand, ycand_d, respart_d, bpart, bscal;
+    DevBuf<double> Ediag_d, Ddiag_d; // equilibration diagonals (exit path)
     DevBuf<double> esv_d;            // [2][ns]: support values of E (update only | whole entry), k_primal_update_S
     // dense constraint matrix (proxsdp_problem.M_dense): borrowed device pointer or own upload
     const double* Md = nullptr;

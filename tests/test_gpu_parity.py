@@ -438,6 +438,35 @@ def test_operator_form_matvec_matches_packed_matvec(case):
         assert np.allclose(b.trace[:tight, [1, 2, 3, 4, 7, 11]], G[:tight], rtol=1e-7, atol=1e-10)
 
 
+@pytest.mark.parametrize("kw", [dict(equilibration_force=1), dict(approx_norm=0),
+                                dict(equilibration_force=1, approx_norm=0)])
+@pytest.mark.parametrize("build", ["sdp_wiki_min", "lp_in_SDP_inequality_form", "maxcut30", "mimo6"])
+def test_equilibration_and_spectral_norm_against_oracle(build, kw):
+    """equilibrate! (host, once) + un-scaling at the exit (pdhg.jl:64-92,751-755) and the
+    sigma_max step size (pdhg.jl:108-119: Arpack.svds in the reference, SciPy's ARPACK svds in
+    the oracle, a host Lanczos on M'M in the library)."""
+    pr = {"maxcut30": lambda: P.maxcut(30, seed=2), "mimo6": lambda: P.mimo(6, seed=1)}.get(build, None)
+    pr = pr() if pr else KATS[build][0]()
+    opt = Optimizer(tol_gap=1e-6, tol_feasibility=1e-6, **kw)
+    sol = opt.optimize(pr, trace_capacity=400)
+    o = Options()
+    o.tol_gap = o.tol_feasibility = 1e-6
+    for k, v in kw.items():
+        o.set(k, bool(v))
+    ref = oracle.solve(pr, o, trace=True)
+    assert sol.status == ref.status == 1
+    assert abs(sol.iter - ref.iter) <= max(2, 0.02 * ref.iter)
+    m = min(len(ref.trace), len(sol.trace), 40)
+    G, T = _trace_cols(ref.trace)[:m], sol.trace[:m, [1, 2, 3, 4, 7, 11]]
+    assert np.allclose(T, G, rtol=1e-6, atol=1e-9 * max(1.0, np.abs(G).max()))
+    assert abs(sol.objval - ref.objval) <= 1e-6 * (1 + abs(ref.objval))
+    sc = max(1.0, np.abs(ref.primal).max())
+    assert np.allclose(sol.primal, ref.primal, atol=2e-5 * sc)
+    assert np.allclose(sol.slack_eq, ref.slack_eq, atol=2e-5 * sc)
+    assert np.allclose(sol.dual_eq, ref.dual_eq, atol=2e-4 * max(1.0, np.abs(ref.dual_eq).max(initial=0.0)))
+    assert np.allclose(sol.dual_in, ref.dual_in, atol=2e-4 * max(1.0, np.abs(ref.dual_in).max(initial=0.0)))
+
+
 def test_blocks_wider_than_64_workgroups():
     """n = 4200 -> 66 row groups: the per-workgroup partial arrays no longer fit one wave-wide
     load (pld = 128) and the `n > 4096` branches of the Lanczos kernels run.  Eigenpairs against

@@ -197,3 +197,38 @@ def test_unbounded_lp_certificate():
     """pdhg.jl:407-422 + certificate search :184-244, :639-676."""
     r = oracle.solve(unbounded_lp(), _opt())
     assert r.status == 5 and r.certificate_found
+
+
+# ----------------------------------------------------------------- off-by-default preprocessing variants
+@pytest.mark.parametrize("name", ["simple_lp", "sdp_wiki_min", "lp_in_SDP_equality_form", "double_sdp_from_moi"])
+@pytest.mark.parametrize("kw", [dict(equilibration_force=True), dict(approx_norm=False)])
+def test_known_answers_with_equilibration_and_spectral_norm(name, kw):
+    """equilibrate! (equilibration.jl, pdhg.jl:64-92,751-755) and the svds step size
+    (pdhg.jl:108-119).  The reference's tests never switch these on (parity unpinned beyond
+    this): the known answers must be invariant under them."""
+    build, expected, atol, xexp = KATS[name]
+    r = oracle.solve(build(), _opt(**kw))
+    assert r.status == 1 and abs(r.objval - expected) <= atol
+    assert r.primal_feasible_user_tol and r.dual_feasible_user_tol
+    if xexp is not None:
+        assert np.allclose(r.primal, xexp, atol=atol)
+
+
+def test_equilibration_switches_itself_off_and_scales_uniformly():
+    """pdhg.jl:66-73: `equilibration=true` survives only if min(M)/max(M) > equilibration_limit
+    (implicit zeros count), so on any sparse M it is a no-op unless forced; equilibration.jl:56-58
+    averages v, so D is a multiple of the identity."""
+    from oracle import pdhg as opdhg
+    pr = P.maxcut(12, seed=1)
+    a = oracle.solve(pr, _opt(equilibration=True))
+    b = oracle.solve(pr, _opt())
+    assert a.iter == b.iter and a.objval == b.objval
+    aff, cones = oracle.to_standard_form(pr)
+    o = Options()
+    Ed, Dd = opdhg.equilibrate(sp_vstack(aff), aff, o)
+    assert np.allclose(Dd, Dd[0]) and Dd[0] >= 1.0 and np.all(Ed > 0)
+
+
+def sp_vstack(aff):
+    import scipy.sparse as sp
+    return sp.vstack([aff.A, aff.G], format="csc")
