@@ -284,6 +284,26 @@ int proxsdp_hip_reconstruct(const double* Z, const double* lambda, int64_t n, in
 int proxsdp_hip_spmv(const proxsdp_csc* M, int32_t index_base, int32_t transpose,
                      const double* in, double* out);
 
+/* x_out = x - tau (Mty + c)   (primal_step!, pdhg.jl:622; fused AXPY kernel, FP contraction off) */
+int proxsdp_hip_primal_update(const double* x, const double* Mty, const double* c, double tau, int64_t n,
+                              double* x_out);
+
+/* one linesearch trial in y-space (pdhg.jl:547-553 + box_projection!, prox_operators.jl:160-170):
+ *   ybar = y + bt ((1+theta) Mx - theta Mx_old);  y_out = ybar - bt * box(ybar / bt)
+ * with box = b on the first p rows and min(., h) on the rest (bh = [b;h]);
+ * ynorm2 = |y_out - y|^2 (the right-hand side of the acceptance test, :566) */
+int proxsdp_hip_dual_trial(const double* y, const double* Mx, const double* Mx_old, const double* bh,
+                           int64_t p, int64_t Q, double bt, double theta, double* y_out, double* ynorm2);
+
+/* compute_residual! + compute_gap! (residuals.jl:2-71), the reductions only.  out[9]:
+ *   0 max|(x - tau Mty) - (x_old - tau Mty_old)|   1 max|x_old - tau Mty_old|   2 c'x
+ *   3 max|(y - sigma Mx) - (y_old - sigma Mx_old)| 4 max|y_old - sigma Mx_old|
+ *   5 max|Mx - b| (equalities)  6 max(0, max(Mx - h)) (inequalities)  7 b'y_eq  8 h'y_in */
+int proxsdp_hip_residuals(const double* x, const double* x_old, const double* Mty, const double* Mty_old,
+                          const double* c, double tau, int64_t n,
+                          const double* y, const double* y_old, const double* Mx, const double* Mx_old,
+                          const double* bh, int64_t p, int64_t Q, double sigma, double* out);
+
 /* ------------------------------------------- host-only helpers (no GPU needed;
  * exercised by the CPU test-suite) */
 /* eigen-decomposition of a small dense symmetric matrix (column-major k x k,

@@ -377,6 +377,37 @@ def symv_packed(packed, n, v, repeat=0):
     return (y, ms.value) if repeat else y
 
 
+def primal_update(x, Mty, c, tau):
+    L = lib()
+    x, Mty, c = _f(x), _f(Mty), _f(c)
+    out = np.zeros_like(x)
+    L.proxsdp_hip_primal_update.argtypes = [pf64, pf64, pf64, f64, i64, pf64]
+    _check(L.proxsdp_hip_primal_update(_p(x), _p(Mty), _p(c), float(tau), len(x), _p(out)))
+    return out
+
+
+def dual_trial(y, Mx, Mx_old, bh, p, bt, theta):
+    L = lib()
+    y, Mx, Mx_old, bh = _f(y), _f(Mx), _f(Mx_old), _f(bh)
+    out = np.zeros_like(y)
+    nrm = f64(0.0)
+    L.proxsdp_hip_dual_trial.argtypes = [pf64, pf64, pf64, pf64, i64, i64, f64, f64, pf64, pf64]
+    _check(L.proxsdp_hip_dual_trial(_p(y), _p(Mx), _p(Mx_old), _p(bh), int(p), len(y), float(bt), float(theta),
+                                    _p(out), C.byref(nrm)))
+    return out, nrm.value
+
+
+def residuals(x, x_old, Mty, Mty_old, c, tau, y, y_old, Mx, Mx_old, bh, p, sigma):
+    L = lib()
+    a = [_f(v) for v in (x, x_old, Mty, Mty_old, c)]
+    b = [_f(v) for v in (y, y_old, Mx, Mx_old, bh)]
+    out = np.zeros(9)
+    L.proxsdp_hip_residuals.argtypes = [pf64] * 5 + [f64, i64] + [pf64] * 5 + [i64, i64, f64, pf64]
+    _check(L.proxsdp_hip_residuals(*[_p(v) for v in a], float(tau), len(a[0]), *[_p(v) for v in b],
+                                   int(p), len(b[0]), float(sigma), _p(out)))
+    return out
+
+
 def reconstruct(Z, lam, n, repeat=0):
     L = lib()
     Zc = np.asfortranarray(Z, dtype=np.float64)

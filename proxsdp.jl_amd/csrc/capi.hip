@@ -273,6 +273,80 @@ int proxsdp_hip_spmv(const proxsdp_csc* M, int32_t index_base, int32_t transpose
     });
 }
 
+int proxsdp_hip_primal_update(const double* x, const double* Mty, const double* c, double tau, int64_t n,
+                              double* x_out) {
+    return guarded([&]() -> int {
+        if (n < 0 || (n > 0 && (!x || !Mty || !c || !x_out))) throw std::invalid_argument("invalid argument");
+        if (n == 0) return 0;
+        Engine E(nullptr, 2, 2);
+        hipStream_t st = E.S.stream;
+        proxsdp::DevBuf<double> dx(n), dm(n), dc(n), dout(n);
+        dx.upload(x, n, st); dm.upload(Mty, n, st); dc.upload(c, n, st);
+        hipLaunchKernelGGL(proxsdp::dev::k_primal_update, dim3(proxsdp::grid_for(n)), dim3(proxsdp::dev::TPB), 0, st,
+                           dout.p, (const double*)dx.p, (const double*)dm.p, (const double*)dc.p, tau, (long long)n);
+        dout.download(x_out, n, st);
+        PX_HIP(hipStreamSynchronize(st));
+        return 0;
+    });
+}
+
+int proxsdp_hip_dual_trial(const double* y, const double* Mx, const double* Mx_old, const double* bh,
+                           int64_t p, int64_t Q, double bt, double theta, double* y_out, double* ynorm2) {
+    return guarded([&]() -> int {
+        if (Q <= 0 || p < 0 || p > Q || !y || !Mx || !Mx_old || !bh || !y_out) throw std::invalid_argument("invalid argument");
+        Engine E(nullptr, 2, 2);
+        hipStream_t st = E.S.stream;
+        const int g = std::min(proxsdp::PSTRIDE, proxsdp::grid_for(Q));
+        proxsdp::DevBuf<double> dy(Q), d1(Q), d0(Q), dbh(Q), dout(Q), part(proxsdp::PSTRIDE), sc(2);
+        dy.upload(y, Q, st); d1.upload(Mx, Q, st); d0.upload(Mx_old, Q, st); dbh.upload(bh, Q, st);
+        part.zero(st);
+        hipLaunchKernelGGL(proxsdp::dev::k_dual_trial, dim3(g), dim3(proxsdp::dev::TPB), 0, st,
+                           (const double*)dy.p, (const double*)d1.p, (const double*)d0.p, (const double*)dbh.p,
+                           (int)p, (int)Q, bt, theta, dout.p, part.p);
+        hipLaunchKernelGGL(proxsdp::dev::k_combine, dim3(1), dim3(proxsdp::dev::TPB), 0, st,
+                           (const double*)part.p, proxsdp::PSTRIDE, g, 1, 0u, sc.p);
+        dout.download(y_out, Q, st);
+        double nrm = 0.0;
+        sc.download(&nrm, 1, st);
+        PX_HIP(hipStreamSynchronize(st));
+        if (ynorm2) *ynorm2 = nrm;
+        return 0;
+    });
+}
+
+int proxsdp_hip_residuals(const double* x, const double* x_old, const double* Mty, const double* Mty_old,
+                          const double* c, double tau, int64_t n,
+                          const double* y, const double* y_old, const double* Mx, const double* Mx_old,
+                          const double* bh, int64_t p, int64_t Q, double sigma, double* out) {
+    return guarded([&]() -> int {
+        if (n <= 0 || Q <= 0 || p < 0 || p > Q || !x || !x_old || !Mty || !Mty_old || !c || !y || !y_old || !Mx ||
+            !Mx_old || !bh || !out) throw std::invalid_argument("invalid argument");
+        Engine E(nullptr, 2, 2);
+        hipStream_t st = E.S.stream;
+        using proxsdp::DevBuf;
+        const int gx = std::min(proxsdp::PSTRIDE, proxsdp::grid_for(n)), gq = std::min(proxsdp::PSTRIDE, proxsdp::grid_for(Q));
+        DevBuf<double> dx(n), dxo(n), dm(n), dmo(n), dc(n), dy(Q), dyo(Q), d1(Q), d0(Q), dbh(Q);
+        DevBuf<double> part((size_t)9 * proxsdp::PSTRIDE), sc(9);
+        dx.upload(x, n, st); dxo.upload(x_old, n, st); dm.upload(Mty, n, st); dmo.upload(Mty_old, n, st); dc.upload(c, n, st);
+        dy.upload(y, Q, st); dyo.upload(y_old, Q, st); d1.upload(Mx, Q, st); d0.upload(Mx_old, Q, st); dbh.upload(bh, Q, st);
+        part.zero(st);
+        // the kernels lay their quantities out with stride gridDim.x: run both with PSTRIDE-strided combines
+        hipLaunchKernelGGL(proxsdp::dev::k_residual_x, dim3(gx), dim3(proxsdp::dev::TPB), 0, st,
+                           (const double*)dx.p, (const double*)dxo.p, 1.0, (const double*)dm.p, (const double*)dmo.p,
+                           (const double*)dc.p, tau, (long long)n, part.p);
+        hipLaunchKernelGGL(proxsdp::dev::k_combine, dim3(1), dim3(proxsdp::dev::TPB), 0, st,
+                           (const double*)part.p, gx, gx, 3, 0x3u, sc.p);
+        hipLaunchKernelGGL(proxsdp::dev::k_residual_y, dim3(gq), dim3(proxsdp::dev::TPB), 0, st,
+                           (const double*)dy.p, (const double*)dyo.p, (const double*)d1.p, (const double*)d0.p,
+                           (const double*)dbh.p, (int)p, (int)Q, sigma, part.p + (size_t)3 * proxsdp::PSTRIDE);
+        hipLaunchKernelGGL(proxsdp::dev::k_combine, dim3(1), dim3(proxsdp::dev::TPB), 0, st,
+                           (const double*)(part.p + (size_t)3 * proxsdp::PSTRIDE), gq, gq, 6, 0xFu, sc.p + 3);
+        sc.download(out, 9, st);
+        PX_HIP(hipStreamSynchronize(st));
+        return 0;
+    });
+}
+
 int proxsdp_host_symeig(int32_t k, double* a, double* d) {
     if (k < 0 || !a || !d) { g_last_error = "invalid argument"; return PROXSDP_E_INVALID; }
     int rc = proxsdp::symeig_dense(k, a, d);

@@ -88,6 +88,38 @@ def test_spmv_both_orientations():
     assert _rel(B.spmv(M, x), M @ x) < 1e-13
 
 
+def test_vector_kernels_against_oracle_functions():
+    """Kernel-level seams of SURVEY section 8b: primal update (pdhg.jl:622), one linesearch
+    trial in y-space (pdhg.jl:547-553 + box_projection!) and the residual / gap reductions
+    (residuals.jl:2-71) against the oracle's own functions on random data."""
+    rng = np.random.default_rng(5)
+    n, p, m = 70001, 3001, 2500
+    Q = p + m
+    x, x_old, Mty, Mty_old, c = (rng.standard_normal(n) for _ in range(5))
+    y, y_old, Mx, Mx_old = (rng.standard_normal(Q) for _ in range(4))
+    b, h = rng.standard_normal(p), rng.standard_normal(m)
+    bh = np.concatenate([b, h])
+    tau, beta, theta = 0.37, 1.7, 0.8
+    # primal update: the oracle statement is x .-= tau .* (Mty .+ c)
+    assert np.array_equal(B.primal_update(x, Mty, c, tau), x - tau * (Mty + c))
+    # dual trial
+    bt = beta * tau
+    ybar = y + bt * ((1.0 + theta) * Mx - theta * Mx_old)
+    proj = np.concatenate([b, np.minimum(ybar[p:] / bt, h)])     # box_projection!(ybar/bt) (prox_operators.jl:160-170)
+    yref = ybar - bt * proj
+    yout, nrm = B.dual_trial(y, Mx, Mx_old, bh, p, bt, theta)
+    assert np.allclose(yout, yref, rtol=1e-14, atol=1e-14)
+    assert nrm == pytest.approx(np.sum((yref - y) ** 2), rel=1e-12)
+    # residuals + gap reductions
+    sigma = bt
+    out = B.residuals(x, x_old, Mty, Mty_old, c, tau, y, y_old, Mx, Mx_old, bh, p, sigma)
+    Px, Pxo = x - tau * Mty, x_old - tau * Mty_old
+    Py, Pyo = y - sigma * Mx, y_old - sigma * Mx_old
+    ref = [np.abs(Px - Pxo).max(), np.abs(Pxo).max(), c @ x, np.abs(Py - Pyo).max(), np.abs(Pyo).max(),
+           np.abs(Mx[:p] - b).max(), max(0.0, (Mx[p:] - h).max()), b @ y[:p], h @ y[p:]]
+    assert np.allclose(out, ref, rtol=1e-12, atol=1e-12)
+
+
 # ----------------------------------------------------------------- eigen layer
 @pytest.mark.parametrize("n,nev,top", [
     (101, 2, [40.0, 25.0, 9.0, 4.0]),
