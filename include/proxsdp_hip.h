@@ -172,7 +172,8 @@ typedef struct proxsdp_options {
                                 * iterate (what dsymv('U') reads, 8 N bytes), 1 = operator form
                                 * x_prev(low rank) + sparse update when available (support path;
                                 * DESIGN.md section 4), -1 auto = 1 (default) */
-    int32_t reserved2;
+    int32_t initial_target_rank; /* reference: 2, hard-coded (pdhg.jl:19-20); a benchmark may start at the
+                                  * rank a config names ("rank ~ sqrt(n)"); capped at the block side */
 } proxsdp_options;
 
 #define PROXSDP_TRACE_COLS 14

@@ -104,6 +104,9 @@ class Options:
     equilibration_limit: float = 0.9
     equilibration_force: bool = False
     approx_norm: bool = True
+    # no reference counterpart (pdhg.jl:19-20 hard-codes 2): lets a benchmark start at the rank a
+    # BASELINE config names ("rank ~ sqrt(n)", "target rank 50"); mirrored by the library
+    initial_target_rank: int = 2
 
     def set(self, name, value):
         """MOI.set(::Optimizer, ::RawOptimizerAttribute) semantics

@@ -581,7 +581,8 @@ def chambolle_pock(aff_in, cones, opt_in=None, *, eig_resid=None, trace=False,
     p.rank_update, p.stop_reason, p.update_cont = 0, 0, 0
     p.stop_reason_string = "Not optimized"
     nb = len(cones.sdpcone)
-    p.target_rank = 2 * np.ones(nb, dtype=np.int64)
+    p.target_rank = np.array([min(max(int(opt.initial_target_rank), 1), s_.sq_side) for s_ in cones.sdpcone], dtype=np.int64) \
+        if nb else np.zeros(0, dtype=np.int64)
     p.current_rank = 2 * np.ones(nb, dtype=np.int64)
     p.min_eig = np.zeros(nb)
     p.dual_feasibility = -1.0

@@ -100,7 +100,7 @@ def _opt_fields():
     a("equilibration_lb", f64); a("equilibration_ub", f64); a("equilibration_limit", f64)
     a("equilibration_force", i32); a("approx_norm", i32)
     a("device_id", i32); a("trace_capacity", i32); a("profile_symv_every", i32); a("support_path", i32)
-    a("lanczos_operator", i32); a("pad7", i32)
+    a("lanczos_operator", i32); a("initial_target_rank", i32)
     return F
 
 

@@ -234,7 +234,7 @@ inline const std::vector<OptEntry>& option_table() {
         PX_OPT(equilibration_lb, OT_F64), PX_OPT(equilibration_ub, OT_F64), PX_OPT(equilibration_limit, OT_F64),
         PX_OPT(equilibration_force, OT_I32), PX_OPT(approx_norm, OT_I32),
         PX_OPT(device_id, OT_I32), PX_OPT(trace_capacity, OT_I32), PX_OPT(profile_symv_every, OT_I32),
-        PX_OPT(support_path, OT_I32), PX_OPT(lanczos_operator, OT_I32),
+        PX_OPT(support_path, OT_I32), PX_OPT(lanczos_operator, OT_I32), PX_OPT(initial_target_rank, OT_I32),
     };
     return t;
 }
@@ -271,7 +271,7 @@ inline void default_options(proxsdp_options* o) {      // options.jl:1-132
     o->equilibration_ub = 10.0; o->equilibration_limit = 0.9; o->equilibration_force = 0;
     o->approx_norm = 1;
     o->device_id = 0; o->trace_capacity = 0; o->profile_symv_every = 0; o->support_path = -1;
-    o->lanczos_operator = -1; o->reserved2 = 0;
+    o->lanczos_operator = -1; o->initial_target_rank = 2;
 }
 
 inline int set_option(proxsdp_options* o, const char* name, double v) {

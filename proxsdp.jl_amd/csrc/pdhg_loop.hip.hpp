@@ -816,6 +816,8 @@ inline void Solver::run() {
     const int window = opt.convergence_window;
     const size_t nb = P.blocks.size();
     target_rank.assign(nb, 2); current_rank.assign(nb, 2); min_eig.assign(nb, 0.0);
+    for (size_t idx = 0; idx < nb; ++idx)               // 2 in the reference (pdhg.jl:19-20)
+        target_rank[idx] = std::min<long long>(std::max(opt.initial_target_rank, 1), P.blocks[idx].n);
     time_limit = opt.time_limit;
     {   // global constants (sums over shards of a block-sharded solve; local values otherwise)
         std::vector<double> sums = {(double)P.n, (double)P.p, (double)P.m, P.norm_b * P.norm_b, P.norm_h * P.norm_h,
