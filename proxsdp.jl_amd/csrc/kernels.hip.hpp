@@ -996,23 +996,54 @@ k_soc_gap(const double* __restrict__ x, const long long* __restrict__ soc_off, c
     if (threadIdx.x == 0) out[blockIdx.x] = sqrt(tot) - x[off];
 }
 
-// Mx = M x, M in CSR.  Thread-per-row (short rows) and wave-per-row (long rows)
-// variants; pdhg.jl:634 (the reference does a CSC scatter in pure Julia).
+// Mx = M x, M in CSR; pdhg.jl:634 (the reference does a CSC scatter in pure Julia).  Three row
+// classes: thread-per-row (short rows), wave-per-row (medium), and rows longer than
+// `long_thresh` (gpp500-1 has one all-ones row of 125 250 entries) which the two kernels skip:
+// those are cut into segments of SPMV_SEG entries, one workgroup per segment with the products
+// reduced through LDS (k_spmv_csr_seg), and a fixed-order sum of the segment partials per row
+// (k_spmv_seg_fin): parallel width for the long row, still deterministic.
+constexpr int SPMV_SEG = 4096;
+__global__ void __launch_bounds__(TPB)
+k_spmv_csr_seg(const int* __restrict__ seg_lo, const int* __restrict__ seg_hi, const int* __restrict__ col,
+               const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ segpart) {
+    __shared__ double sm[NWAVE];
+    const int lo = seg_lo[blockIdx.x], hi = seg_hi[blockIdx.x];
+    double a0 = 0.0, a1 = 0.0;
+    int k = lo + threadIdx.x;
+    for (; k + TPB < hi; k += 2 * TPB) {
+        a0 += val[k] * x[col[k]];
+        a1 += val[k + TPB] * x[col[k + TPB]];
+    }
+    if (k < hi) a0 += val[k] * x[col[k]];
+    const double tot = block_sum(a0 + a1, sm);
+    if (threadIdx.x == 0) segpart[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(TPB)
+k_spmv_seg_fin(const int* __restrict__ long_row, const int* __restrict__ long_ptr, int nlong,
+               const double* __restrict__ segpart, double* __restrict__ y) {
+    const int r = blockIdx.x * TPB + threadIdx.x;
+    if (r >= nlong) return;
+    double a = 0.0;
+    for (int sg = long_ptr[r]; sg < long_ptr[r + 1]; ++sg) a += segpart[sg];
+    y[long_row[r]] = a;
+}
 __global__ void __launch_bounds__(TPB)
 k_spmv_csr_thread(const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val,
-                  const double* __restrict__ x, double* __restrict__ y, int nrows) {
+                  const double* __restrict__ x, double* __restrict__ y, int nrows, int long_thresh) {
     int r = blockIdx.x * TPB + threadIdx.x;
     if (r >= nrows) return;
+    if (rowptr[r + 1] - rowptr[r] > long_thresh) return;      // segmented path
     double acc = 0.0;
     for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) acc += val[k] * x[col[k]];
     y[r] = acc;
 }
 __global__ void __launch_bounds__(TPB)
 k_spmv_csr_wave(const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val,
-                const double* __restrict__ x, double* __restrict__ y, int nrows) {
+                const double* __restrict__ x, double* __restrict__ y, int nrows, int long_thresh) {
     const int lane = threadIdx.x & 63;
     int r = blockIdx.x * NWAVE + (threadIdx.x >> 6);
     if (r >= nrows) return;
+    if (rowptr[r + 1] - rowptr[r] > long_thresh) return;      // segmented path
     double acc = 0.0;
     for (int k = rowptr[r] + lane; k < rowptr[r + 1]; k += WAVE) acc += val[k] * x[col[k]];
     acc = wave_sum(acc);

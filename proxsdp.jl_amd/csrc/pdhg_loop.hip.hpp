@@ -18,10 +18,32 @@ inline void Solver::spmv_sparse(const double* x, double* y) {
     if (P.Q == 0) return;
     if (csr_wave)
         hipLaunchKernelGGL(dev::k_spmv_csr_wave, dim3(ceil_div(P.Q, dev::NWAVE)), dim3(dev::TPB), 0, stream,
-                           csr_ptr.p, csr_col.p, csr_val.p, x, y, (int)P.Q);
+                           csr_ptr.p, csr_col.p, csr_val.p, x, y, (int)P.Q, LONG_ROW);
     else
         hipLaunchKernelGGL(dev::k_spmv_csr_thread, dim3(ceil_div(P.Q, dev::TPB)), dim3(dev::TPB), 0, stream,
-                           csr_ptr.p, csr_col.p, csr_val.p, x, y, (int)P.Q);
+                           csr_ptr.p, csr_col.p, csr_val.p, x, y, (int)P.Q, LONG_ROW);
+    if (n_seg > 0) {
+        hipLaunchKernelGGL(dev::k_spmv_csr_seg, dim3(n_seg), dim3(dev::TPB), 0, stream,
+                           seg_lo_d.p, seg_hi_d.p, csr_col.p, csr_val.p, x, segpart_d.p);
+        hipLaunchKernelGGL(dev::k_spmv_seg_fin, dim3(ceil_div(n_long, dev::TPB)), dim3(dev::TPB), 0, stream,
+                           long_row_d.p, long_ptr_d.p, n_long, segpart_d.p, y);
+    }
+}
+// rows with more than LONG_ROW entries -> segments of SPMV_SEG entries
+inline void Solver::setup_long_rows(const std::vector<int>& rp) {
+    std::vector<int> lo, hi, rows, ptr{0};
+    for (int64_t r = 0; r < P.Q; ++r) {
+        if (rp[r + 1] - rp[r] <= LONG_ROW) continue;
+        rows.push_back((int)r);
+        for (int k = rp[r]; k < rp[r + 1]; k += dev::SPMV_SEG) { lo.push_back(k); hi.push_back(std::min(k + dev::SPMV_SEG, rp[r + 1])); }
+        ptr.push_back((int)lo.size());
+    }
+    n_seg = (int)lo.size(); n_long = (int)rows.size();
+    if (n_seg == 0) return;
+    seg_lo_d.alloc(n_seg); seg_hi_d.alloc(n_seg); long_row_d.alloc(n_long); long_ptr_d.alloc(n_long + 1); segpart_d.alloc(n_seg);
+    seg_lo_d.upload(lo.data(), n_seg, stream); seg_hi_d.upload(hi.data(), n_seg, stream);
+    long_row_d.upload(rows.data(), n_long, stream); long_ptr_d.upload(ptr.data(), n_long + 1, stream);
+    PX_HIP(hipStreamSynchronize(stream));
 }
 
 // psd_projection! (prox_operators.jl:33-66), one block: reads the packed block of xin,
@@ -794,6 +816,7 @@ inline void Solver::test_spmv(bool transpose, const double* in, double* out) {
     csr_col.upload(P.colidx.data(), P.nnz, stream); csr_val.upload(P.rval.data(), P.nnz, stream);
     csc_row.upload(P.rowidx.data(), P.nnz, stream); csc_val.upload(P.val.data(), P.nnz, stream);
     csr_wave = P.Q > 0 && (double)P.nnz / (double)P.Q > 8.0;
+    setup_long_rows(rp);
     DevBuf<double> xin(std::max<int64_t>(transpose ? P.Q : P.n, 1)), xout(std::max<int64_t>(transpose ? P.n : P.Q, 1));
     xin.upload(in, transpose ? P.Q : P.n, stream);
     if (transpose)
@@ -876,6 +899,7 @@ inline void Solver::run() {
         csc_row.upload(P.rowidx.data(), P.nnz, stream); csc_val.upload(P.val.data(), P.nnz, stream);
         PX_HIP(hipStreamSynchronize(stream));
         csr_wave = P.Q > 0 && (double)P.nnz / (double)P.Q > 8.0;
+        setup_long_rows(rp);
     }
     eig.resize(nb);
     {

@@ -277,6 +277,12 @@ private:
     std::vector<int> big_blocks;               // indices of the blocks that are projected by an eigensolver
     std::vector<double> hscal;
     bool csr_wave = false;
+    // rows longer than LONG_ROW entries: segmented SpMV (kernels.hip.hpp k_spmv_csr_seg)
+    static constexpr int LONG_ROW = 8192;
+    DevBuf<int> seg_lo_d, seg_hi_d, long_row_d, long_ptr_d;
+    DevBuf<double> segpart_d;
+    int n_seg = 0, n_long = 0;
+    void setup_long_rows(const std::vector<int>& rp);
 
     // scalar state (Params, structs.jl:159-192)
     double theta = 1, beta = 1, adapt_level = 0.9, primal_step = 0, primal_step_old = 0, dual_step = 0;

@@ -86,6 +86,16 @@ def test_spmv_both_orientations():
     M = M.tocsc()
     x = rng.standard_normal(20000)
     assert _rel(B.spmv(M, x), M @ x) < 1e-13
+    # several rows beyond the segment threshold (8192 entries), random values, mixed with short
+    # and medium rows: segmented workgroup-per-4096-entries path + fixed-order combination
+    cols = 140000
+    rows = [rng.choice(cols, size=k, replace=False) for k in (9000, 130000, 3, 700, 8192, 8193)]
+    r = np.concatenate([np.full(len(c), i) for i, c in enumerate(rows)])
+    M = sp.csc_matrix((rng.standard_normal(len(r)), (r, np.concatenate(rows))), shape=(len(rows) + 2, cols))
+    x = rng.standard_normal(cols)
+    assert _rel(B.spmv(M, x), M @ x) < 1e-13
+    y = rng.standard_normal(M.shape[0])
+    assert _rel(B.spmv(M, y, transpose=True), M.T @ y) < 1e-13
 
 
 def test_vector_kernels_against_oracle_functions():
