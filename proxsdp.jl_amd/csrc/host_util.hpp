@@ -63,17 +63,15 @@ inline void start_vector(int64_t n, uint64_t seed, int init, double* out) {
 // (Measured: AVX-512 clones of this routine are slower than the AVX2 build at K ~ 50; half of
 // the QL time is the scalar rotation set-up, hence plain sqrt instead of hypot below -- the
 // Rayleigh-quotient entries are O(|X|), far from the overflow range hypot guards against.)
-inline int symeig_dense(int n, double* a, double* d, bool tridiagonal = false) {
-    if (n <= 0) return 0;
-    if (n == 1) { d[0] = a[0]; a[0] = 1.0; return 0; }
-    std::vector<double> e(n, 0.0);
+// Phase 1: Householder reduction of a (column-major, full symmetric storage) to tridiagonal form;
+// on exit a holds the accumulated orthogonal transform Q (a_in = Q T Q'), d the diagonal and
+// e[i] the coupling between i-1 and i (e[0] = 0).  The reflectors only ever act on the leading
+// coordinates of a row, so for an arrow matrix [D f; f' c] the last coordinate is left alone:
+// Q = blkdiag(Q~, 1) and d[n-1] = c -- which lets the Lanczos driver reduce the arrow part of a
+// restarted Rayleigh quotient before the rest of it exists (see symeig_tridiag_from).
+inline void householder_tridiag(int n, double* a, double* d, double* e) {
     auto V = [&](int i, int j) -> double& { return a[(size_t)j * n + i]; };
-    if (tridiagonal) {
-        for (int j = 0; j < n; ++j) d[j] = V(j, j);
-        for (int j = 1; j < n; ++j) e[j] = V(j, j - 1);
-        std::fill(a, a + (size_t)n * n, 0.0);
-        for (int j = 0; j < n; ++j) V(j, j) = 1.0;
-    } else {
+    if (n == 1) { d[0] = a[0]; e[0] = 0.0; a[0] = 1.0; return; }
     // ---- Householder reduction to tridiagonal form (accumulating the transform)
     for (int j = 0; j < n; ++j) d[j] = V(n - 1, j);
     for (int i = n - 1; i > 0; --i) {
@@ -128,8 +126,14 @@ inline int symeig_dense(int n, double* a, double* d, bool tridiagonal = false) {
     for (int j = 0; j < n; ++j) { d[j] = V(n - 1, j); V(n - 1, j) = 0.0; }
     V(n - 1, n - 1) = 1.0;
     e[0] = 0.0;
-    }
-    // ---- implicit-shift QL on the tridiagonal (d, e), accumulating into V
+}
+
+// Phase 2: implicit-shift QL on the tridiagonal (d, e as left by phase 1), accumulating the
+// rotations into the n x n matrix a (which must hold the transform so far: Q, or the identity).
+// On exit columns of a are orthonormal eigenvectors, d ascending.  Returns 0, or 1 if QL failed.
+inline int ql_implicit(int n, double* a, double* d, double* e_in) {
+    auto V = [&](int i, int j) -> double& { return a[(size_t)j * n + i]; };
+    std::vector<double> e(e_in, e_in + n);
     for (int i = 1; i < n; ++i) e[i - 1] = e[i];
     e[n - 1] = 0.0;
     double f = 0.0, tst1 = 0.0;
@@ -190,6 +194,42 @@ inline int symeig_dense(int n, double* a, double* d, bool tridiagonal = false) {
         }
     }
     return rc;
+}
+
+inline int symeig_dense(int n, double* a, double* d, bool tridiagonal = false) {
+    if (n <= 0) return 0;
+    if (n == 1) { d[0] = a[0]; a[0] = 1.0; return 0; }
+    std::vector<double> e(n, 0.0);
+    auto V = [&](int i, int j) -> double& { return a[(size_t)j * n + i]; };
+    if (tridiagonal) {
+        for (int j = 0; j < n; ++j) d[j] = V(j, j);
+        for (int j = 1; j < n; ++j) e[j] = V(j, j - 1);
+        std::fill(a, a + (size_t)n * n, 0.0);
+        for (int j = 0; j < n; ++j) V(j, j) = 1.0;
+    } else {
+        householder_tridiag(n, a, d, e.data());
+    }
+    return ql_implicit(n, a, d, e.data());
+}
+
+// Eigen-decomposition of the restarted Rayleigh quotient
+//     T = [ diag(D)  f   0 ;  f'  alpha_m  beta_m e1' ;  0  beta_m e1  tridiag(alpha, beta) ]   (K x K, m = keep)
+// from a PRE-REDUCED arrow part: Qa ((m+1) x (m+1), column-major), da, ea = householder_tridiag of
+// [diag(D) f; f' 0], computed while the GPU was still running the Lanczos steps of the cycle.
+// al[m..K), be[m..K-1) are the recurrence coefficients of the new steps.  U (K x K) receives the
+// eigenvectors, d the ascending eigenvalues.
+inline int symeig_tridiag_from(int K, int m, const double* Qa, const double* da, const double* ea,
+                               const double* al, const double* be, double* U, double* d) {
+    std::vector<double> e(K, 0.0);
+    std::fill(U, U + (size_t)K * K, 0.0);
+    for (int c = 0; c <= m; ++c)
+        for (int r = 0; r <= m; ++r) U[(size_t)c * K + r] = Qa[(size_t)c * (m + 1) + r];
+    for (int j = m + 1; j < K; ++j) U[(size_t)j * K + j] = 1.0;
+    for (int j = 0; j < m; ++j) d[j] = da[j];
+    for (int j = m; j < K; ++j) d[j] = al[j];
+    for (int j = 1; j <= m; ++j) e[j] = ea[j];
+    for (int j = m + 1; j < K; ++j) e[j] = be[j - 1];
+    return ql_implicit(K, U, d, e.data());
 }
 
 // ------------------------------------------------------------------ options
