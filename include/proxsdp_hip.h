@@ -311,6 +311,13 @@ int proxsdp_hip_residuals(const double* x, const double* x_old, const double* Mt
  * overwritten by eigenvectors; d ascending) -- the K x K Rayleigh quotient of
  * the thick-restart Lanczos */
 int proxsdp_host_symeig(int32_t k, double* a, double* d);
+/* eigen-decomposition of a thick-restarted Rayleigh quotient
+ *   T = [diag(D) f 0; f' al[m] be[m] e1'; 0 be[m] e1 tridiag(al[m+1..], be[m+1..])]   (K x K)
+ * through the two-phase path the Lanczos driver uses (arrow part reduced first, QL afterwards);
+ * U (K x K column-major) eigenvectors, d ascending eigenvalues.  al, be are indexed by step (entries
+ * below m unused). */
+int proxsdp_host_symeig_arrow(int32_t K, int32_t m, const double* D, const double* f,
+                              const double* al, const double* be, double* U, double* d);
 /* the library's Lanczos start vector (init 3/2/1 as options.jl:98-103) */
 int proxsdp_host_start_vector(int64_t n, int64_t seed, int32_t init, double* out);
 /* preprocess!/norm_scaling (scaling.jl): returns the variable order, the

@@ -441,6 +441,18 @@ def host_symeig(A):
     return d, a
 
 
+def host_symeig_arrow(D, f, al, be):
+    """Two-phase eigen-decomposition of a thick-restarted Rayleigh quotient (see the header)."""
+    L = lib()
+    D, f, al, be = _f(D), _f(f), _f(al), _f(be)
+    K, m = len(al), len(D)
+    U = np.zeros((K, K), order="F")
+    d = np.zeros(K)
+    L.proxsdp_host_symeig_arrow.argtypes = [i32, i32, pf64, pf64, pf64, pf64, pf64, pf64]
+    _check(L.proxsdp_host_symeig_arrow(K, m, _p(D), _p(f), _p(al), _p(be), U.ctypes.data_as(pf64), _p(d)))
+    return d, U
+
+
 def host_start_vector(n, seed=1234, init=3):
     out = np.zeros(n)
     _check(lib().proxsdp_host_start_vector(n, seed, init, _p(out)))

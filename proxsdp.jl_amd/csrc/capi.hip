@@ -354,6 +354,18 @@ int proxsdp_host_symeig(int32_t k, double* a, double* d) {
     return 0;
 }
 
+int proxsdp_host_symeig_arrow(int32_t K, int32_t m, const double* D, const double* f,
+                              const double* al, const double* be, double* U, double* d) {
+    if (K < 2 || m < 1 || m >= K || !D || !f || !al || !be || !U || !d) { g_last_error = "invalid argument"; return PROXSDP_E_INVALID; }
+    const int n1 = m + 1;
+    std::vector<double> Qa((size_t)n1 * n1, 0.0), da(n1), ea(n1);
+    for (int j = 0; j < m; ++j) { Qa[(size_t)j * n1 + j] = D[j]; Qa[(size_t)j * n1 + m] = Qa[(size_t)m * n1 + j] = f[j]; }
+    proxsdp::householder_tridiag(n1, Qa.data(), da.data(), ea.data());
+    int rc = proxsdp::symeig_tridiag_from(K, m, Qa.data(), da.data(), ea.data(), al, be, U, d);
+    if (rc != 0) { g_last_error = "QL iteration did not converge"; return PROXSDP_E_INTERNAL; }
+    return 0;
+}
+
 int proxsdp_host_start_vector(int64_t n, int64_t seed, int32_t init, double* out) {
     if (n < 0 || !out) { g_last_error = "invalid argument"; return PROXSDP_E_INVALID; }
     proxsdp::start_vector(n, (uint64_t)seed, init, out);

@@ -211,3 +211,27 @@ def test_bindings_mirror_the_header_field_by_field(cname, jname, cls):
     body = re.search(r"struct %s\b.*?\n(.*?)\n(?:    \w+\(\) = new\(\)\n)?end" % jname, jl, re.S).group(1)
     jf = [re.match(r"\s*(\w+)::", ln).group(1) for ln in body.splitlines() if re.match(r"\s*\w+::", ln)]
     assert jf == cf
+
+
+@pytest.mark.parametrize("K,m", [(25, 15), (53, 31), (127, 76), (5, 1), (9, 8)])
+def test_two_phase_eigensolver_of_the_restarted_rayleigh_quotient(K, m):
+    """host_util.hpp symeig_tridiag_from: the arrow part [diag(D) f; f' .] is Householder-reduced
+    first (in the solver: while the GPU runs the cycle), the alpha/beta tail appended, then one QL
+    sweep -- must equal the dense eigen-decomposition of the assembled matrix."""
+    rng = np.random.default_rng(K + m)
+    D = np.sort(rng.uniform(1, 60, m))[::-1].copy()
+    f = rng.standard_normal(m) * np.where(np.arange(m) < m // 3, 1e-13, 1e-2)     # converged + open pairs
+    al = np.zeros(K); be = np.zeros(K)
+    al[m:] = rng.standard_normal(K - m)
+    be[m:K - 1] = 1 + 0.1 * rng.standard_normal(K - 1 - m)
+    T = np.zeros((K, K))
+    T[np.arange(m), np.arange(m)] = D
+    T[m, :m] = T[:m, m] = f
+    for j in range(m, K):
+        T[j, j] = al[j]
+        if j + 1 < K:
+            T[j, j + 1] = T[j + 1, j] = be[j]
+    d, U = B.host_symeig_arrow(D, f, al, be)
+    assert np.allclose(d, np.linalg.eigvalsh(T), rtol=0, atol=1e-12 * np.abs(T).max())
+    assert np.allclose(U.T @ U, np.eye(K), atol=1e-13)
+    assert np.abs(T @ U - U * d).max() <= 1e-12 * np.abs(T).max()
