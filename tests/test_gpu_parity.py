@@ -440,7 +440,7 @@ def test_support_and_dense_paths_agree_on_maxcut():
     assert abs(a.objval - b.objval) <= 1e-3 * (1 + abs(a.objval))
 
 
-@pytest.mark.parametrize("case", ["maxcut", "two_blocks", "periodic_full_eig"])
+@pytest.mark.parametrize("case", ["maxcut", "two_blocks", "periodic_full_eig", "arpack_rule"])
 def test_operator_form_matvec_matches_packed_matvec(case):
     """lanczos_operator=1 (A v = Vp Lam Vp' v + E v from the previous projection's factors and the
     sparse support update) against lanczos_operator=0 (the packed triangle, what dsymv('U')
@@ -453,6 +453,9 @@ def test_operator_form_matvec_matches_packed_matvec(case):
         pr = P.maxcut(300, seed=2)
     elif case == "two_blocks":
         pr = P.block_diag_problems([P.maxcut(180, seed=1), P.maxcut(130, seed=4)])
+    elif case == "arpack_rule":                  # eigsolver=1: dsaupd's acceptance rule on the same engine
+        pr = P.maxcut(260, seed=5)
+        kw.update(eigsolver=1)
     else:
         pr = P.maxcut(220, seed=3)
         kw.update(full_eig_freq=12, full_eig_len=1)
@@ -463,6 +466,8 @@ def test_operator_form_matvec_matches_packed_matvec(case):
     nblk = len(pr.psd)
     if case == "periodic_full_eig":
         assert 0 < b.stats["full_eigs"] and b.stats["fop_projections"] < b.stats["lanczos_calls"]
+    elif case == "arpack_rule":                  # a non-converged dsaupd falls back to full_eig!: no factors next time
+        assert b.stats["fop_projections"] >= b.stats["lanczos_calls"] - 2 * b.stats["krylov_fallbacks"] - 1 >= 140
     else:
         assert b.stats["fop_projections"] == b.stats["lanczos_calls"] == 160 * nblk
     assert np.array_equal(a.trace[:, 11], b.trace[:, 11])                 # linesearch trials
