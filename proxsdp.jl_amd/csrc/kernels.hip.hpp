@@ -623,6 +623,11 @@ k_lz_orth(const double* __restrict__ Ppart, int nt, int npad, const double* __re
 //   unless w' itself is numerically inside span(V), where beta <= tol ends the run anyway);
 //   alpha_k = h1[k] + h2[k] - carry;  V[:,k+1] = (w' - V h2)/beta, or stop when beta <= tol.
 // `g` = index of the 64-row group handled by this workgroup.
+// Same latency discipline as k_lz_orth: every global load (partial dots, the wave's basis
+// columns, w', the scalars) is issued before the stop flag is tested; 16 column sums are reduced
+// together by the fold network.  NCH = 16-column chunks per wave (k + 1 <= 64 NCH).
+// s_h needs 4*16*NCH + 1 doubles, s_d NWAVE*64.
+template <int NCH>
 __device__ __forceinline__ void lz_finish_body(const double* __restrict__ wbuf, double* __restrict__ V, int ldv, int k,
                                                const double* __restrict__ hpart_in, int pld,
                                                const double* __restrict__ h1, double* __restrict__ alphas,
@@ -630,48 +635,88 @@ __device__ __forceinline__ void lz_finish_body(const double* __restrict__ wbuf, 
                                                double tol, int use_carry, int g,
                                                double* __restrict__ s_h, double* __restrict__ s_d,
                                                double* __restrict__ s_beta) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int NC = 16 * NCH;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int kk = k + 1;
-    lz_reduce_partials(hpart_in, pld, kk, true, s_h);
-    if (wv == 0) {
-        double hh = 0.0;
-        for (int j = lane; j < kk; j += WAVE) hh += s_h[j] * s_h[j];
-        hh = wave_sum(hh);
-        if (lane == 0) *s_beta = sqrt(fmax(s_h[NRM_SLOT] - hh, 0.0));
-    }
     const int i = g * LZ_ROWS + lane;
-    double d = 0.0;
-    for (int j = wv; j < kk; j += NWAVE) d += V[(long long)j * ldv + i] * s_h[j];
-    s_d[wv * LZ_ROWS + lane] = d;
+    // ---- all loads
+    const int stop = ctl->stop;
+    const int gl = min(lane, pld - 1);
+    double hp[NC], vr[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int j = min(wv + 4 * c, MAXK - 2);
+        hp[c] = hpart_in[(long long)j * pld + gl];
+        vr[c] = V[(long long)min(wv + 4 * c, k) * ldv + i];
+    }
+    double hn = hpart_in[(long long)NRM_SLOT * pld + gl];
+    const double w0 = wbuf[i];
+    const double h1k = h1[k];
+    const double carry = use_carry ? ctl->carry : 0.0;
+    if (stop) return;
+    // ---- h2 = sums of the partial dots, |w'|^2
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int j = wv + 4 * c;
+        if (lane >= pld || j >= kk) hp[c] = 0.0;
+        else for (int q = lane + WAVE; q < pld; q += WAVE) hp[c] += hpart_in[(long long)j * pld + q];   // n > 4096
+    }
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        double t[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) t[c] = hp[16 * ch + c];
+        const double hs = fold16_all(t, lane);
+        if (lane < 16) s_h[wv + 4 * (16 * ch + lane)] = hs;              // zero for j >= kk
+    }
+    if (wv == 0) {
+        if (lane >= pld) hn = 0.0;
+        else for (int q = lane + WAVE; q < pld; q += WAVE) hn += hpart_in[(long long)NRM_SLOT * pld + q];
+        hn = wave_sum(hn);
+        if (lane == 0) s_h[4 * NC] = hn;
+    }
     __syncthreads();
-    const double beta = *s_beta;
+    // ---- beta, v_{k+1} = (w' - V h2) / beta
+    double hh = 0.0;
+    for (int j = lane; j < kk; j += WAVE) hh += s_h[j] * s_h[j];
+    hh = wave_sum(hh);                                   // every wave: same value, same order
+    const double beta = sqrt(fmax(s_h[4 * NC] - hh, 0.0));
+    double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+    for (int c = 0; c < NC; c += 2) {
+        const int j0 = wv + 4 * c, j1 = j0 + 4;
+        if (j0 < kk) d0 += vr[c] * s_h[j0];
+        if (j1 < kk) d1 += vr[c + 1] * s_h[j1];
+    }
+    s_d[wv * LZ_ROWS + lane] = d0 + d1;
     if (g == 0 && threadIdx.x == 0) {
-        alphas[k] = h1[k] + s_h[k] - (use_carry ? ctl->carry : 0.0);
+        alphas[k] = h1k + s_h[k] - carry;
         betas[k] = beta;
         ctl->carry = s_h[k];
-    }
-    if (beta <= tol) {
         // every workgroup computes the same beta; the flag is only READ by later
         // launches (stream order), so a plain store by one thread is enough
-        if (g == 0 && threadIdx.x == 0) { ctl->kstop = k + 1; ctl->stop = 1; }
-        return;
+        if (beta <= tol) { ctl->kstop = k + 1; ctl->stop = 1; }
     }
+    if (beta <= tol) return;
+    __syncthreads();
     if (wv == 0) {
-        const double wi = wbuf[i] - ((s_d[lane] + s_d[LZ_ROWS + lane]) + (s_d[2 * LZ_ROWS + lane] + s_d[3 * LZ_ROWS + lane]));
+        const double wi = w0 - ((s_d[lane] + s_d[LZ_ROWS + lane]) + (s_d[2 * LZ_ROWS + lane] + s_d[3 * LZ_ROWS + lane]));
         V[(long long)(k + 1) * ldv + i] = wi / beta;          // rows >= n stay zero
     }
+    (void)s_beta;
 }
 
+template <int NCH>
 __global__ void __launch_bounds__(TPB)
 k_lz_finish(const double* __restrict__ wbuf, int n, double* __restrict__ V, int ldv, int k,
             const double* __restrict__ hpart_in, int pld, const double* __restrict__ h1,
             double* __restrict__ alphas, double* __restrict__ betas, LanczosCtl* __restrict__ ctl, double tol,
             int use_carry) {
-    if (ctl->stop) return;
-    __shared__ double s_h[MAXK];
+    __shared__ double s_h[64 * NCH + 1];
     __shared__ double s_d[NWAVE * LZ_ROWS];
     __shared__ double s_beta;
-    lz_finish_body(wbuf, V, ldv, k, hpart_in, pld, h1, alphas, betas, ctl, tol, use_carry, blockIdx.x, s_h, s_d, &s_beta);
+    lz_finish_body<NCH>(wbuf, V, ldv, k, hpart_in, pld, h1, alphas, betas, ctl, tol, use_carry, blockIdx.x, s_h, s_d, &s_beta);
 }
 
 // The step-closing work of step k and the mat-vec of step k+1 in ONE launch.
@@ -681,19 +726,20 @@ k_lz_finish(const double* __restrict__ wbuf, int n, double* __restrict__ V, int 
 // recurrence terms; so the mat-vec runs on w' (ready before the closing work), the 1/beta
 // is applied by k_lz_orth, and alpha_{k+1} gets the exact correction -h2[k] (`carry`).
 // Workgroups [0, nt) close step k, workgroups [nt, nt + ntile) are mat-vec tiles.
+template <int NCH>
 __global__ void __launch_bounds__(TPB)
 k_symv_finish(const double* __restrict__ xp, int n, int nt, int npad, double* __restrict__ Ppart,
               const double* __restrict__ wbuf, double* __restrict__ V, int ldv, int k,
               const double* __restrict__ hpart_in, int pld, const double* __restrict__ h1,
               double* __restrict__ alphas, double* __restrict__ betas, LanczosCtl* __restrict__ ctl, double tol,
               int use_carry, double* __restrict__ Apart) {
-    if (ctl->stop) return;
     __shared__ double s_a[2 * NWAVE * TILE];                            // s_h   | s_row (double-buffered)
     __shared__ double s_b[NWAVE * LZ_ROWS];                             // s_d   | s_col (double-buffered)
     __shared__ double s_beta;
     if ((int)blockIdx.x < nt)
-        lz_finish_body(wbuf, V, ldv, k, hpart_in, pld, h1, alphas, betas, ctl, tol, use_carry, blockIdx.x,
-                       s_a, s_b, &s_beta);
+        lz_finish_body<NCH>(wbuf, V, ldv, k, hpart_in, pld, h1, alphas, betas, ctl, tol, use_carry, blockIdx.x,
+                            s_a, s_b, &s_beta);
+    else if (ctl->stop) return;
     else
         symv_tiles(xp, n, npad, nt * (nt + 1) / 2, wbuf, Ppart, (int)blockIdx.x - nt, (int)gridDim.x - nt, s_a, s_b, Apart);
 }
@@ -781,7 +827,7 @@ k_fop(const double* __restrict__ v, const double* __restrict__ Vp, int ldv, int 
     fop_body<NCHP>(v, Vp, ldv, rp, ell_col, ell_sidx, ell_w, npad, esv, tpart, pld, ebuf, apart, blockIdx.x, s_e, ctl);
 }
 // closing work of step k (workgroups [0, nt)) + operator rows of step k+1 on w' ([nt, 2 nt))
-template <int NCHP>
+template <int NCHP, int NCH>
 __global__ void __launch_bounds__(TPB)
 k_fop_finish(const double* __restrict__ wbuf, double* __restrict__ V, int ldv, int k,
              const double* __restrict__ hpart_in, int pld, const double* __restrict__ h1,
@@ -794,9 +840,8 @@ k_fop_finish(const double* __restrict__ wbuf, double* __restrict__ V, int ldv, i
     __shared__ double s_b[NWAVE * LZ_ROWS];
     __shared__ double s_beta;
     if ((int)blockIdx.x < nt) {
-        if (ctl->stop) return;
-        lz_finish_body(wbuf, V, ldv, k, hpart_in, pld, h1, alphas, betas, ctl, tol, use_carry, blockIdx.x,
-                       s_a, s_b, &s_beta);
+        lz_finish_body<NCH>(wbuf, V, ldv, k, hpart_in, pld, h1, alphas, betas, ctl, tol, use_carry, blockIdx.x,
+                            s_a, s_b, &s_beta);
     } else {
         fop_body<NCHP>(wbuf, Vp, ldv, rp, ell_col, ell_sidx, ell_w, npad, esv, tpart, pld, ebuf, apart,
                        (int)blockIdx.x - nt, s_b, ctl);

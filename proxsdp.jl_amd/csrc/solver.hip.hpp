@@ -277,6 +277,7 @@ private:
     std::vector<int> big_blocks;               // indices of the blocks that are projected by an eigensolver
     std::vector<double> hscal;
     bool csr_wave = false;
+    int rotate_lds_cap = 60 * 1024;           // dynamic LDS granted to k_lz_rotate (setup_device)
     // rows longer than LONG_ROW entries: segmented SpMV (kernels.hip.hpp k_spmv_csr_seg)
     static constexpr int LONG_ROW = 8192;
     DevBuf<int> seg_lo_d, seg_hi_d, long_row_d, long_ptr_d;
@@ -396,6 +397,9 @@ inline void Solver::setup_device() {
     if (opt.device_id < 0 || opt.device_id >= ndev) throw std::invalid_argument("device_id out of range");
     PX_HIP(hipSetDevice(opt.device_id));
     PX_HIP(hipStreamCreate(&stream.main));
+    rotate_lds_cap = (hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_lz_rotate),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) == hipSuccess)
+                         ? 144 * 1024 : 60 * 1024;
     PX_ROC(rocblas_create_handle(&blas));
     PX_ROC(rocblas_set_stream(blas, stream));
 }
@@ -491,7 +495,9 @@ inline void Solver::launch_symv_finish(EigWork& W, const double* xp, int kclose,
     }
     hipEvent_t e0 = prof ? W.ev.e0[slot] : nullptr, e1 = prof ? W.ev.e1[slot] : nullptr;
     if (W.use_fop) {
-        auto kern = (W.F_r <= 64) ? dev::k_fop_finish<1> : dev::k_fop_finish<2>;
+        const int nchf = (kclose + 1 <= 64) ? 1 : (kclose + 1 <= 128) ? 2 : 3;
+        auto kern = (W.F_r <= 64) ? (nchf == 1 ? dev::k_fop_finish<1, 1> : nchf == 2 ? dev::k_fop_finish<1, 2> : dev::k_fop_finish<1, 3>)
+                                  : (nchf == 1 ? dev::k_fop_finish<2, 1> : nchf == 2 ? dev::k_fop_finish<2, 2> : dev::k_fop_finish<2, 3>);
         launch_prof(prof, e0, e1, kern, dim3(2 * W.nt), stream,
                     (const double*)W.w.p, W.V.p, W.npad, kclose, (const double*)lz_hpart(W, kclose), W.pld,
                     (const double*)W.hsum1.p, W.alphas_p, W.betas_p, W.ctl_p, tol, use_carry ? 1 : 0, W.nt,
@@ -499,7 +505,9 @@ inline void Solver::launch_symv_finish(EigWork& W, const double* xp, int kclose,
                     (const int*)W.ell_col.p, (const int*)W.ell_sidx.p, W.ell_w, W.npad, W.esv, W.tpart.p, W.ebuf.p,
                     W.apartf.p);
     } else {
-        launch_prof(prof, e0, e1, dev::k_symv_finish, dim3(W.nt + ntile), stream,
+        const int nchf = (kclose + 1 <= 64) ? 1 : (kclose + 1 <= 128) ? 2 : 3;
+        auto ksf = nchf == 1 ? dev::k_symv_finish<1> : nchf == 2 ? dev::k_symv_finish<2> : dev::k_symv_finish<3>;
+        launch_prof(prof, e0, e1, ksf, dim3(W.nt + ntile), stream,
                     xp, W.n, W.nt, W.npad, W.Ppart.p, (const double*)W.w.p, W.V.p, W.npad, kclose,
                     (const double*)lz_hpart(W, kclose), W.pld, (const double*)W.hsum1.p, W.alphas_p, W.betas_p, W.ctl_p,
                     tol, use_carry ? 1 : 0, W.Apart.p);
@@ -532,9 +540,12 @@ inline void Solver::rotate(EigWork& W, int K, const std::vector<double>& U, int 
     for (int c = 0; c < ncols; ++c)
         for (int j = 0; j < K; ++j) tmp[(size_t)c * K + j] = U[(size_t)c * ldu + j];
     W.U.upload(tmp.data(), (size_t)K * ncols, stream);
-    // dynamic LDS: U chunk (K x cn) + V tile (K x 65); keep it <= 60 KiB
+    // dynamic LDS: U chunk (K x cn) + V tile (K x 65).  gfx950 has 160 KiB of LDS per CU: the
+    // kernel is allowed 144 KiB (setup_device), so a whole restart rotation is ONE launch up to
+    // K = 127 (with a 60 KiB cap the V tile alone no longer fitted at K >= 116 and the loop
+    // degenerated into one launch per column: 141 launches per iteration at target rank 63)
     const int vbytes = K * (dev::LZ_ROWS + 1) * 8;
-    const int maxcols = std::max(1, (60 * 1024 - vbytes) / (8 * K));
+    const int maxcols = std::max(1, (rotate_lds_cap - vbytes) / (8 * K));
     int c0 = 0;
     do {
         const int cn = std::max(0, std::min(maxcols, ncols - c0));
@@ -614,7 +625,8 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev) {
                 default: launch_orth(dev::k_lz_orth<3, 2>); break;
             }
         }
-        hipLaunchKernelGGL(dev::k_lz_finish, dim3(W.nt), dim3(dev::TPB), 0, stream,
+        auto klf = (krylovdim <= 64) ? dev::k_lz_finish<1> : (krylovdim <= 128) ? dev::k_lz_finish<2> : dev::k_lz_finish<3>;
+        hipLaunchKernelGGL(klf, dim3(W.nt), dim3(dev::TPB), 0, stream,
                            W.w.p, W.n, W.V.p, W.npad, krylovdim - 1, lz_hpart(W, krylovdim - 1), W.pld, W.hsum1.p,
                            W.alphas_p, W.betas_p, W.ctl_p, step_tol, (krylovdim - 1 > kfirst) ? 1 : 0);
         // the first mat-vec of a possible next cycle only needs v_K = V[:,krylovdim], which is
