@@ -327,46 +327,6 @@ constexpr int NRM_SLOT = MAXK - 1;  // slot of a partial-dots row that carries |
 // Partial dots live column-major over workgroups: hpart[j * pld + g] (pld = number of
 // workgroups rounded up to 64, padding stays zero), so that the consumer reads the
 // partials of one basis column with ONE coalesced load per wave.
-// dots of this workgroup's 64 rows of w against basis columns j = wv, wv+4, ... < kk
-__device__ __forceinline__ void lz_dots(const double* __restrict__ V, int ldv, int kk, int i, double wi,
-                                        int wv, int lane, double* __restrict__ hpart, int pld, int g) {
-    for (int j = wv; j < kk; j += 2 * NWAVE) {
-        const int j2 = j + NWAVE;
-        double p0 = V[(long long)j * ldv + i] * wi;
-        double p1 = (j2 < kk) ? V[(long long)j2 * ldv + i] * wi : 0.0;
-        p0 = wave_sum(p0);
-        p1 = wave_sum(p1);
-        if (lane == 0) {
-            hpart[(long long)j * pld + g] = p0;
-            if (j2 < kk) hpart[(long long)j2 * pld + g] = p1;
-        }
-    }
-}
-// s_h[j] = sum over workgroups of the partials of column j, j < kk and j == NRM_SLOT when
-// `with_norm`: one coalesced load + one DPP wave reduction per column (fixed order).
-// Ends with a barrier.
-__device__ __forceinline__ void lz_reduce_partials(const double* __restrict__ hpart, int pld, int kk,
-                                                   bool with_norm, double* __restrict__ s_h) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int total = kk + (with_norm ? 1 : 0);
-    for (int jj = wv; jj < total; jj += 2 * NWAVE) {
-        const int ja = (jj < kk) ? jj : NRM_SLOT;
-        const int j2 = jj + NWAVE;
-        const int jb = (j2 < kk) ? j2 : NRM_SLOT;
-        double ha = 0.0, hb = 0.0;
-        for (int g = lane; g < pld; g += WAVE) {
-            ha += hpart[(long long)ja * pld + g];
-            if (j2 < total) hb += hpart[(long long)jb * pld + g];
-        }
-        ha = wave_sum(ha);
-        hb = wave_sum(hb);
-        if (lane == 0) {
-            s_h[ja] = ha;
-            if (j2 < total) s_h[jb] = hb;
-        }
-    }
-    __syncthreads();
-}
 
 // y = smat(xp) v from the mat-vec partial slots (test seam / residual checks):
 // w = (sum of slots) / sqrt2, fixed order.
