@@ -385,7 +385,7 @@ struct FopArgs {
 template <int NCH, int NCHP>
 __global__ void __launch_bounds__(TPB)
 k_lz_orth(const double* __restrict__ Ppart, int nt, int npad, const double* __restrict__ V, int ldv, int k,
-          double* __restrict__ wbuf, const double* __restrict__ hpart_prev, double* __restrict__ hpart_out, int pld,
+          double* __restrict__ wbuf, const double* __restrict__ hred, double* __restrict__ hpart_out, int pld,
           double* __restrict__ hsum_out, const LanczosCtl* __restrict__ ctl,
           const double* __restrict__ alphas, const double* __restrict__ betas,
           const double* __restrict__ Apart, int napart, int first, const double* __restrict__ arrow, int keep,
@@ -425,10 +425,8 @@ k_lz_orth(const double* __restrict__ Ppart, int nt, int npad, const double* __re
     double vr[NC];                                   // basis columns of this wave (column k included)
 #pragma unroll
     for (int c = 0; c < NC; ++c) vr[c] = V[(long long)min(wv + 4 * c, k) * ldv + i];
-    double hp[NC];                                   // partial dots of step k-1, one workgroup share per lane
-    const int gl = min(lane, pld - 1);
-#pragma unroll
-    for (int c = 0; c < NC; ++c) hp[c] = hpart_prev[(long long)min(wv + 4 * c, MAXK - 1) * pld + gl];
+    // h2 of step k-1, already reduced by the closing workgroup 0 of the previous launch
+    const double hred_j = hred[min((int)threadIdx.x, MAXK - 1)];
     // coefficient data of the prediction (thread j <-> basis column j; lane-indexed copies for
     // the two short dot products): issued with everything else, used after the first barrier
     const int j = threadIdx.x;
@@ -479,22 +477,7 @@ k_lz_orth(const double* __restrict__ Ppart, int nt, int npad, const double* __re
         ap = wave_sum(ap);
         if (lane == 0) s_red[wv] = (wv == 0) ? ap : 0.0;
     }
-    if (!first) {
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int j = wv + 4 * c;
-            if (lane >= pld || j >= k) hp[c] = 0.0;
-            else for (int g = lane + WAVE; g < pld; g += WAVE) hp[c] += hpart_prev[(long long)j * pld + g];   // n > 4096
-        }
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
-            double t[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) t[c] = hp[16 * ch + c];
-            const double hs = fold16_all(t, lane);
-            if (lane < 16) s_h[wv + 4 * (16 * ch + lane)] = hs;          // zero for j >= k
-        }
-    }
+    if (!first && (int)threadIdx.x < 4 * NC) s_h[threadIdx.x] = ((int)threadIdx.x < k) ? hred_j : 0.0;
     __syncthreads();
     // ---- coefficients: s_q[j], j < k, over V_{k-1}; s_q[k] = coefficient of v_k
     double alpha, wi;
@@ -594,7 +577,7 @@ __device__ __forceinline__ void lz_finish_body(const double* __restrict__ wbuf, 
                                                double* __restrict__ betas, LanczosCtl* __restrict__ ctl,
                                                double tol, int use_carry, int g,
                                                double* __restrict__ s_h, double* __restrict__ s_d,
-                                               double* __restrict__ s_beta) {
+                                               double* __restrict__ s_beta, double* __restrict__ hred) {
     constexpr int NC = 16 * NCH;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -650,6 +633,9 @@ __device__ __forceinline__ void lz_finish_body(const double* __restrict__ wbuf, 
         if (j1 < kk) d1 += vr[c + 1] * s_h[j1];
     }
     s_d[wv * LZ_ROWS + lane] = d0 + d1;
+    // the reduced h2 for the prediction of the next step (k_lz_orth reads k values instead of
+    // re-reducing 64 partials per column)
+    if (g == 0 && (int)threadIdx.x < kk) hred[threadIdx.x] = s_h[threadIdx.x];
     if (g == 0 && threadIdx.x == 0) {
         alphas[k] = h1k + s_h[k] - carry;
         betas[k] = beta;
@@ -672,11 +658,11 @@ __global__ void __launch_bounds__(TPB)
 k_lz_finish(const double* __restrict__ wbuf, int n, double* __restrict__ V, int ldv, int k,
             const double* __restrict__ hpart_in, int pld, const double* __restrict__ h1,
             double* __restrict__ alphas, double* __restrict__ betas, LanczosCtl* __restrict__ ctl, double tol,
-            int use_carry) {
+            int use_carry, double* __restrict__ hred) {
     __shared__ double s_h[64 * NCH + 1];
     __shared__ double s_d[NWAVE * LZ_ROWS];
     __shared__ double s_beta;
-    lz_finish_body<NCH>(wbuf, V, ldv, k, hpart_in, pld, h1, alphas, betas, ctl, tol, use_carry, blockIdx.x, s_h, s_d, &s_beta);
+    lz_finish_body<NCH>(wbuf, V, ldv, k, hpart_in, pld, h1, alphas, betas, ctl, tol, use_carry, blockIdx.x, s_h, s_d, &s_beta, hred);
 }
 
 // The step-closing work of step k and the mat-vec of step k+1 in ONE launch.
@@ -692,13 +678,13 @@ k_symv_finish(const double* __restrict__ xp, int n, int nt, int npad, double* __
               const double* __restrict__ wbuf, double* __restrict__ V, int ldv, int k,
               const double* __restrict__ hpart_in, int pld, const double* __restrict__ h1,
               double* __restrict__ alphas, double* __restrict__ betas, LanczosCtl* __restrict__ ctl, double tol,
-              int use_carry, double* __restrict__ Apart) {
+              int use_carry, double* __restrict__ Apart, double* __restrict__ hred) {
     __shared__ double s_a[2 * NWAVE * TILE];                            // s_h   | s_row (double-buffered)
     __shared__ double s_b[NWAVE * LZ_ROWS];                             // s_d   | s_col (double-buffered)
     __shared__ double s_beta;
     if ((int)blockIdx.x < nt)
         lz_finish_body<NCH>(wbuf, V, ldv, k, hpart_in, pld, h1, alphas, betas, ctl, tol, use_carry, blockIdx.x,
-                            s_a, s_b, &s_beta);
+                            s_a, s_b, &s_beta, hred);
     else if (ctl->stop) return;
     else
         symv_tiles(xp, n, npad, nt * (nt + 1) / 2, wbuf, Ppart, (int)blockIdx.x - nt, (int)gridDim.x - nt, s_a, s_b, Apart);
@@ -795,13 +781,13 @@ k_fop_finish(const double* __restrict__ wbuf, double* __restrict__ V, int ldv, i
              int use_carry, int nt, const double* __restrict__ Vp, int rp,
              const int* __restrict__ ell_col, const int* __restrict__ ell_sidx, int ell_w, int npad,
              const double* __restrict__ esv, double* __restrict__ tpart, double* __restrict__ ebuf,
-             double* __restrict__ apart) {
+             double* __restrict__ apart, double* __restrict__ hred) {
     __shared__ double s_a[2 * NWAVE * TILE];
     __shared__ double s_b[NWAVE * LZ_ROWS];
     __shared__ double s_beta;
     if ((int)blockIdx.x < nt) {
         lz_finish_body<NCH>(wbuf, V, ldv, k, hpart_in, pld, h1, alphas, betas, ctl, tol, use_carry, blockIdx.x,
-                            s_a, s_b, &s_beta);
+                            s_a, s_b, &s_beta, hred);
     } else {
         fop_body<NCHP>(wbuf, Vp, ldv, rp, ell_col, ell_sidx, ell_w, npad, esv, tpart, pld, ebuf, apart,
                        (int)blockIdx.x - nt, s_b, ctl);

@@ -138,7 +138,7 @@ struct EigWork {
     int n = 0, nt = 0, npad = 0, nwg = 0, cap = 0, pld = 0;   // cap = columns of V (krylovdim_max + 1)
     int64_t N = 0;
     DevBuf<double> V, Z;            // npad x cap each (V: Krylov basis, Z: rotation target / Ritz vectors)
-    DevBuf<double> w, Ppart, hpart1, hpart2, hsum1, U, lam, resid, Apart, arrow;
+    DevBuf<double> w, Ppart, hpart1, hpart2, hsum1, hred, U, lam, resid, Apart, arrow;
     int napart = 0;
     PinnedBuf arrow_host;
     // alphas[MAXK] | betas[MAXK] | LanczosCtl in ONE device record, read back with one copy
@@ -373,6 +373,7 @@ inline void Solver::alloc_eigwork(EigWork& W, int n, int max_nev) {
     W.hpart2.alloc((size_t)W.pld * dev::MAXK);
     W.hpart1.zero(stream); W.hpart2.zero(stream);
     W.hsum1.alloc(dev::MAXK);
+    W.hred.alloc(dev::MAXK); W.hred.zero(stream);
     W.napart = 8 * ceil_div(W.nt * (W.nt + 1) / 2, 8);
     W.Apart.alloc(W.napart); W.Apart.zero(stream);      // padding tiles never write: stay zero
     W.arrow.alloc(2 * dev::MAXK); W.arrow.zero(stream);   // arrow: f | D (see k_lz_orth)
@@ -503,14 +504,14 @@ inline void Solver::launch_symv_finish(EigWork& W, const double* xp, int kclose,
                     (const double*)W.hsum1.p, W.alphas_p, W.betas_p, W.ctl_p, tol, use_carry ? 1 : 0, W.nt,
                     (const double*)(W.F.p + (size_t)W.F_first * W.npad), W.F_r,
                     (const int*)W.ell_col.p, (const int*)W.ell_sidx.p, W.ell_w, W.npad, W.esv, W.tpart.p, W.ebuf.p,
-                    W.apartf.p);
+                    W.apartf.p, W.hred.p);
     } else {
         const int nchf = (kclose + 1 <= 64) ? 1 : (kclose + 1 <= 128) ? 2 : 3;
         auto ksf = nchf == 1 ? dev::k_symv_finish<1> : nchf == 2 ? dev::k_symv_finish<2> : dev::k_symv_finish<3>;
         launch_prof(prof, e0, e1, ksf, dim3(W.nt + ntile), stream,
                     xp, W.n, W.nt, W.npad, W.Ppart.p, (const double*)W.w.p, W.V.p, W.npad, kclose,
                     (const double*)lz_hpart(W, kclose), W.pld, (const double*)W.hsum1.p, W.alphas_p, W.betas_p, W.ctl_p,
-                    tol, use_carry ? 1 : 0, W.Apart.p);
+                    tol, use_carry ? 1 : 0, W.Apart.p, W.hred.p);
     }
     W.lst.symv_launches++;
     W.lst.symv_bytes += 8.0 * (double)W.N + 16.0 * (double)W.n;
@@ -608,7 +609,7 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev) {
             auto launch_orth = [&](auto kern) {
                 hipLaunchKernelGGL(kern, dim3(W.nt), dim3(dev::TPB), 0, stream,
                                    (const double*)W.Ppart.p, W.nt, W.npad, (const double*)W.V.p, W.npad, k, W.w.p,
-                                   (const double*)hp[(k + 1) & 1], hp[k & 1], W.pld, W.hsum1.p,
+                                   (const double*)W.hred.p, hp[k & 1], W.pld, W.hsum1.p,
                                    (const dev::LanczosCtl*)W.ctl_p, (const double*)W.alphas_p, (const double*)W.betas_p,
                                    (const double*)W.Apart.p, W.napart, k == kfirst ? 1 : 0, (const double*)W.arrow.p,
                                    kfirst, fo);
@@ -628,7 +629,7 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev) {
         auto klf = (krylovdim <= 64) ? dev::k_lz_finish<1> : (krylovdim <= 128) ? dev::k_lz_finish<2> : dev::k_lz_finish<3>;
         hipLaunchKernelGGL(klf, dim3(W.nt), dim3(dev::TPB), 0, stream,
                            W.w.p, W.n, W.V.p, W.npad, krylovdim - 1, lz_hpart(W, krylovdim - 1), W.pld, W.hsum1.p,
-                           W.alphas_p, W.betas_p, W.ctl_p, step_tol, (krylovdim - 1 > kfirst) ? 1 : 0);
+                           W.alphas_p, W.betas_p, W.ctl_p, step_tol, (krylovdim - 1 > kfirst) ? 1 : 0, W.hred.p);
         // the first mat-vec of a possible next cycle only needs v_K = V[:,krylovdim], which is
         // final now: enqueue it before the host round trip so the GPU works during the K x K
         // eigensolve (wasted only when this cycle turns out to be the last one)
