@@ -538,6 +538,34 @@ def test_blocks_wider_than_64_workgroups():
     assert runs[2].stats["fop_projections"] == 40 and runs[1].stats["fop_projections"] == 0
 
 
+@pytest.mark.parametrize("n,seed,rank0,maxrank,iters", [
+    (101, 1, 2, 16, 260),        # smallest Lanczos-sized block, 2 row groups, rank updates after iteration 200
+    (333, 2, 30, 40, 60),        # krylovdim 61..81: 2 chunks of basis columns per wave
+    (300, 3, 70, 78, 40),        # rp > 64: two chunks of previous factors (NCHP = 2), krylovdim 141 (NCH = 3)
+    (1000, 4, 12, 16, 80),       # BASELINE config 2 size
+])
+def test_operator_form_across_ranks_and_sizes(n, seed, rank0, maxrank, iters):
+    """The operator-form kernels are templated on the number of 16-column chunks of the Krylov
+    basis (NCH) and of the previous factors (NCHP); this sweeps the combinations against the
+    packed-triangle mat-vec on the same instances."""
+    pr = P.maxcut(n, seed=seed)
+    kw = dict(max_iter=iters, support_path=1, initial_target_rank=rank0, max_target_rank_krylov_eigs=maxrank)
+    a = Optimizer(lanczos_operator=0, **kw).optimize(pr, trace_capacity=iters)
+    b = Optimizer(lanczos_operator=1, **kw).optimize(pr, trace_capacity=iters)
+    assert a.iter == b.iter == iters and b.stats["fop_projections"] > 0 and b.stats["full_eigs"] == a.stats["full_eigs"]
+    assert np.array_equal(a.trace[:, 10], b.trace[:, 10])                 # target-rank schedule
+    assert np.array_equal(a.trace[:, 11], b.trace[:, 11])                 # linesearch trials
+    krylovdim = max(2 * rank0 + 1, 25)
+    mv = a.trace[:, 13]
+    tight = max(3, int(np.argmax(mv > krylovdim)) if np.any(mv > krylovdim) else iters)
+    assert np.array_equal(a.trace[:tight, 13], b.trace[:tight, 13])
+    for col in (1, 2, 3, 4, 5, 6, 7, 9):
+        assert np.allclose(a.trace[:tight, col], b.trace[:tight, col], rtol=1e-8, atol=1e-11), col
+    sc = np.abs(a.trace[:, 1]).max()
+    assert abs(a.trace[-1, 1] - b.trace[-1, 1]) <= 2e-2 * sc              # same neighbourhood after the separation
+    assert np.all(np.isfinite(b.trace))
+
+
 def test_operator_form_converges_to_the_same_optimum():
     """Full solves (tol 1e-4) of a Max-Cut instance with both operators: same status, objectives
     within the solver's own gap measure, iterate feasible by the solver's own criterion
