@@ -129,3 +129,44 @@ def unbounded_lp():
     """min -x1 - x2  s.t. x1 - x2 = 0, x >= 0: dual infeasible (status DUAL_INFEASIBLE = 5)."""
     return Problem(n=2, A=_mat([{0: 1, 1: -1}], 2), b=np.array([0.0]), G=_mat([{0: -1}, {1: -1}], 2),
                    h=np.zeros(2), c=_cvec(2, {0: -1, 1: -1}), name="unbounded_lp")
+
+
+def mixed_cones(seed=0, sides=(1, 3, 104, 1, 5), soc_len=4, nfree=3, p=30, m=12):
+    """Random feasible model with every variable class at once, variables deliberately NOT in
+    solver order: PSD blocks of the given sides (1x1, full-eig-sized and Lanczos-sized), one SOC,
+    free variables; equalities and inequalities built from a known strictly feasible point so that
+    the optimum exists; objective = trace-like positive weights (bounded below on the cones)."""
+    rng = np.random.default_rng(seed)
+    lens = [s_ * (s_ + 1) // 2 for s_ in sides]
+    n = sum(lens) + soc_len + nfree
+    perm = rng.permutation(n)                      # user variable ids of the cone slots
+    psd, pos = [], 0
+    for L in lens:
+        psd.append(perm[pos:pos + L].astype(np.int64)); pos += L
+    soc = [perm[pos:pos + soc_len].astype(np.int64)]; pos += soc_len
+    free = perm[pos:]
+    x0 = np.zeros(n)
+    c = np.zeros(n)
+    for s_, idx in zip(sides, psd):
+        G = rng.standard_normal((s_, s_ + 2))
+        X = G @ G.T / (s_ + 2) + 0.5 * np.eye(s_)
+        W = rng.standard_normal((s_, s_)); W = W @ W.T / s_ + np.eye(s_)       # PD objective weight
+        k = 0
+        for j in range(s_):
+            for i in range(j + 1):
+                x0[idx[k]] = X[i, j]
+                c[idx[k]] = W[i, j] if i == j else 2.0 * W[i, j]
+                k += 1
+    u = rng.standard_normal(soc_len - 1)
+    x0[soc[0][0]] = np.linalg.norm(u) + 1.0
+    x0[soc[0][1:]] = u
+    c[soc[0][0]] = 1.5
+    x0[free] = rng.standard_normal(nfree)
+    A = sp.random(p, n, density=0.08, random_state=rng, format="csc")
+    # every free variable must be pinned by an equality, or the problem is unbounded in it
+    rows = [{int(v): 1.0} for v in free]
+    A = sp.vstack([A, _mat(rows, n)]).tocsc()
+    b = A @ x0
+    Gm = sp.random(m, n, density=0.1, random_state=rng, format="csc")
+    h = Gm @ x0 + rng.uniform(0.1, 1.0, m)
+    return Problem(n=n, A=A, b=b, G=Gm, h=h, c=c, psd=psd, soc=soc, name=f"mixed-cones-s{seed}")

@@ -18,7 +18,7 @@ from proxsdp_jl_amd import problems as P
 from proxsdp_jl_amd.optimizer import Optimizer
 
 from helpers import PROJ_CASES, oracle_project, planted_packed, smat, svec
-from kat_problems import KATS, sdp_wiki, simple_lp, soc_norm, sdp_plus_soc, unbounded_lp, infeasible_lp
+from kat_problems import KATS, sdp_wiki, simple_lp, soc_norm, sdp_plus_soc, unbounded_lp, infeasible_lp, mixed_cones
 
 pytestmark = pytest.mark.gpu
 
@@ -292,6 +292,35 @@ def test_soc_cones_against_oracle(build):
     assert np.allclose(sol.primal, ref.primal, atol=1e-8) and np.allclose(sol.dual_cone, ref.dual_cone, atol=1e-8)
     if build is soc_norm:
         assert abs(opt.objective_value() - 5.0) < 1e-4
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_mixed_cone_model_against_oracle(seed):
+    """Every variable class in one model, user variable ids shuffled: 1x1 PSD blocks, a 3x3 and a
+    5x5 block (full_eig!), a 104x104 block (Lanczos), one SOC, free variables, sparse equalities
+    and inequalities.  Exercises preprocess! reordering, the concurrent block projections and the
+    un-permutation of the results."""
+    pr = mixed_cones(seed)
+    opt = _gopt()
+    sol = opt.optimize(pr, trace_capacity=300)
+    o = Options()
+    o.tol_gap = o.tol_feasibility = 1e-6
+    ref = oracle.solve(pr, o, trace=True)
+    assert sol.status == ref.status == 1
+    assert abs(sol.iter - ref.iter) <= max(3, 0.05 * ref.iter)
+    m = min(len(ref.trace), len(sol.trace), 30)
+    G, T = _trace_cols(ref.trace)[:m], sol.trace[:m, [1, 2, 3, 4, 7, 11]]
+    assert np.allclose(T, G, rtol=1e-7, atol=1e-9 * max(1.0, np.abs(G).max()))
+    assert abs(sol.objval - ref.objval) <= 2e-6 * (1 + abs(ref.objval))
+    sc = max(1.0, np.abs(ref.primal).max())
+    assert np.allclose(sol.primal, ref.primal, atol=2e-5 * sc)
+    assert np.allclose(sol.slack_eq, ref.slack_eq, atol=2e-5 * sc) and np.allclose(sol.slack_in, ref.slack_in, atol=2e-5 * sc)
+    assert sol.stats["lanczos_matvecs"] > 0 and sol.stats["full_eigs"] > 0
+    # the answer itself: cone membership in USER variable order
+    for idx, side in zip(pr.psd, pr.psd_sides()):
+        assert np.linalg.eigvalsh(P.unpack_psd(sol.primal[idx], side)).min() >= -1e-6
+    t = sol.primal[pr.soc[0]]
+    assert t[0] >= np.linalg.norm(t[1:]) - 1e-6
 
 
 def test_unbounded_lp_certificate_search():

@@ -232,3 +232,19 @@ def test_equilibration_switches_itself_off_and_scales_uniformly():
 def sp_vstack(aff):
     import scipy.sparse as sp
     return sp.vstack([aff.A, aff.G], format="csc")
+
+
+def test_mixed_cone_model_is_solved_by_the_oracle():
+    """All variable classes at once with shuffled user variable ids (kat_problems.mixed_cones):
+    the answer must lie in the cones in USER order and satisfy the constraints."""
+    from kat_problems import mixed_cones
+    pr = mixed_cones(0)
+    r = oracle.solve(pr, _opt())
+    assert r.status == 1 and r.primal_feasible_user_tol
+    for idx, side in zip(pr.psd, pr.psd_sides()):
+        assert np.linalg.eigvalsh(P.unpack_psd(r.primal[idx], side)).min() >= -1e-6
+    t = r.primal[pr.soc[0]]
+    assert t[0] >= np.linalg.norm(t[1:]) - 1e-6
+    assert np.abs(pr.A @ r.primal - pr.b).max() <= 1e-5 * (1 + np.linalg.norm(pr.b))
+    assert (pr.G @ r.primal - pr.h).max() <= 1e-5 * (1 + np.linalg.norm(pr.h))
+    assert r.stats["lanczos_matvecs"] > 0 and r.stats["full_eigs"] > 0

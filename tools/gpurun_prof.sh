@@ -1,6 +1,6 @@
 # usage: gpurun_prof.sh <script.py> [args]  -- rocprofv3 kernel stats (avg us per kernel)
 cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/prof
-rocprofv3 --kernel-trace --stats -d /tmp/prof -o p -- python $GRAFT_REPO_ROOT/"$1" > /tmp/prof.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/prof -o p -- python $GRAFT_REPO_ROOT/"$1" "${@:2}" > /tmp/prof.log 2>&1
 cd $GRAFT_REPO_ROOT
 python - <<PY
 import sqlite3, glob
