@@ -19,7 +19,10 @@ Extra objects on the JSON line: "roofline" for the dominant kernel
 (k_symv_packed; HIP events recorded by the library on its own stream around
 every 16th launch inside the timed solve) and "cpu_baseline" (the NumPy/SciPy
 oracle -- a restatement, NOT the Julia reference, which cannot run here -- on a
-bounded sample of the same instance, rank 0, N = 1 only).
+bounded sample of the same instance, rank 0, N = 1 only), plus "packed_operator"
+(same window with the reference's mat-vec operator), "rank_sqrt_n" (window
+started at the metric's target rank), "time_to_tol" and "config_maxcut_n1000"
+(BASELINE config 2 on both sides).
 """
 import argparse
 import json
@@ -221,6 +224,19 @@ def main():
                                          "instance, %.1f s of CPU work, OpenBLAS threads=%d" % (cpu_it, cpu_loop, ncores),
                                "gpu_it_per_s_same_iterations": min(cpu_it, len(tr)) / max(gpu_same, 1e-9),
                                "wall_s": time.time() - tc}
+        # BASELINE config 2 (Max-Cut n=1000, the size the CPU path handles comfortably): the same
+        # 200 iterations on both sides ("iterations 1-200 at n=1000 fully")
+        pr2 = problems.maxcut(1000, seed=args.seed)
+        o.time_limit = 3600.0
+        o.max_iter = 200
+        tc2 = time.time()
+        ref2 = oracle.solve(pr2, o)
+        g2 = Optimizer(max_iter=200, device_id=dev_id).optimize(pr2, trace_capacity=200)
+        out["config_maxcut_n1000"] = {
+            "iterations": [1, int(ref2.iter)],
+            "cpu_it_per_s": ref2.iter / max(ref2.stats["loop_time"], 1e-9), "cpu_kind": "port", "cpu_cores": ncores,
+            "gpu_it_per_s": g2.iter / max(g2.stats["loop_time"], 1e-9),
+            "same_iteration_count": bool(int(g2.iter) == int(ref2.iter)), "wall_s": time.time() - tc2}
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
