@@ -853,6 +853,20 @@ k_reconstruct_packed(const double* __restrict__ Z, int ldz, const double* __rest
     int I, J;
     tile_coords(tile, I, J);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int gi = I * TILE + lane;
+    // the old iterate and the support mask of this thread's 16 entries are requested first, so
+    // that the 8 N bytes of x_old stream in while the factors are staged and multiplied
+    double xo[CPW];
+    unsigned mk[CPW];
+    if (FUSE_RES) {
+#pragma unroll
+        for (int k = 0; k < CPW; ++k) {
+            const int gjc = min(J * TILE + w * CPW + k, n - 1);
+            const long long idxc = (long long)gjc * (gjc + 1) / 2 + min(gi, gjc);      // always a valid entry
+            xo[k] = xold[idxc];
+            mk[k] = mask[(mask_off + idxc) >> 5];
+        }
+    }
     double acc[CPW];
 #pragma unroll
     for (int k = 0; k < CPW; ++k) acc[k] = 0.0;
@@ -863,9 +877,9 @@ k_reconstruct_packed(const double* __restrict__ Z, int ldz, const double* __rest
             const int kk = t / TILE, rr = t % TILE;
             double zi = 0.0, zj = 0.0;
             if (kk < kc) {
-                const int gi = I * TILE + rr, gj = J * TILE + rr;
-                if (gi < n) zi = Z[(long long)(k0 + kk) * ldz + gi];
-                if (gj < n) zj = Z[(long long)(k0 + kk) * ldz + gj] * lam[k0 + kk];
+                const int gi2 = I * TILE + rr, gj2 = J * TILE + rr;
+                if (gi2 < n) zi = Z[(long long)(k0 + kk) * ldz + gi2];
+                if (gj2 < n) zj = Z[(long long)(k0 + kk) * ldz + gj2] * lam[k0 + kk];
             }
             s_ZI[kk][rr] = zi;
             s_ZJ[kk][rr] = zj;
@@ -878,7 +892,6 @@ k_reconstruct_packed(const double* __restrict__ Z, int ldz, const double* __rest
             for (int k = 0; k < CPW; ++k) acc[k] += zi * s_ZJ[kk][w * CPW + k];
         }
     }
-    const int gi = I * TILE + lane;
     double m0 = 0.0, m1 = 0.0;
 #pragma unroll
     for (int k = 0; k < CPW; ++k) {
@@ -890,11 +903,10 @@ k_reconstruct_packed(const double* __restrict__ Z, int ldz, const double* __rest
             xp[idx] = xn;
             if (FUSE_RES) {
                 const long long gidx = mask_off + idx;
-                const bool on = (mask[gidx >> 5] >> (gidx & 31)) & 1u;
+                const bool on = (mk[k] >> (gidx & 31)) & 1u;
                 if (!on) {
-                    const double xo = xold[idx];
-                    m0 = fmax(m0, fabs(xn - xo));
-                    m1 = fmax(m1, fabs(xo));
+                    m0 = fmax(m0, fabs(xn - xo[k]));
+                    m1 = fmax(m1, fabs(xo[k]));
                 }
             }
         }
