@@ -328,6 +328,15 @@ constexpr int NRM_SLOT = MAXK - 1;  // slot of a partial-dots row that carries |
 // workgroups rounded up to 64, padding stays zero), so that the consumer reads the
 // partials of one basis column with ONE coalesced load per wave.
 
+// start of a projection: V[:,0] = start vector, control block cleared (one launch instead of a
+// device-to-device copy plus a memset in the solve stream)
+__global__ void __launch_bounds__(TPB)
+k_lz_begin(double* __restrict__ V0, const double* __restrict__ resid, int npad, LanczosCtl* __restrict__ ctl) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i < npad) V0[i] = resid[i];
+    if (i == 0) { ctl->stop = 0; ctl->kstop = 0; ctl->carry = 0.0; }
+}
+
 // y = smat(xp) v from the mat-vec partial slots (test seam / residual checks):
 // w = (sum of slots) / sqrt2, fixed order.
 __global__ void __launch_bounds__(TPB)

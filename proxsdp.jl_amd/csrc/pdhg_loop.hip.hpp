@@ -94,7 +94,8 @@ inline void Solver::project_block(int idx, const double* xin, double* xout, bool
     if (W.fop_ok) {                           // x_new = Z[:, first..] diag(lam) Z': keep the factors
         std::swap(W.Z.p, W.F.p);
         W.F_first = first; W.F_r = npos;
-        if (npos > 0) PX_HIP(hipMemcpyAsync(W.Flam.p, W.lam.p, (size_t)npos * 8, hipMemcpyDeviceToDevice, stream));
+        std::swap(W.lam.p, W.Flam.p);            // the eigenvalues just uploaded become the next projection's factors
+        std::swap(W.lam.n, W.Flam.n);
         W.have_factors = true; W.x_prev_sparse = false;
     }
 }
@@ -663,7 +664,7 @@ inline void Solver::setup_support() {
             W.ell_col.alloc(col.size()); W.ell_sidx.alloc(sx.size());
             W.ell_col.upload(col.data(), col.size(), stream); W.ell_sidx.upload(sx.data(), sx.size(), stream);
             W.F.alloc((size_t)W.npad * W.cap); W.F.zero(stream);
-            W.Flam.alloc(dev::MAXK); W.Flam.zero(stream);
+            W.Flam.alloc(std::max(W.n, dev::MAXK)); W.Flam.zero(stream);
             W.tpart.alloc((size_t)dev::MAXK * W.pld); W.tpart.zero(stream);
             W.ebuf.alloc(W.npad); W.ebuf.zero(stream);
             W.apartf.alloc(W.pld); W.apartf.zero(stream);

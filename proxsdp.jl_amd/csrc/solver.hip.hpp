@@ -141,6 +141,7 @@ struct EigWork {
     DevBuf<double> w, Ppart, hpart1, hpart2, hsum1, hred, U, lam, resid, Apart, arrow;
     int napart = 0;
     PinnedBuf arrow_host;
+    const double* arrow_p = nullptr;   // where the kernels read the arrow part: behind U after a restart upload
     // alphas[MAXK] | betas[MAXK] | LanczosCtl in ONE device record, read back with one copy
     DevBuf<double> rec;
     double* alphas_p = nullptr; double* betas_p = nullptr; dev::LanczosCtl* ctl_p = nullptr;
@@ -158,7 +159,7 @@ struct EigWork {
     int count = 0, converged_eigs = 0, numiter = 0, prev_numiter = 1;
     bool converged = false;
     // operator-form mat-vec (kernels.hip.hpp "Operator-form mat-vec")
-    DevBuf<double> F, Flam, tpart, ebuf, apartf;   // F: npad x cap, the previous projection's Ritz vectors (swapped with Z)
+    DevBuf<double> F, Flam, tpart, ebuf, apartf;   // (lam / Flam swap roles every projection)   // F: npad x cap, the previous projection's Ritz vectors (swapped with Z)
     DevBuf<int> ell_col, ell_sidx;                 // E in ELL form, [k * npad + row]
     int ell_w = 0, F_first = 0, F_r = 0;
     bool fop_ok = false;                           // structures built (support path, narrow rows)
@@ -213,7 +214,8 @@ public:
     void launch_symv_finish(EigWork& W, const double* xp, int kclose, double tol, bool use_carry);
     void launch_reconstruct(EigWork& W, const double* Z, int ldz, const double* lam, int r, double* xp_out,
                             const double* xp_old = nullptr, int blk = -1);
-    void rotate(EigWork& W, int K, const std::vector<double>& U, int ldu, int ncols, double* out, int copy_src, int copy_dst);
+    void rotate(EigWork& W, int K, const std::vector<double>& U, int ldu, int ncols, double* out, int copy_src, int copy_dst,
+                const double* extra, int nextra);
 
     // test hooks (capi.hip)
     void test_project(int idx, double* xp, int tr);
@@ -383,7 +385,8 @@ inline void Solver::alloc_eigwork(EigWork& W, int n, int max_nev) {
     W.ctl_p = reinterpret_cast<dev::LanczosCtl*>(W.rec.p + 2 * dev::MAXK);
     W.rec_pinned.alloc(EigWork::REC_DOUBLES);
     W.rec_host = W.rec_pinned.p;
-    W.U.alloc((size_t)dev::MAXK * dev::MAXK);
+    W.U.alloc((size_t)dev::MAXK * dev::MAXK + 2 * dev::MAXK);
+    W.arrow_p = W.arrow.p;
     W.lam.alloc(std::max(n, dev::MAXK));
     W.resid.alloc(W.npad);
     W.V.zero(stream); W.Z.zero(stream); W.w.zero(stream);
@@ -531,16 +534,20 @@ inline void Solver::launch_reconstruct(EigWork& W, const double* Z, int ldz, con
 }
 
 inline void Solver::rotate(EigWork& W, int K, const std::vector<double>& U, int ldu, int ncols,
-                           double* out, int copy_src, int copy_dst) {
+                           double* out, int copy_src, int copy_dst, const double* extra, int nextra) {
     // U: host column-major (ldu x >=ncols); upload the K x ncols part compactly from a
     // staging buffer that alternates between two slots: two rotations can be in flight
     // between host synchronisations (restart rotation, then the final Ritz-vector one)
     std::vector<double>& tmp = W.Ustage[W.ustage_next];
     W.ustage_next ^= 1;
-    tmp.resize((size_t)K * std::max(ncols, 1));
+    // `extra` (the arrow part f | D of the restarted Rayleigh quotient) rides behind U in the same
+    // host-to-device copy; the kernels find it at W.arrow_p
+    tmp.resize((size_t)K * std::max(ncols, 1) + (size_t)std::max(nextra, 0));
     for (int c = 0; c < ncols; ++c)
         for (int j = 0; j < K; ++j) tmp[(size_t)c * K + j] = U[(size_t)c * ldu + j];
-    W.U.upload(tmp.data(), (size_t)K * ncols, stream);
+    for (int q = 0; q < nextra; ++q) tmp[(size_t)K * ncols + q] = extra[q];
+    W.U.upload(tmp.data(), (size_t)K * ncols + (size_t)std::max(nextra, 0), stream);
+    if (nextra > 0) W.arrow_p = W.U.p + (size_t)K * ncols;
     // dynamic LDS: U chunk (K x cn) + V tile (K x 65).  gfx950 has 160 KiB of LDS per CU: the
     // kernel is allowed 144 KiB (setup_device), so a whole restart rotation is ONE launch up to
     // K = 127 (with a 60 KiB cap the V tile alone no longer fitted at K >= 116 and the loop
@@ -577,8 +584,8 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev) {
     if (arpack && (!(0 < nev && nev < W.n) || krylovdim > W.n)) return;   // dsaupd info=-1/-3 -> error -> fallback
 
     const double step_tol = arpack ? 0.0 : tol;       // invariant-subspace test inside the recurrence
-    PX_HIP(hipMemsetAsync(W.ctl_p, 0, sizeof(dev::LanczosCtl), stream));
-    PX_HIP(hipMemcpyAsync(W.V.p, W.resid.p, (size_t)W.npad * 8, hipMemcpyDeviceToDevice, stream));
+    hipLaunchKernelGGL(dev::k_lz_begin, dim3(ceil_div(W.npad, dev::TPB)), dim3(dev::TPB), 0, stream,
+                       W.V.p, (const double*)W.resid.p, W.npad, W.ctl_p);
 
     const int ld = krylovdim + 1;
     std::vector<double> T((size_t)ld * ld, 0.0), Tw, D(ld), U, f(ld), al(ld), be(ld), Qa, da, ea;
@@ -611,7 +618,7 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev) {
                                    (const double*)W.Ppart.p, W.nt, W.npad, (const double*)W.V.p, W.npad, k, W.w.p,
                                    (const double*)W.hred.p, hp[k & 1], W.pld, W.hsum1.p,
                                    (const dev::LanczosCtl*)W.ctl_p, (const double*)W.alphas_p, (const double*)W.betas_p,
-                                   (const double*)W.Apart.p, W.napart, k == kfirst ? 1 : 0, (const double*)W.arrow.p,
+                                   (const double*)W.Apart.p, W.napart, k == kfirst ? 1 : 0, (const double*)W.arrow_p,
                                    kfirst, fo);
             };
             switch (nch * 3 + nchp) {
@@ -723,8 +730,7 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev) {
         // arrow part of the restarted T for k_lz_orth: f (couplings of v_K with the kept Ritz
         // vectors) and D (their Ritz values)
         for (int j = 0; j < keep; ++j) { W.arrow_host.p[j] = f[j]; W.arrow_host.p[dev::MAXK + j] = D[j]; }
-        PX_HIP(hipMemcpyAsync(W.arrow.p, W.arrow_host.p, 2 * dev::MAXK * sizeof(double), hipMemcpyHostToDevice, stream));
-        rotate(W, K, U, K, keep, W.Z.p, K, keep);        // Z[:, :keep] = V U[:, :keep]; Z[:, keep] = V[:, K]
+        rotate(W, K, U, K, keep, W.Z.p, K, keep, W.arrow_host.p, 2 * dev::MAXK);   // Z[:, :keep] = V U[:, :keep]; Z[:, keep] = V[:, K]
         std::swap(W.V.p, W.Z.p);
         std::fill(T.begin(), T.end(), 0.0);
         for (int j = 0; j < keep; ++j) {
@@ -748,7 +754,7 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev) {
         std::vector<double> Ur((size_t)K * nev);
         for (int c = 0; c < nev; ++c)
             for (int r = 0; r < K; ++r) Ur[(size_t)c * K + r] = U[(size_t)(nev - 1 - c) * K + r];
-        rotate(W, K, Ur, K, nev, W.Z.p, -1, 0);
+        rotate(W, K, Ur, K, nev, W.Z.p, -1, 0, nullptr, 0);
         W.converged = true;
         return;
     }
@@ -757,7 +763,7 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev) {
     W.vals.assign(D.begin(), D.begin() + howmany);
     W.converged_eigs = converged;
     W.converged = (converged != 0);                      // eigsolver.jl:816-818
-    rotate(W, K, U, K, howmany, W.Z.p, -1, 0);            // Ritz vectors B*v
+    rotate(W, K, U, K, howmany, W.Z.p, -1, 0, nullptr, 0);            // Ritz vectors B*v
 }
 
 // eigen!(Symmetric(smat(xp))) through rocSOLVER dsyevd (ascending), the dense
