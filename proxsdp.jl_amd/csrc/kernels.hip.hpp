@@ -1254,18 +1254,18 @@ k_spmvT_S_batch(const int* __restrict__ colptr, const int* __restrict__ row, con
 
 // on-support part of compute_residual! + c.x (residuals.jl:22,41-48), per candidate
 // part[c][q][wg], q = 0: max |dPx|  1: max |Px_old|  2: sum c*x
-__global__ void __launch_bounds__(TPB)
-k_residual_xS_batch(const double* __restrict__ xnew, const int* __restrict__ supp, int ns,
-                    const double* __restrict__ xsave, double xold_coef,
-                    const double* __restrict__ MtyScand, long long mstride, const double* __restrict__ MtyS_old,
-                    const double* __restrict__ cS, TrialBatch tb, double* __restrict__ part, int pstride,
-                    long long cstride) {
-    __shared__ double sm[NWAVE];
+__device__ __forceinline__ void
+residual_xS_body(const double* __restrict__ xnew, const int* __restrict__ supp, int ns,
+                 const double* __restrict__ xsave, double xold_coef,
+                 const double* __restrict__ MtyScand, long long mstride, const double* __restrict__ MtyS_old,
+                 const double* __restrict__ cS, const TrialBatch& tb, double* __restrict__ part, int pstride,
+                 long long cstride, int gx, double* __restrict__ sm) {
+    if ((int)blockIdx.x >= gx) return;
     const int c = blockIdx.y;
     const double tau = tb.tau[c];
     const double* MtyS = MtyScand + (long long)c * mstride;
     double m0 = 0.0, m1 = 0.0, s2 = 0.0;
-    for (int s = blockIdx.x * TPB + threadIdx.x; s < ns; s += gridDim.x * TPB) {
+    for (int s = blockIdx.x * TPB + threadIdx.x; s < ns; s += gx * TPB) {
         const double xi = xnew[supp[s]];
         const double pold = xold_coef * xsave[s] - tau * MtyS_old[s];
         const double pnew = xi - tau * MtyS[s];
@@ -1281,17 +1281,17 @@ k_residual_xS_batch(const double* __restrict__ xnew, const int* __restrict__ sup
 }
 
 // y part of compute_residual! + compute_gap! per candidate; part[c][q][wg], q as in k_residual_y
-__global__ void __launch_bounds__(TPB)
-k_residual_y_batch(const double* __restrict__ ycand, long long ystride, const double* __restrict__ yold,
-                   const double* __restrict__ Mx, const double* __restrict__ Mx_old,
-                   const double* __restrict__ bh, int p, int Q, TrialBatch tb,
-                   double* __restrict__ part, int pstride, long long cstride) {
-    __shared__ double sm[NWAVE];
+__device__ __forceinline__ void
+residual_y_body(const double* __restrict__ ycand, long long ystride, const double* __restrict__ yold,
+                const double* __restrict__ Mx, const double* __restrict__ Mx_old,
+                const double* __restrict__ bh, int p, int Q, const TrialBatch& tb,
+                double* __restrict__ part, int pstride, long long cstride, int gx, double* __restrict__ sm) {
+    if ((int)blockIdx.x >= gx) return;
     const int c = blockIdx.y;
     const double sigma = tb.sigma[c];
     const double* y = ycand + (long long)c * ystride;
     double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0, s4 = 0.0, s5 = 0.0;
-    for (int i = blockIdx.x * TPB + threadIdx.x; i < Q; i += gridDim.x * TPB) {
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < Q; i += gx * TPB) {
         const double yi = y[i], mx = Mx[i], rhs = bh[i];
         const double pold = yold[i] - sigma * Mx_old[i];
         const double pnew = yi - sigma * mx;
@@ -1308,6 +1308,26 @@ k_residual_y_batch(const double* __restrict__ ycand, long long ystride, const do
         pp[b] = r0; pp[pstride + b] = r1; pp[2 * pstride + b] = r2; pp[3 * pstride + b] = r3;
         pp[4 * pstride + b] = r4; pp[5 * pstride + b] = r5;
     }
+}
+
+// both residual parts of every candidate in ONE launch: grid (max(gs, gq), nc, 2), z = 0 the
+// on-support x part, z = 1 the y part (they are independent; one link less in the per-iteration chain)
+__global__ void __launch_bounds__(TPB)
+k_residual_xy_batch(const double* __restrict__ xnew, const int* __restrict__ supp, int ns,
+                    const double* __restrict__ xsave, double xold_coef,
+                    const double* __restrict__ MtyScand, long long mstride, const double* __restrict__ MtyS_old,
+                    const double* __restrict__ cS, int gs,
+                    const double* __restrict__ ycand, long long ystride, const double* __restrict__ yold,
+                    const double* __restrict__ Mx, const double* __restrict__ Mx_old,
+                    const double* __restrict__ bh, int p, int Q, int gq,
+                    TrialBatch tb, double* __restrict__ part, int pstride, long long cstride) {
+    __shared__ double sm[NWAVE];
+    if (blockIdx.z == 0)
+        residual_xS_body(xnew, supp, ns, xsave, xold_coef, MtyScand, mstride, MtyS_old, cS, tb,
+                         part + 2 * (long long)pstride, pstride, cstride, gs, sm);
+    else
+        residual_y_body(ycand, ystride, yold, Mx, Mx_old, bh, p, Q, tb,
+                        part + 5 * (long long)pstride, pstride, cstride, gq, sm);
 }
 
 // non-PSD tail of x (SOC + free variables): x_new = x_trial copied to the other buffer,
@@ -1531,13 +1551,17 @@ k_dense_frob(const double* __restrict__ M, long long ld, int Q, long long n,
     if (threadIdx.x == 0) part[blockIdx.x] = tot;
 }
 
-// one workgroup per quantity: out[q] = sum or max of part[q*stride .. +cnt)
+// one workgroup per quantity: out[q] = sum or max of part[q*stride .. +cnt); workgroups
+// q >= nq1 reduce a second family (maxima): out2[q - nq1] = max of part2[(q-nq1)*stride2 .. +cnt2)
 __global__ void __launch_bounds__(TPB)
 k_combine_multi(const double* __restrict__ part, int stride, int cnt, unsigned long long ismax,
-                double* __restrict__ out) {
+                double* __restrict__ out, int nq1, const double* __restrict__ part2, int stride2, int cnt2,
+                double* __restrict__ out2) {
     __shared__ double sm[NWAVE];
-    const int q = blockIdx.x;
-    const bool mx = (ismax >> q) & 1ull;
+    int q = blockIdx.x;
+    bool mx;
+    if (q >= nq1) { q -= nq1; part = part2; stride = stride2; cnt = cnt2; out = out2; mx = true; }
+    else mx = (ismax >> q) & 1ull;
     double a = 0.0;
     for (int i = threadIdx.x; i < cnt; i += TPB) {
         const double v = part[(long long)q * stride + i];

@@ -564,7 +564,8 @@ inline int Solver::linesearch_dense() {
         dense_mtv(nc, ycand_d.p, ystride, true, Mtycand_d.p, (long long)P.n, Mtybuf[mtyc].p, nullptr,
                   bpart.p + PSTRIDE, cstride);
         hipLaunchKernelGGL(dev::k_combine_multi, dim3(nc * 2), dim3(dev::TPB), 0, stream,
-                           bpart.p, PSTRIDE, std::max(gq, gx), 0ull, bscal.p);
+                           (const double*)bpart.p, PSTRIDE, std::max(gq, gx), 0ull, bscal.p, nc * 2,
+                           (const double*)nullptr, 0, 0, (double*)nullptr);
         PX_HIP(hipMemcpyAsync(hbscal.data(), bscal.p, NC * 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
         PX_HIP(hipStreamSynchronize(stream));
         for (int c = 0; c < nc; ++c) {
@@ -692,9 +693,8 @@ inline int Solver::linesearch_residual_support() {
     int trials = 0;
     bool accepted = false;
     const double* s_acc = nullptr;
-    // off-support residual maxima of this iteration (independent of the candidate)
-    hipLaunchKernelGGL(dev::k_combine_multi, dim3(2), dim3(dev::TPB), 0, stream,
-                       respart_d.p, rstride, n_res_wg, 0x3ull, bscal.p + NC * 11);
+    // (the off-support residual maxima of this iteration, independent of the candidate, are
+    // reduced by the two extra workgroups of the batch's final combine)
     while (!accepted && trials < opt.max_linsearch_steps) {
         dev::TrialBatch tb{};
         double tau_c = primal_step;
@@ -713,17 +713,17 @@ inline int Solver::linesearch_residual_support() {
         hipLaunchKernelGGL(dev::k_spmvT_S_batch, dim3(gs, nc), dim3(dev::TPB), 0, stream,
                            csc_ptr.p, csc_row.p, csc_val.p, supp_d.p, ns, ycand_d.p, ystride,
                            MtyS_cand.p, mstride, MtyS_cur.p, bpart.p + PSTRIDE, cstride);
-        hipLaunchKernelGGL(dev::k_residual_xS_batch, dim3(gs, nc), dim3(dev::TPB), 0, stream,
+        hipLaunchKernelGGL(dev::k_residual_xy_batch, dim3(std::max(gs, gq), nc, 2), dim3(dev::TPB), 0, stream,
                            xbuf[1 - xc].p, supp_d.p, ns, xsave_d.p, xold_coef, MtyS_cand.p, mstride, MtyS_cur.p,
-                           cS_d.p, tb, bpart.p + 2 * PSTRIDE, PSTRIDE, cstride);
-        hipLaunchKernelGGL(dev::k_residual_y_batch, dim3(gq, nc), dim3(dev::TPB), 0, stream,
-                           ycand_d.p, ystride, ybuf[yc].p, Mxbuf[1 - mxc].p, Mxbuf[mxc].p, bh_d.p, (int)P.p, (int)P.Q,
-                           tb, bpart.p + 5 * PSTRIDE, PSTRIDE, cstride);
+                           cS_d.p, gs,
+                           ycand_d.p, ystride, ybuf[yc].p, Mxbuf[1 - mxc].p, Mxbuf[mxc].p, bh_d.p, (int)P.p, (int)P.Q, gq,
+                           tb, bpart.p, PSTRIDE, cstride);
         // per candidate: q0,q1 sums | q2,q3 max, q4 sum | q5..q8 max, q9,q10 sum
         unsigned long long ismax = 0;
         for (int c = 0; c < nc; ++c) ismax |= 0x1ECull << (11 * c);      // bits 2,3,5,6,7,8
-        hipLaunchKernelGGL(dev::k_combine_multi, dim3(nc * 11), dim3(dev::TPB), 0, stream,
-                           bpart.p, PSTRIDE, std::max(gq, gs), ismax, bscal.p);
+        hipLaunchKernelGGL(dev::k_combine_multi, dim3(nc * 11 + 2), dim3(dev::TPB), 0, stream,
+                           (const double*)bpart.p, PSTRIDE, std::max(gq, gs), ismax, bscal.p, nc * 11,
+                           (const double*)respart_d.p, rstride, n_res_wg, bscal.p + NC * 11);
         PX_HIP(hipMemcpyAsync(hbscal.data(), bscal.p, (NC * 11 + 2) * sizeof(double), hipMemcpyDeviceToHost, stream));
         PX_HIP(hipStreamSynchronize(stream));
         if (sharded()) {
