@@ -711,12 +711,23 @@ k_symv_finish(const double* __restrict__ xp, int n, int nt, int npad, double* __
 // E is kept in ELL form per PSD block: entry k of row i at [k*npad + i]: column, index into the
 // support-value array (-1 = padding); off-diagonal values carry the svec sqrt(2).
 // ---------------------------------------------------------------------------
+// rows of E wider than the ELL part (hub vertices): their remaining entries, handled by the whole
+// workgroup of the row's block with a fixed-order reduction
+struct EllOverflow {
+    const int* wr_ptr;       // [nt + 1] wide rows of each 64-row block
+    const int* wr_row;       // local row (0..63)
+    const int* wr_lo;        // range into ov_col / ov_sidx
+    const int* wr_hi;
+    const int* ov_col;
+    const int* ov_sidx;
+};
 template <int NCHP>
 __device__ __forceinline__ void fop_body(const double* __restrict__ v, const double* __restrict__ Vp, int ldv, int rp,
                                          const int* __restrict__ ell_col, const int* __restrict__ ell_sidx, int ell_w,
                                          int npad, const double* __restrict__ esv, double* __restrict__ tpart, int pld,
                                          double* __restrict__ ebuf, double* __restrict__ apart, int g,
-                                         double* __restrict__ s_e /* NWAVE*64 */, const LanczosCtl* __restrict__ ctl) {
+                                         double* __restrict__ s_e /* NWAVE*64 */, const LanczosCtl* __restrict__ ctl,
+                                         const EllOverflow& ov) {
     constexpr int NCP = 16 * NCHP;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -753,6 +764,27 @@ __device__ __forceinline__ void fop_body(const double* __restrict__ v, const dou
             if (sx[u] >= 0) e += ((col[u] == i) ? ev[u] : ev[u] * INV_SQRT2) * xv[u];
     }
     s_e[wv * LZ_ROWS + lane] = e;
+    if (ov.wr_ptr != nullptr) {
+        const int q0 = ov.wr_ptr[g], q1 = ov.wr_ptr[g + 1];
+        if (q1 > q0) {                                   // uniform over the workgroup; rare
+            __shared__ double s_w[NWAVE];
+            __syncthreads();
+            for (int q = q0; q < q1; ++q) {
+                const int rloc = ov.wr_row[q], grow = g * LZ_ROWS + rloc;
+                double a = 0.0;
+                for (int k = ov.wr_lo[q] + (int)threadIdx.x; k < ov.wr_hi[q]; k += TPB) {
+                    const int col = ov.ov_col[k];
+                    const double evk = esv[ov.ov_sidx[k]];
+                    a += ((col == grow) ? evk : evk * INV_SQRT2) * v[col];
+                }
+                a = wave_sum(a);
+                if (lane == 0) s_w[wv] = a;
+                __syncthreads();
+                if (threadIdx.x == 0) s_e[rloc] += (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+                __syncthreads();
+            }
+        }
+    }
     // Vp' v partials of this workgroup's rows
 #pragma unroll
     for (int ch = 0; ch < NCHP; ++ch) {
@@ -777,9 +809,9 @@ __global__ void __launch_bounds__(TPB)
 k_fop(const double* __restrict__ v, const double* __restrict__ Vp, int ldv, int rp,
       const int* __restrict__ ell_col, const int* __restrict__ ell_sidx, int ell_w, int npad,
       const double* __restrict__ esv, double* __restrict__ tpart, int pld, double* __restrict__ ebuf,
-      double* __restrict__ apart, const LanczosCtl* __restrict__ ctl) {
+      double* __restrict__ apart, const LanczosCtl* __restrict__ ctl, EllOverflow ov) {
     __shared__ double s_e[NWAVE * LZ_ROWS];
-    fop_body<NCHP>(v, Vp, ldv, rp, ell_col, ell_sidx, ell_w, npad, esv, tpart, pld, ebuf, apart, blockIdx.x, s_e, ctl);
+    fop_body<NCHP>(v, Vp, ldv, rp, ell_col, ell_sidx, ell_w, npad, esv, tpart, pld, ebuf, apart, blockIdx.x, s_e, ctl, ov);
 }
 // closing work of step k (workgroups [0, nt)) + operator rows of step k+1 on w' ([nt, 2 nt))
 template <int NCHP, int NCH>
@@ -790,7 +822,7 @@ k_fop_finish(const double* __restrict__ wbuf, double* __restrict__ V, int ldv, i
              int use_carry, int nt, const double* __restrict__ Vp, int rp,
              const int* __restrict__ ell_col, const int* __restrict__ ell_sidx, int ell_w, int npad,
              const double* __restrict__ esv, double* __restrict__ tpart, double* __restrict__ ebuf,
-             double* __restrict__ apart, double* __restrict__ hred) {
+             double* __restrict__ apart, double* __restrict__ hred, EllOverflow ov) {
     __shared__ double s_a[2 * NWAVE * TILE];
     __shared__ double s_b[NWAVE * LZ_ROWS];
     __shared__ double s_beta;
@@ -799,7 +831,7 @@ k_fop_finish(const double* __restrict__ wbuf, double* __restrict__ V, int ldv, i
                             s_a, s_b, &s_beta, hred);
     } else {
         fop_body<NCHP>(wbuf, Vp, ldv, rp, ell_col, ell_sidx, ell_w, npad, esv, tpart, pld, ebuf, apart,
-                       (int)blockIdx.x - nt, s_b, ctl);
+                       (int)blockIdx.x - nt, s_b, ctl, ov);
     }
 }
 

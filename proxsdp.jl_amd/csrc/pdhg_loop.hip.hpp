@@ -651,19 +651,49 @@ inline void Solver::setup_support() {
                 if (i != (int)j) { ent.push_back({(int)j, i, (int)sidx}); cnt[j]++; }
             }
             s0 = s1;
-            int w = 1;
-            for (int c : cnt) w = std::max(w, c);
-            if (w > 64) continue;                                 // a hub row: keep the packed mat-vec
+            int wmax = 1;
+            for (int c : cnt) wmax = std::max(wmax, c);
+            // ELL part of at most 32 entries per row; the rest of a wider (hub) row goes to an
+            // overflow list that the row's workgroup reduces cooperatively
+            const int w = std::min(wmax, 32);
+            // measured (tools/gpurun_opcmp.py): below n ~ 2000 the two operators cost the same
+            // (latency-bound), and a hub row costs the operator form ~15 us per mat-vec at
+            // n = 1000 (maxG51) -- more than streaming a packed triangle of up to ~100 MB.  With
+            // hub rows the operator form is therefore only taken for large blocks.
+            if (wmax > w && B.n < 6000 && opt.lanczos_operator < 0) continue;
             std::vector<int> col((size_t)w * W.npad), sx((size_t)w * W.npad, -1);
             for (int k = 0; k < w; ++k) for (int i = 0; i < W.npad; ++i) col[(size_t)k * W.npad + i] = i;
+            std::vector<std::vector<std::array<int, 2>>> over(W.npad);
             std::fill(cnt.begin(), cnt.end(), 0);
             for (const auto& e : ent) {
-                const size_t at = (size_t)cnt[e[0]]++ * W.npad + e[0];
-                col[at] = e[1]; sx[at] = e[2];
+                const int kk = cnt[e[0]]++;
+                if (kk < w) { const size_t at = (size_t)kk * W.npad + e[0]; col[at] = e[1]; sx[at] = e[2]; }
+                else over[e[0]].push_back({e[1], e[2]});
             }
             W.ell_w = w;
             W.ell_col.alloc(col.size()); W.ell_sidx.alloc(sx.size());
             W.ell_col.upload(col.data(), col.size(), stream); W.ell_sidx.upload(sx.data(), sx.size(), stream);
+            W.ov = dev::EllOverflow{};
+            if (wmax > w) {
+                std::vector<int> wptr(W.nt + 1, 0), wrow, wlo, whi, ocol, osx;
+                for (int g = 0; g < W.nt; ++g) {
+                    for (int rl = 0; rl < dev::LZ_ROWS; ++rl) {
+                        const int row = g * dev::LZ_ROWS + rl;
+                        if (row >= W.npad || over[row].empty()) continue;
+                        wrow.push_back(rl); wlo.push_back((int)ocol.size());
+                        for (const auto& e : over[row]) { ocol.push_back(e[0]); osx.push_back(e[1]); }
+                        whi.push_back((int)ocol.size());
+                    }
+                    wptr[g + 1] = (int)wrow.size();
+                }
+                W.wr_ptr.alloc(wptr.size()); W.wr_row.alloc(wrow.size()); W.wr_lo.alloc(wlo.size()); W.wr_hi.alloc(whi.size());
+                W.ov_col.alloc(ocol.size()); W.ov_sidx.alloc(osx.size());
+                W.wr_ptr.upload(wptr.data(), wptr.size(), stream); W.wr_row.upload(wrow.data(), wrow.size(), stream);
+                W.wr_lo.upload(wlo.data(), wlo.size(), stream); W.wr_hi.upload(whi.data(), whi.size(), stream);
+                W.ov_col.upload(ocol.data(), ocol.size(), stream); W.ov_sidx.upload(osx.data(), osx.size(), stream);
+                W.ov = dev::EllOverflow{W.wr_ptr.p, W.wr_row.p, W.wr_lo.p, W.wr_hi.p, W.ov_col.p, W.ov_sidx.p};
+                PX_HIP(hipStreamSynchronize(stream));             // host vectors go out of scope
+            }
             W.F.alloc((size_t)W.npad * W.cap); W.F.zero(stream);
             W.Flam.alloc(std::max(W.n, dev::MAXK)); W.Flam.zero(stream);
             W.tpart.alloc((size_t)dev::MAXK * W.pld); W.tpart.zero(stream);

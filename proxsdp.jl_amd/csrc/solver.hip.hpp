@@ -161,6 +161,8 @@ struct EigWork {
     // operator-form mat-vec (kernels.hip.hpp "Operator-form mat-vec")
     DevBuf<double> F, Flam, tpart, ebuf, apartf;   // (lam / Flam swap roles every projection)   // F: npad x cap, the previous projection's Ritz vectors (swapped with Z)
     DevBuf<int> ell_col, ell_sidx;                 // E in ELL form, [k * npad + row]
+    DevBuf<int> wr_ptr, wr_row, wr_lo, wr_hi, ov_col, ov_sidx;   // entries beyond the ELL width (hub rows)
+    dev::EllOverflow ov{};
     int ell_w = 0, F_first = 0, F_r = 0;
     bool fop_ok = false;                           // structures built (support path, narrow rows)
     bool have_factors = false;                     // x_prev of this block is F[:, F_first .. +F_r) diag(Flam) F'
@@ -470,7 +472,7 @@ inline void Solver::launch_symv(EigWork& W, const double* xp, const double* v, b
         launch_prof(prof, e0, e1, kern, dim3(W.nt), stream,
                     v, (const double*)(W.F.p + (size_t)W.F_first * W.npad), W.npad, W.F_r,
                     (const int*)W.ell_col.p, (const int*)W.ell_sidx.p, W.ell_w, W.npad, W.esv, W.tpart.p, W.pld,
-                    W.ebuf.p, W.apartf.p, (const dev::LanczosCtl*)(use_ctl ? W.ctl_p : nullptr));
+                    W.ebuf.p, W.apartf.p, (const dev::LanczosCtl*)(use_ctl ? W.ctl_p : nullptr), W.ov);
     } else {
         launch_prof(prof, e0, e1, dev::k_symv_packed, dim3(ntile), stream,
                     xp, W.n, W.nt, W.npad, v, W.Ppart.p, (const dev::LanczosCtl*)(use_ctl ? W.ctl_p : nullptr), W.Apart.p);
@@ -507,7 +509,7 @@ inline void Solver::launch_symv_finish(EigWork& W, const double* xp, int kclose,
                     (const double*)W.hsum1.p, W.alphas_p, W.betas_p, W.ctl_p, tol, use_carry ? 1 : 0, W.nt,
                     (const double*)(W.F.p + (size_t)W.F_first * W.npad), W.F_r,
                     (const int*)W.ell_col.p, (const int*)W.ell_sidx.p, W.ell_w, W.npad, W.esv, W.tpart.p, W.ebuf.p,
-                    W.apartf.p, W.hred.p);
+                    W.apartf.p, W.hred.p, W.ov);
     } else {
         const int nchf = (kclose + 1 <= 64) ? 1 : (kclose + 1 <= 128) ? 2 : 3;
         auto ksf = nchf == 1 ? dev::k_symv_finish<1> : nchf == 2 ? dev::k_symv_finish<2> : dev::k_symv_finish<3>;

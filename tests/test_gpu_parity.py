@@ -469,7 +469,7 @@ def test_support_and_dense_paths_agree_on_maxcut():
     assert abs(a.objval - b.objval) <= 1e-3 * (1 + abs(a.objval))
 
 
-@pytest.mark.parametrize("case", ["maxcut", "two_blocks", "periodic_full_eig", "arpack_rule"])
+@pytest.mark.parametrize("case", ["maxcut", "two_blocks", "periodic_full_eig", "arpack_rule", "hub_rows"])
 def test_operator_form_matvec_matches_packed_matvec(case):
     """lanczos_operator=1 (A v = Vp Lam Vp' v + E v from the previous projection's factors and the
     sparse support update) against lanczos_operator=0 (the packed triangle, what dsymv('U')
@@ -482,6 +482,17 @@ def test_operator_form_matvec_matches_packed_matvec(case):
         pr = P.maxcut(300, seed=2)
     elif case == "two_blocks":
         pr = P.block_diag_problems([P.maxcut(180, seed=1), P.maxcut(130, seed=4)])
+    elif case == "hub_rows":                     # vertices of degree 150 and 90: rows wider than the ELL part
+        L = P.erdos_renyi_laplacian(300, 6).tolil()
+        W = -L
+        W.setdiag(0)
+        for hub, deg in ((7, 150), (200, 90)):
+            for v in np.random.default_rng(hub).choice(300, size=deg, replace=False):
+                if v != hub:
+                    W[hub, v] = W[v, hub] = 1.0
+        W = W.tocsr()
+        import scipy.sparse as sp
+        pr = P.maxcut_from_laplacian((sp.diags(np.asarray(W.sum(axis=1)).ravel()) - W).tocsr(), name="maxcut-hubs")
     elif case == "arpack_rule":                  # eigsolver=1: dsaupd's acceptance rule on the same engine
         pr = P.maxcut(260, seed=5)
         kw.update(eigsolver=1)
