@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PROXSDP_HIP_ABI_VERSION 2
+#define PROXSDP_HIP_ABI_VERSION 3
 
 /* error codes (negative return values) */
 #define PROXSDP_E_INVALID  (-1)   /* invalid argument / inconsistent problem data */
@@ -203,6 +203,13 @@ typedef struct proxsdp_stats {
     double  dense_ms;            /* their summed durations (HIP events on the solve stream)    */
     int64_t fop_projections;     /* projections whose Lanczos mat-vecs ran in operator form     */
     int64_t exit_matvecs;        /* mat-vecs of the exit path's lambda_min(dual cone) Lanczos   */
+    double  host_eig_time;       /* s: K x K Rayleigh-quotient eigensolves done on the HOST     */
+    int64_t host_eigs;           /* how many of them                                            */
+    int64_t device_eigs;         /* K x K eigensolves done by the device eigensolver            */
+    int64_t batched_small_eigs;  /* small-block (n <= 32) projections done by the batched Jacobi kernel */
+    int64_t mfma_reconstructions;/* reconstructions that took the MFMA (v_mfma_f64_16x16x4) SYRK */
+    int64_t reserved_i[3];
+    double  reserved_d[4];
 } proxsdp_stats;
 
 /* Result (structs.jl:60-81).  Arrays are caller-allocated with the stated

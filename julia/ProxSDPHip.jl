@@ -76,6 +76,13 @@ struct Stats                     # proxsdp_stats
     dense_ms::Float64
     fop_projections::Int64
     exit_matvecs::Int64
+    host_eig_time::Float64
+    host_eigs::Int64
+    device_eigs::Int64
+    batched_small_eigs::Int64
+    mfma_reconstructions::Int64
+    reserved_i::NTuple{3,Int64}
+    reserved_d::NTuple{4,Float64}
 end
 
 mutable struct CResult           # proxsdp_result

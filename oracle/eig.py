@@ -235,7 +235,9 @@ def arpack_eig(arc, Xdata, nev, opt):
         d, v = scipy.sparse.linalg.eigsh(op, k=nev, which="LA", ncv=arc.ncv,
                                          tol=opt.arpack_tol, v0=arc.resid0.copy(),
                                          maxiter=opt.arpack_max_iter)
-    except scipy.sparse.linalg.ArpackNoConvergence:
+    except (scipy.sparse.linalg.ArpackNoConvergence, scipy.sparse.linalg.ArpackError):
+        # info outside 0..1 -> arc.arpackerror -> not converged -> full_eig! (eigsolver.jl:697-702);
+        # e.g. info = -9 "starting vector is zero" on the all-zero first iterate
         arc.matvecs += count[0]
         return
     del full

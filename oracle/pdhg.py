@@ -384,11 +384,15 @@ class _State:
     pass
 
 
-def primal_step(st, a, cones, M, c, opt, p, arc_list):
-    """primal_step! (pdhg.jl:611-637)."""
+def primal_step(st, a, cones, M, c, opt, p, arc_list, proj_callback=None):
+    """primal_step! (pdhg.jl:611-637).  proj_callback(iter, x_in, x_out, p, arc_list): test hook that
+    sees the vector handed to psd_projection! and what came back (captured-iterate fixtures)."""
     st.x -= p.primal_step * (a.Mty + c)
     if cones.sdpcone:
+        x_in = st.x.copy() if proj_callback is not None else None
         psd_projection(st.x, a, cones, opt, p, arc_list, p.iter)
+        if proj_callback is not None:
+            proj_callback(p.iter, x_in, st.x, p, arc_list)
     if cones.socone:
         soc_projection(st.x, a)
     a.Mx = M @ st.x
@@ -488,9 +492,12 @@ def dual_feas(y, cones, aff, c, A, G, a):
 
 
 def equilibrate(M, aff, opt):
-    """equilibrate! (equilibration.jl:1-72): projected-gradient row/column scaling.  NB the
-    reference replaces v by its mean in every iteration (:56-58), so D is a multiple of the
-    identity; reproduced as written.  Returns the diagonals (E over rows, D over columns)."""
+    """equilibrate! (equilibration.jl:1-72): projected-gradient row/column scaling.  Two quirks of
+    the reference, both reproduced as written: (i) v is replaced by its mean in every iteration
+    (:56-58), so D is a multiple of the identity; (ii) `E = Diagonal(u)`, `D = Diagonal(v)` (:16-17)
+    WRAP u and v without copying, so `E.diag .= exp.(u)` (:25-26) overwrites u with exp(u) (and v
+    with exp(v)) at the top of every iteration: the gradient and projection steps then start from
+    exp(u), exp(v).  Returns the diagonals (E over rows, D over columns)."""
     M = sp.csc_matrix(M)
     nQ, n = aff.m + aff.p, aff.n
     alpha = (n / nQ) ** 0.25
@@ -502,7 +509,8 @@ def equilibrate(M, aff, opt):
     rows = M.indices
     cols = np.repeat(np.arange(n), np.diff(M.indptr))
     for it in range(1, opt.equilibration_iters + 1):
-        Ed, Dd = np.exp(u), np.exp(v)
+        u, v = np.exp(u), np.exp(v)               # E.diag .= exp.(u) with E.diag === u  (aliasing, see docstring)
+        Ed, Dd = u, v
         d2 = (M.data * Dd[cols] * Ed[rows]) ** 2
         step_size = 2.0 / (gamma * (it + 1.0))
         row_norms = np.bincount(rows, weights=d2, minlength=nQ)
@@ -560,7 +568,7 @@ def cache_solution(st, res, cones, aff, p, opt, c, A, b, G, h, var_ordering, a, 
 
 
 def chambolle_pock(aff_in, cones, opt_in=None, *, eig_resid=None, trace=False,
-                   iter_callback=None):
+                   iter_callback=None, proj_callback=None):
     """chambolle_pock (pdhg.jl:1-530).  `aff_in` and `opt_in` are not mutated
     (the reference mutates both; the C ABI must not -- SURVEY.md section 8b).
     eig_resid: optional list of start vectors, one per PSD block."""
@@ -668,7 +676,7 @@ def chambolle_pock(aff_in, cones, opt_in=None, *, eig_resid=None, trace=False,
     while k < kmax:
         k += 1
         p.iter = k
-        primal_step(st, a, cones, M, aff.c, opt, p, arc_list)
+        primal_step(st, a, cones, M, aff.c, opt, p, arc_list, proj_callback)
         if opt.line_search_flag:
             linesearch(st, a, aff, Mt, opt, p)
         else:

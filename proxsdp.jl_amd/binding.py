@@ -114,7 +114,9 @@ class Stats(C.Structure):
                 ("symv_launches", i64), ("symv_profiled", i64), ("symv_profiled_ms", f64),
                 ("symv_bytes", f64), ("algorithmic_bytes", f64), ("init_time", f64),
                 ("loop_time", f64), ("exit_time", f64), ("t_primal", f64), ("t_psd", f64),
-                ("t_linesearch", f64), ("t_residual", f64), ("dense_passes", i64), ("dense_ms", f64), ("fop_projections", i64), ("exit_matvecs", i64)]
+                ("t_linesearch", f64), ("t_residual", f64), ("dense_passes", i64), ("dense_ms", f64), ("fop_projections", i64), ("exit_matvecs", i64),
+                ("host_eig_time", f64), ("host_eigs", i64), ("device_eigs", i64), ("batched_small_eigs", i64),
+                ("mfma_reconstructions", i64), ("reserved_i", i64 * 3), ("reserved_d", f64 * 4)]
 
 
 class Result(C.Structure):
@@ -177,7 +179,7 @@ def lib():
     L.proxsdp_host_symeig.argtypes = [i32, pf64, pf64]
     L.proxsdp_host_start_vector.argtypes = [i64, i64, i32, pf64]
     L.proxsdp_host_preprocess.argtypes = [C.POINTER(Problem), pi64, pi64, pf64, pf64]
-    if L.proxsdp_hip_abi_version() != 2:
+    if L.proxsdp_hip_abi_version() != 3:
         raise ProxSDPHipError(-1, "ABI version mismatch")
     _lib = L
     return L
@@ -289,7 +291,8 @@ class SolveResult:
             v = getattr(R, name)
             setattr(self, name, v.decode(errors="replace") if isinstance(v, bytes) else v)
         self.primal, self.dual_cone, self.dual_eq, self.dual_in, self.slack_eq, self.slack_in = arrays
-        self.stats = {k: getattr(R.stats, k) for k, _ in Stats._fields_}
+        self.stats = {k: (list(getattr(R.stats, k)) if k.startswith("reserved") else getattr(R.stats, k))
+                      for k, _ in Stats._fields_}
         self.trace = trace[:R.trace_rows].copy()
         for k in ("certificate_found", "primal_feasible_user_tol", "dual_feasible_user_tol"):
             setattr(self, k, bool(getattr(self, k)))

@@ -432,6 +432,11 @@ inline void Solver::cache_solution(const std::vector<double>& cvec) {
     res.result_count = 1;
     res.time = now_s() - time0;
     have_snapshot = true;
+    // x was rescaled IN PLACE above (the reference quirk, pdhg.jl:749-755).  When a certificate
+    // search continues from here, the operator-form factors F diag(Flam) F' still describe the
+    // UNscaled iterate: drop them so the next projection reads the (rescaled) packed buffer, as the
+    // fused residual and the dense / full-eig paths do.
+    for (EigWork& W : eig) { W.have_factors = false; W.x_prev_sparse = false; }
     st.exit_time += now_s() - t0;
 }
 
@@ -725,6 +730,33 @@ inline int Solver::linesearch_residual_support() {
     const double* s_acc = nullptr;
     // (the off-support residual maxima of this iteration, independent of the candidate, are
     // reduced by the two extra workgroups of the batch's final combine)
+    // block-sharded solve: every shard evaluated the same candidates on its own blocks/rows: combine
+    auto reduce_candidates = [&](int nc) {
+        if (!sharded()) return;
+        std::vector<double> sums, maxs;
+        for (int c = 0; c < NC; ++c) {
+            const double* sc = hbscal.data() + 11 * c;
+            for (int q : {0, 1, 4, 9, 10}) sums.push_back(c < nc ? sc[q] : 0.0);
+            for (int q : {2, 3, 5, 6, 7, 8}) maxs.push_back(c < nc ? sc[q] : 0.0);
+        }
+        maxs.push_back(hbscal[NC * 11]); maxs.push_back(hbscal[NC * 11 + 1]);
+        maxs.push_back(convergedrank() ? 0.0 : 1.0);          // any shard not rank-converged
+        bool below = false;
+        for (size_t idx = 0; idx < P.blocks.size(); ++idx) below = below || target_rank[idx] < P.blocks[idx].n;
+        maxs.push_back(below ? 1.0 : 0.0);                    // any block with target_rank < side
+        maxs.push_back(now_s() - time0);                      // one clock for the limits
+        reduce(sums, maxs);
+        size_t si = 0, mi = 0;
+        for (int c = 0; c < NC; ++c) {
+            double* sc = hbscal.data() + 11 * c;
+            for (int q : {0, 1, 4, 9, 10}) sc[q] = sums[si++];
+            for (int q : {2, 3, 5, 6, 7, 8}) sc[q] = maxs[mi++];
+        }
+        hbscal[NC * 11] = maxs[mi++]; hbscal[NC * 11 + 1] = maxs[mi++];
+        g_not_converged_rank = maxs[mi++] > 0.5;
+        g_any_below_full = maxs[mi++] > 0.5;
+        g_elapsed = maxs[mi++];
+    };
     while (!accepted && trials < opt.max_linsearch_steps) {
         dev::TrialBatch tb{};
         double tau_c = primal_step;
@@ -756,32 +788,7 @@ inline int Solver::linesearch_residual_support() {
                            (const double*)respart_d.p, rstride, n_res_wg, bscal.p + NC * 11);
         PX_HIP(hipMemcpyAsync(hbscal.data(), bscal.p, (NC * 11 + 2) * sizeof(double), hipMemcpyDeviceToHost, stream));
         PX_HIP(hipStreamSynchronize(stream));
-        if (sharded()) {
-            // every shard evaluated the same candidates on its own blocks/rows: combine
-            std::vector<double> sums, maxs;
-            for (int c = 0; c < NC; ++c) {
-                const double* sc = hbscal.data() + 11 * c;
-                for (int q : {0, 1, 4, 9, 10}) sums.push_back(c < nc ? sc[q] : 0.0);
-                for (int q : {2, 3, 5, 6, 7, 8}) maxs.push_back(c < nc ? sc[q] : 0.0);
-            }
-            maxs.push_back(hbscal[NC * 11]); maxs.push_back(hbscal[NC * 11 + 1]);
-            maxs.push_back(convergedrank() ? 0.0 : 1.0);          // any shard not rank-converged
-            bool below = false;
-            for (size_t idx = 0; idx < P.blocks.size(); ++idx) below = below || target_rank[idx] < P.blocks[idx].n;
-            maxs.push_back(below ? 1.0 : 0.0);                    // any block with target_rank < side
-            maxs.push_back(now_s() - time0);                      // one clock for the limits
-            reduce(sums, maxs);
-            size_t si = 0, mi = 0;
-            for (int c = 0; c < NC; ++c) {
-                double* sc = hbscal.data() + 11 * c;
-                for (int q : {0, 1, 4, 9, 10}) sc[q] = sums[si++];
-                for (int q : {2, 3, 5, 6, 7, 8}) sc[q] = maxs[mi++];
-            }
-            hbscal[NC * 11] = maxs[mi++]; hbscal[NC * 11 + 1] = maxs[mi++];
-            g_not_converged_rank = maxs[mi++] > 0.5;
-            g_any_below_full = maxs[mi++] > 0.5;
-            g_elapsed = maxs[mi++];
-        }
+        reduce_candidates(nc);
         for (int c = 0; c < nc; ++c) {
             ++trials;
             const double* sc = hbscal.data() + 11 * c;
@@ -791,9 +798,30 @@ inline int Solver::linesearch_residual_support() {
             const bool ok = std::sqrt(beta) * primal_step * Mty_norm <= opt.delta * y_norm;
             const bool last = trials >= opt.max_linsearch_steps;
             if (ok || last) {
-                if (!ok) primal_step *= opt.linsearch_decay;     // reference quirk: decayed once more, trial kept
                 accepted = true;
                 s_acc = sc;
+                if (!ok) {
+                    // reference quirk (pdhg.jl:545-569): max_linsearch_steps exhausted -> the step is
+                    // decayed once more while the last trial's y / Mty are kept, and compute_residual!
+                    // / compute_gap! then run with THAT primal_step and dual_step.  Re-evaluate the
+                    // residual scalars of candidate c with the final steps (rare path: one more batch).
+                    primal_step *= opt.linsearch_decay;
+                    dev::TrialBatch t1{};
+                    t1.nc = 1; t1.tau[0] = primal_step; t1.theta[0] = theta; t1.bt[0] = beta * primal_step;
+                    t1.sigma[0] = beta * primal_step;
+                    hipLaunchKernelGGL(dev::k_residual_xy_batch, dim3(std::max(gs, gq), 1, 2), dim3(dev::TPB), 0, stream,
+                                       xbuf[1 - xc].p, supp_d.p, ns, xsave_d.p, xold_coef,
+                                       MtyS_cand.p + (size_t)c * mstride, mstride, MtyS_cur.p, cS_d.p, gs,
+                                       ycand_d.p + (size_t)c * ystride, ystride, ybuf[yc].p, Mxbuf[1 - mxc].p, Mxbuf[mxc].p,
+                                       bh_d.p, (int)P.p, (int)P.Q, gq, t1, bpart.p, PSTRIDE, cstride);
+                    hipLaunchKernelGGL(dev::k_combine_multi, dim3(11 + 2), dim3(dev::TPB), 0, stream,
+                                       (const double*)bpart.p, PSTRIDE, std::max(gq, gs), 0x1ECull, bscal.p, 11,
+                                       (const double*)respart_d.p, rstride, n_res_wg, bscal.p + NC * 11);
+                    PX_HIP(hipMemcpyAsync(hbscal.data(), bscal.p, (NC * 11 + 2) * sizeof(double), hipMemcpyDeviceToHost, stream));
+                    PX_HIP(hipStreamSynchronize(stream));
+                    reduce_candidates(1);
+                    s_acc = hbscal.data();
+                }
                 // y <- y_c, Mty <- Mty_c
                 PX_HIP(hipMemcpyAsync(ybuf[1 - yc].p, ycand_d.p + (size_t)c * ystride, (size_t)P.Q * 8,
                                       hipMemcpyDeviceToDevice, stream));
@@ -921,6 +949,7 @@ inline void Solver::run() {
     hscal.assign(NQ, 0.0);
     {   // sparse operator, both orientations, int32 indices
         std::vector<int> rp(P.Q + 1), cp(P.n + 1);
+        // (prepare() guarantees n, Q, nnz < 2^31: the casts below cannot truncate)
         for (int64_t i = 0; i <= P.Q; ++i) rp[i] = (int)P.rowptr[i];
         for (int64_t i = 0; i <= P.n; ++i) cp[i] = (int)P.colptr[i];
         csr_ptr.alloc(P.Q + 1); csr_col.alloc(std::max<int64_t>(P.nnz, 1)); csr_val.alloc(std::max<int64_t>(P.nnz, 1));

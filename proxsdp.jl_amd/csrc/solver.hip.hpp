@@ -180,9 +180,10 @@ struct EigWork {
 
 class Solver {
 public:
+    // time0 is stamped BEFORE prepare(): the reference's clock starts at the top of chambolle_pock
+    // (pdhg.jl:13), so preprocessing and equilibration count towards Result.time and time_limit
     Solver(const proxsdp_problem& prob, const proxsdp_options& opt_in, proxsdp_result& res_out)
-        : opt(opt_in), res(res_out), P(prepare(prob, &opt_in)) {
-        time0 = now_s();
+        : opt(opt_in), res(res_out), time0(now_s()), P(prepare(prob, &opt_in)) {
         user_resid = prob.eig_resid;
         reduce_fn = prob.reduce_fn;
         reduce_ctx = prob.reduce_ctx;
@@ -227,13 +228,13 @@ public:
 
     proxsdp_options opt;
     proxsdp_result& res;
+    double time0 = 0;               // (declared before P: initialised first)
     Prep P;
     StreamRef stream;
     rocblas_handle blas = nullptr;
     std::vector<EigWork> eig;
     EigEvents ev;
     proxsdp_stats st{};
-    double time0 = 0;
     const double* user_resid = nullptr;
     // block-sharded solve: scalar all-reduce across shards (include/proxsdp_hip.h)
     int (*reduce_fn)(void*, double*, int32_t, double*, int32_t) = nullptr;
@@ -707,7 +708,7 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev) {
                 symeig_tridiag_from(K, m_arrow, Qa.data(), da.data(), ea.data(), al.data(), be.data(), Tw.data(), Dasc.data());
             else
             symeig_dense(K, Tw.data(), Dasc.data(), kfirst == 0);
-            W.lst.t_primal += now_s() - te0;            // (field reused: host K x K eigensolves)
+            W.lst.host_eig_time += now_s() - te0; W.lst.host_eigs++;
             U.assign((size_t)K * K, 0.0);
             for (int c = 0; c < K; ++c) {                // :LR -> descending
                 D[c] = Dasc[K - 1 - c];
@@ -881,7 +882,8 @@ inline void Solver::merge_block_stats() {
         st.lanczos_calls += a.lanczos_calls; st.full_eigs += a.full_eigs;
         st.krylov_fallbacks += a.krylov_fallbacks; st.symv_launches += a.symv_launches;
         st.symv_profiled += a.symv_profiled; st.symv_profiled_ms += a.symv_profiled_ms;
-        st.symv_bytes += a.symv_bytes; st.t_primal += a.t_primal; st.fop_projections += a.fop_projections;
+        st.symv_bytes += a.symv_bytes; st.host_eig_time += a.host_eig_time; st.host_eigs += a.host_eigs;
+        st.fop_projections += a.fop_projections;
         a = proxsdp_stats{};
         lz_matvec_iter += W.mv_iter; recon_r_iter += W.recon_r;
         W.mv_iter = 0; W.recon_r = 0;

@@ -29,7 +29,7 @@ from kat_problems import KATS  # noqa: E402
 OUT = pathlib.Path(__file__).resolve().parent
 
 
-from helpers import planted_packed, oracle_project, PROJ_CASES  # noqa: E402
+from helpers import planted_packed, oracle_project, PROJ_CASES, smat  # noqa: E402
 
 
 def main():
@@ -49,8 +49,29 @@ def main():
     for name, pr, iters in cases:
         o = Options()
         o.max_iter = iters
-        r = oracle.solve(pr, o, trace=True)
-        traces[name] = dict(status=r.status, iter=r.iter, objval=r.objval, rows=[
+        # iterations whose projection input has lambda_r == lambda_{r+1} (to 1e-8 |X|): there the
+        # reference's rank-r truncation (prox_operators.jl:99-106) is defined only up to a rotation
+        # inside the eigenspace, so two correct eigensolvers may continue on different trajectories
+        n_side = pr.psd_sides()[0]
+        degenerate, restarts, prev = [], [], [0]
+
+        def cb(it, xin, xout, p, arc_list, n_side=n_side, degenerate=degenerate, restarts=restarts, prev=prev):
+            if n_side < 2:
+                return
+            rs = arc_list[0].restarts - prev[0]
+            prev[0] = arc_list[0].restarts
+            if rs > 0:
+                restarts.append(it)
+            tr = int(p.target_rank[0])
+            if tr < n_side:
+                X = smat(xin[:n_side * (n_side + 1) // 2], n_side)
+                w = np.linalg.eigvalsh(X)[::-1]
+                if w[tr - 1] > 0.0 and abs(w[tr - 1] - w[tr]) <= 1e-8 * np.linalg.norm(X):
+                    degenerate.append(it)
+        r = oracle.solve(pr, o, trace=True, proj_callback=cb)
+        print(name, "restart iterations", restarts[:10], "degenerate iterations", degenerate[:10])
+        traces[name] = dict(status=r.status, iter=r.iter, objval=r.objval, restart_iters=restarts,
+                            degenerate_iters=degenerate, rows=[
             [t["iter"], t["prim_obj"], t["dual_obj"], t["gap"], t["feas"], t["prim_res"], t["dual_res"],
              t["primal_step"], t["beta"], t["theta"], t["target_rank"][0], t["trials"]] for t in r.trace])
         print(name, r.status, r.iter, r.objval)

@@ -1,0 +1,73 @@
+"""Generates the two LARGE-instance fixtures from the CPU oracle (minutes of CPU each; run once
+in the build container, results committed as numbers only):
+
+  trace_maxcut_n4000.json   first 30 PDHG iterations of the metric's instance (Max-Cut ER n=4000,
+                            seed 0, reference default options): the per-iteration trace columns
+  solve_maxcut_n1000.json   BASELINE config 2 (Max-Cut ER n=1000, seed 0) solved to
+                            tol_gap = tol_feasibility = 1e-4 with reference default options:
+                            status, iterations, objective, dual objective, gap, rank schedule
+
+Run from the repo root:  python tests/golden/make_golden_large.py [trace4000] [solve1000]
+The inputs are regenerated from the seed by the tests through the same generator
+(proxsdp_jl_amd.problems.maxcut)."""
+import json
+import pathlib
+import sys
+import time
+
+ROOT = pathlib.Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+import oracle  # noqa: E402
+from oracle import Options  # noqa: E402
+from proxsdp_jl_amd import problems as P  # noqa: E402
+
+OUT = pathlib.Path(__file__).resolve().parent
+
+
+def rows_of(r):
+    return [[t["iter"], t["prim_obj"], t["dual_obj"], t["gap"], t["feas"], t["prim_res"], t["dual_res"],
+             t["primal_step"], t["beta"], t["theta"], t["target_rank"][0], t["trials"]] for t in r.trace]
+
+
+def trace4000():
+    pr = P.maxcut(4000, seed=0)
+    o = Options()
+    o.max_iter = 30
+    mv = []
+
+    def cb(it, xin, xout, p, arc):
+        mv.append(int(arc[0].matvecs))
+    t0 = time.time()
+    r = oracle.solve(pr, o, trace=True, proj_callback=cb)
+    per_iter = [mv[0]] + [mv[i] - mv[i - 1] for i in range(1, len(mv))]
+    (OUT / "trace_maxcut_n4000.json").write_text(json.dumps(dict(
+        n=4000, seed=0, status=r.status, iter=r.iter, objval=r.objval, rows=rows_of(r), matvecs=per_iter,
+        wall_s=time.time() - t0)))
+    print("trace4000", r.status, r.iter, r.objval, per_iter, time.time() - t0)
+
+
+def solve1000():
+    pr = P.maxcut(1000, seed=0)
+    o = Options()
+    o.time_limit = 36000.0
+    t0 = time.time()
+    r = oracle.solve(pr, o, trace=True)
+    sched = []
+    for t in r.trace:                       # (iteration, target_rank) at every change
+        if not sched or sched[-1][1] != t["target_rank"][0]:
+            sched.append([t["iter"], t["target_rank"][0]])
+    (OUT / "solve_maxcut_n1000.json").write_text(json.dumps(dict(
+        n=1000, seed=0, tol=1e-4, status=r.status, iter=r.iter, objval=r.objval, dual_objval=r.dual_objval,
+        gap=r.gap, final_rank=int(r.final_rank), full_eigs=int(r.stats["full_eigs"]),
+        rank_schedule=sched, wall_s=time.time() - t0)))
+    print("solve1000", r.status, r.iter, r.objval, r.dual_objval, r.gap, time.time() - t0)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["trace4000", "solve1000"]
+    if "trace4000" in which:
+        trace4000()
+    if "solve1000" in which:
+        solve1000()

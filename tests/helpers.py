@@ -82,3 +82,70 @@ PROJ_CASES = [  # name, n, seed, top eigenvalues, target_rank, full
 ]
 
 
+
+
+def capture_restart_projections(pr, iters, count, all_after_first=False, any_iter=False, **optkw):
+    """Run the oracle for `iters` PDHG iterations on a single-PSD-block problem and capture the
+    projection input / output of the first `count` iterations whose Lanczos needed a thick restart
+    (through the oracle's proj_callback test hook).  all_after_first: capture every iteration from
+    the first restart on, restart or not."""
+    import oracle
+    n = pr.psd_sides()[0]
+    N = n * (n + 1) // 2
+    caps = []
+    prev = [0, 0]
+
+    def cb(it, xin, xout, p, arc_list):
+        arc = arc_list[0]
+        mv, rs = arc.matvecs - prev[0], arc.restarts - prev[1]
+        prev[0], prev[1] = arc.matvecs, arc.restarts
+        if (rs > 0 or any_iter or (all_after_first and caps)) and len(caps) < count and arc.converged:
+            tr = int(p.target_rank[0])
+            k = min(tr, arc.converged_eigs)
+            vals = np.array(arc.vals[:k])                     # (ARPACK path: ascending, all nev used)
+            pos = vals > 0.0
+            w = np.linalg.eigvalsh(smat(xin[:N], n))[::-1]
+            caps.append(dict(n=n, iter=it, target_rank=tr, rank=int(p.current_rank[0]), min_eig=float(p.min_eig[0]),
+                             matvecs=int(mv), restarts=int(rs), converged_eigs=int(arc.converged_eigs),
+                             x_in=xin[:N].copy(), x_out=xout[:N].copy(), vals=vals[pos].copy(),
+                             vecs=np.array(arc.vecs[:, :k][:, pos]), top=w[:tr + 3].copy()))
+
+    o = Options()
+    o.max_iter = iters
+    for k_, v_ in optkw.items():
+        setattr(o, k_, v_)
+    oracle.solve(pr, o, proj_callback=cb)
+    return caps
+
+
+def check_truncated_projection(x_in, n, target_rank, out, ref_out, tol_rel=1e-9, gap_rel=1e-8):
+    """The reference's Lanczos projection keeps the top `target_rank` eigenpairs (positive part,
+    prox_operators.jl:99-106).  Two correct eigensolvers agree on it to ~tol/gap; when the input has
+    lambda_r == lambda_{r+1} (to gap_rel*|X|) the truncation is only defined up to a rotation inside
+    that eigenspace.  Returns "tight" when `out` matches `ref_out` to tol_rel*|X|; otherwise asserts,
+    with LAPACK on the input, that (i) the cluster really is degenerate and (ii) `out` equals the
+    well-separated part exactly plus lambda_cluster times an orthogonal projector of the right rank
+    INSIDE the degenerate eigenspace -- and returns "degenerate"."""
+    X = smat(x_in, n)
+    nx = np.linalg.norm(X)
+    if np.linalg.norm(out - ref_out) <= tol_rel * nx:
+        return "tight"
+    w, Q = np.linalg.eigh(X)
+    w, Q = w[::-1], Q[:, ::-1]
+    r = target_rank
+    lam = w[r - 1]
+    assert abs(w[r - 1] - w[r]) <= gap_rel * nx, ("projections differ on a non-degenerate input",
+                                                 np.linalg.norm(out - ref_out) / nx, w[:r + 3])
+    cl = np.where(np.abs(w - lam) <= 10 * gap_rel * nx)[0]          # the degenerate cluster
+    lo = cl.min()                                                  # eigenpairs above it are well separated
+    take = r - lo                                                  # how many vectors of the cluster survive
+    sep = (Q[:, :lo] * np.maximum(w[:lo], 0.0)) @ Q[:, :lo].T
+    R = smat(out, n) - sep
+    if lam <= 0.0:
+        assert np.linalg.norm(R) <= 1e-7 * nx
+        return "degenerate"
+    Pc = Q[:, cl] @ Q[:, cl].T
+    assert np.linalg.norm(R - Pc @ R @ Pc) <= 1e-7 * nx, "remainder leaves the degenerate eigenspace"
+    ev = np.linalg.eigvalsh(R)[::-1] / lam
+    assert np.allclose(ev[:take], 1.0, atol=1e-6) and np.abs(ev[take:]).max() <= 1e-6, ev[:take + 2]
+    return "degenerate"

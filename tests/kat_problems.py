@@ -170,3 +170,35 @@ def mixed_cones(seed=0, sides=(1, 3, 104, 1, 5), soc_len=4, nfree=3, p=30, m=12)
     Gm = sp.random(m, n, density=0.1, random_state=rng, format="csc")
     h = Gm @ x0 + rng.uniform(0.1, 1.0, m)
     return Problem(n=n, A=A, b=b, G=Gm, h=h, c=c, psd=psd, soc=soc, name=f"mixed-cones-s{seed}")
+
+
+def _tri(i, j):
+    """0-based index of entry (i <= j) in MOI triangle order (column-major upper triangle)."""
+    return j * (j + 1) // 2 + i
+
+
+def infeasible_sdp(n=110):
+    """Max-Cut-shaped model on a ring graph with one contradictory row: diag(X) = 1 AND X_00 = -1
+    (a PSD matrix has X_00 >= 0): primal infeasible, PSD side > 100 so the block takes the Lanczos
+    path (and the operator-form mat-vec on the support path)."""
+    N = n * (n + 1) // 2
+    rows = [{_tri(i, i): 1.0} for i in range(n)] + [{_tri(0, 0): 1.0}]
+    b = np.concatenate([np.ones(n), [-1.0]])
+    c = {}
+    for i in range(n):
+        j = (i + 1) % n
+        c[_tri(min(i, j), max(i, j))] = 0.5          # -1/4 L on the ring's edges (off-diagonals doubled)
+        c[_tri(i, i)] = -0.5
+    return Problem(n=N, A=_mat(rows, N), b=b, G=_mat([], N), h=np.zeros(0), c=_cvec(N, c),
+                   psd=[np.arange(N)], name=f"infeasible_sdp_n{n}")
+
+
+def unbounded_sdp(n=110):
+    """min -tr(X) + ring terms with only X_00 = 1 fixed: the other diagonal entries can grow without
+    bound inside the PSD cone: dual infeasible (unbounded), PSD side > 100 (Lanczos path)."""
+    N = n * (n + 1) // 2
+    c = {_tri(i, i): -1.0 for i in range(n)}
+    for i in range(n - 1):
+        c[_tri(i, i + 1)] = 0.2
+    return Problem(n=N, A=_mat([{_tri(0, 0): 1.0}], N), b=np.array([1.0]), G=_mat([], N), h=np.zeros(0),
+                   c=_cvec(N, c), psd=[np.arange(N)], name=f"unbounded_sdp_n{n}")
