@@ -208,8 +208,13 @@ typedef struct proxsdp_stats {
     int64_t device_eigs;         /* K x K eigensolves done by the device eigensolver            */
     int64_t batched_small_eigs;  /* small-block (n <= 32) projections done by the batched Jacobi kernel */
     int64_t mfma_reconstructions;/* reconstructions that took the MFMA (v_mfma_f64_16x16x4) SYRK */
-    int64_t reserved_i[3];
-    double  reserved_d[4];
+    int64_t orth_profiled;       /* k_lz_orth launches bracketed by events (profile_symv_every)  */
+    double  orth_profiled_ms;    /* sum of their durations                                       */
+    double  full_eig_solver_ms;  /* full_eig!: dense eigensolver time (events; profile_symv_every > 0) */
+    double  full_eig_recon_ms;   /* full_eig!: reconstruction kernel time (events)               */
+    int64_t cycle_launches;      /* Lanczos cycles run by the persistent LDS-resident kernel     */
+    int64_t reserved_i[2];
+    double  reserved_d[2];
 } proxsdp_stats;
 
 /* Result (structs.jl:60-81).  Arrays are caller-allocated with the stated

@@ -81,8 +81,13 @@ struct Stats                     # proxsdp_stats
     device_eigs::Int64
     batched_small_eigs::Int64
     mfma_reconstructions::Int64
-    reserved_i::NTuple{3,Int64}
-    reserved_d::NTuple{4,Float64}
+    orth_profiled::Int64
+    orth_profiled_ms::Float64
+    full_eig_solver_ms::Float64
+    full_eig_recon_ms::Float64
+    cycle_launches::Int64
+    reserved_i::NTuple{2,Int64}
+    reserved_d::NTuple{2,Float64}
 end
 
 mutable struct CResult           # proxsdp_result

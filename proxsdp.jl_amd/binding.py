@@ -116,7 +116,9 @@ class Stats(C.Structure):
                 ("loop_time", f64), ("exit_time", f64), ("t_primal", f64), ("t_psd", f64),
                 ("t_linesearch", f64), ("t_residual", f64), ("dense_passes", i64), ("dense_ms", f64), ("fop_projections", i64), ("exit_matvecs", i64),
                 ("host_eig_time", f64), ("host_eigs", i64), ("device_eigs", i64), ("batched_small_eigs", i64),
-                ("mfma_reconstructions", i64), ("reserved_i", i64 * 3), ("reserved_d", f64 * 4)]
+                ("mfma_reconstructions", i64), ("orth_profiled", i64), ("orth_profiled_ms", f64),
+                ("full_eig_solver_ms", f64), ("full_eig_recon_ms", f64), ("cycle_launches", i64),
+                ("reserved_i", i64 * 2), ("reserved_d", f64 * 2)]
 
 
 class Result(C.Structure):

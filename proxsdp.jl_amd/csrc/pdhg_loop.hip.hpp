@@ -1259,6 +1259,8 @@ inline void Solver::run() {
         }
     }
     PX_HIP(hipStreamSynchronize(stream));
+    for (EigWork& W : eig) harvest_full_eig_events(W);
+    merge_block_stats();
     st.loop_time = now_s() - t_loop0;
     if (warm.joinable()) warm.join();
 

@@ -174,7 +174,9 @@ struct EigWork {
     hipEvent_t done = nullptr;
     proxsdp_stats lst{};
     long long mv_iter = 0, recon_r = 0;
-    EigEvents ev;
+    EigEvents ev, evo;                             // profiled mat-vec / orthogonalisation launches
+    hipEvent_t fe[3] = {nullptr, nullptr, nullptr};   // full_eig!: before solver | after solver | after reconstruction
+    bool fe_pending = false;
 };
 
 
@@ -198,6 +200,9 @@ public:
         for (EigWork& W : eig) {
             for (auto e : W.ev.e0) (void)hipEventDestroy(e);
             for (auto e : W.ev.e1) (void)hipEventDestroy(e);
+            for (auto e : W.evo.e0) (void)hipEventDestroy(e);
+            for (auto e : W.evo.e1) (void)hipEventDestroy(e);
+            for (auto e : W.fe) if (e) (void)hipEventDestroy(e);
             if (W.done) (void)hipEventDestroy(W.done);
             if (W.stream) (void)hipStreamDestroy(W.stream);
         }
@@ -213,6 +218,7 @@ public:
     void alloc_eigwork(EigWork& W, int n, int max_nev);
     void lanczos(EigWork& W, const double* xp, int nev);
     void full_eig_values(EigWork& W, const double* xp, double offscale, bool vectors, std::vector<double>& Dhost);
+    void harvest_full_eig_events(EigWork& W);
     void launch_symv(EigWork& W, const double* xp, const double* v, bool use_ctl);
     void launch_symv_finish(EigWork& W, const double* xp, int kclose, double tol, bool use_carry);
     void launch_reconstruct(EigWork& W, const double* Z, int ldz, const double* lam, int r, double* xp_out,
@@ -616,8 +622,19 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev) {
             }
             const int nch = (k + 1 <= 64) ? 1 : (k + 1 <= 128) ? 2 : 3;
             const int nchp = !W.use_fop ? 0 : (W.F_r <= 64 ? 1 : 2);
+            const bool prof_o = opt.profile_symv_every > 0 && (W.lst.symv_launches % opt.profile_symv_every) == 1;
+            size_t oslot = 0;
+            if (prof_o) {
+                if (W.evo.used == W.evo.e0.size()) {
+                    hipEvent_t a, b;
+                    PX_HIP(hipEventCreate(&a)); PX_HIP(hipEventCreate(&b));
+                    W.evo.e0.push_back(a); W.evo.e1.push_back(b);
+                }
+                oslot = W.evo.used++;
+            }
             auto launch_orth = [&](auto kern) {
-                hipLaunchKernelGGL(kern, dim3(W.nt), dim3(dev::TPB), 0, stream,
+                launch_prof(prof_o, prof_o ? W.evo.e0[oslot] : nullptr, prof_o ? W.evo.e1[oslot] : nullptr, kern,
+                                   dim3(W.nt), stream,
                                    (const double*)W.Ppart.p, W.nt, W.npad, (const double*)W.V.p, W.npad, k, W.w.p,
                                    (const double*)W.hred.p, hp[k & 1], W.pld, W.hsum1.p,
                                    (const dev::LanczosCtl*)W.ctl_p, (const double*)W.alphas_p, (const double*)W.betas_p,
@@ -677,6 +694,13 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev) {
             }
             W.ev.used = 0;
         }
+        for (size_t s = 0; s < W.evo.used; ++s) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, W.evo.e0[s], W.evo.e1[s]) == hipSuccess) {
+                W.lst.orth_profiled_ms += ms; W.lst.orth_profiled++;
+            }
+        }
+        W.evo.used = 0;
         const int Kend = hctl.stop ? hctl.kstop : krylovdim;
         // launches after the stop flag are no-ops; count the mat-vecs that did work
         {
@@ -795,7 +819,14 @@ inline void Solver::full_eig_values(EigWork& W, const double* xp, double offscal
 inline void Solver::full_eig_project(int idx, const double* xp_in, double* xp_out, bool fuse) {
     EigWork& W = eig[idx];
     std::vector<double> D;
+    const bool prof = opt.profile_symv_every > 0;
+    if (prof) {
+        if (W.fe[0] == nullptr) for (auto& e : W.fe) PX_HIP(hipEventCreate(&e));
+        harvest_full_eig_events(W);                       // previous call's events (completed: see the sync below)
+        PX_HIP(hipEventRecord(W.fe[0], stream));
+    }
     full_eig_values(W, xp_in, dev::INV_SQRT2, true, D);
+    if (prof) PX_HIP(hipEventRecord(W.fe[1], stream));
     W.lst.full_eigs++;
     const int n = W.n;
     int npos = 0, rank = 0;
@@ -805,7 +836,16 @@ inline void Solver::full_eig_project(int idx, const double* xp_in, double* xp_ou
     // ascending order: the positive eigenpairs are the trailing npos columns
     launch_reconstruct(W, W.A.p + (size_t)(n - npos) * n, n, W.D.p + (n - npos), npos, xp_out,
                        fuse ? xp_in : nullptr, fuse ? idx : -1);
+    if (prof) { PX_HIP(hipEventRecord(W.fe[2], stream)); W.fe_pending = true; }
     W.recon_r += npos;
+}
+inline void Solver::harvest_full_eig_events(EigWork& W) {
+    if (!W.fe_pending) return;
+    W.fe_pending = false;
+    if (hipEventSynchronize(W.fe[2]) != hipSuccess) return;
+    float a = 0.f, b = 0.f;
+    if (hipEventElapsedTime(&a, W.fe[0], W.fe[1]) == hipSuccess) W.lst.full_eig_solver_ms += a;
+    if (hipEventElapsedTime(&b, W.fe[1], W.fe[2]) == hipSuccess) W.lst.full_eig_recon_ms += b;
 }
 
 // ---- worker pool for concurrent block projections
@@ -882,6 +922,9 @@ inline void Solver::merge_block_stats() {
         st.lanczos_calls += a.lanczos_calls; st.full_eigs += a.full_eigs;
         st.krylov_fallbacks += a.krylov_fallbacks; st.symv_launches += a.symv_launches;
         st.symv_profiled += a.symv_profiled; st.symv_profiled_ms += a.symv_profiled_ms;
+        st.orth_profiled += a.orth_profiled; st.orth_profiled_ms += a.orth_profiled_ms;
+        st.full_eig_solver_ms += a.full_eig_solver_ms; st.full_eig_recon_ms += a.full_eig_recon_ms;
+        st.device_eigs += a.device_eigs; st.mfma_reconstructions += a.mfma_reconstructions; st.cycle_launches += a.cycle_launches;
         st.symv_bytes += a.symv_bytes; st.host_eig_time += a.host_eig_time; st.host_eigs += a.host_eigs;
         st.fop_projections += a.fop_projections;
         a = proxsdp_stats{};
