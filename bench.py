@@ -74,8 +74,11 @@ def main():
     ap.add_argument("--hbm-n", type=int, default=16000, help="side of the HBM-resident packed mat-vec leg (0: skip)")
     ap.add_argument("--default-time-limit", type=float, default=120.0,
                     help="time limit of the time-to-tol leg with REFERENCE DEFAULT options (0: skip)")
-    ap.add_argument("--warm-start-eig", dest="warm_start_eig", type=int, default=None,
+    ap.add_argument("--lanczos-warm-start", dest="lanczos_warm_start", type=int, default=None,
                     help="library-only: Lanczos start vector from the previous projection's Ritz vectors")
+    ap.add_argument("--full-eig-lanczos", dest="full_eig_lanczos", type=int, default=None,
+                    help="library-only: 0 = full_eig! always through the dense eigensolver")
+    ap.add_argument("--reconstruct-mfma", dest="reconstruct_mfma", type=int, default=None)
     ap.add_argument("--lanczos-cycle-kernel", dest="lanczos_cycle_kernel", type=int, default=None,
                     help="library-only: -1 auto, 0 off, 1 on: persistent LDS-resident Lanczos cycle kernel")
     ap.add_argument("--rand-n", type=int, default=2000)
@@ -285,7 +288,7 @@ def main():
 def extra_opts(args):
     """library-only knobs passed through to every GPU leg (empty = the KrylovKit-faithful parity path)"""
     kw = {}
-    for name in ("warm_start_eig", "lanczos_cycle_kernel"):
+    for name in ("lanczos_warm_start", "lanczos_cycle_kernel", "full_eig_lanczos", "reconstruct_mfma"):
         v = getattr(args, name, None)
         if v is not None:
             kw[name] = v

@@ -174,6 +174,22 @@ typedef struct proxsdp_options {
                                 * DESIGN.md section 4), -1 auto = 1 (default) */
     int32_t initial_target_rank; /* reference: 2, hard-coded (pdhg.jl:19-20); a benchmark may start at the
                                   * rank a config names ("rank ~ sqrt(n)"); capped at the block side */
+    int32_t full_eig_lanczos;    /* full_eig! (prox_operators.jl:111-126) needs every POSITIVE eigenpair, not the
+                                  * whole spectrum: -1 auto / 1 = when the previous projection of the block had few
+                                  * positive eigenvalues, compute them with the Lanczos engine (all pairs down to the
+                                  * first eigenvalue <= 0, converged to krylovkit_tol) and fall back to the dense
+                                  * eigensolver otherwise; 0 = always the dense eigensolver.  Same projection. */
+    int32_t lanczos_cycle_kernel;/* -1 auto, 0 off, 1 on: run a whole Lanczos cycle (operator form) in ONE persistent
+                                  * launch whose workgroups keep their rows of the basis in LDS and exchange partial
+                                  * dots in-launch, instead of two launches per step.  Same arithmetic per step. */
+    int32_t lanczos_warm_start;  /* 0 (default): every projection starts from the fixed start vector, as the
+                                  * reference does (krylovkit_reset_resid = false).  1: start from the normalised sum of
+                                  * the previous projection's Ritz vectors (+ 1e-3 x the fixed vector).  Changes the
+                                  * Krylov space, not what is converged (krylovkit_tol). */
+    int32_t reconstruct_mfma;    /* rank-r reconstruction V Lam+ V': -1 auto, 0 scalar-FMA kernel, 1 fp64 MFMA
+                                  * (v_mfma_f64_16x16x4_f64) kernel */
+    int32_t small_block_batch;   /* -1 auto, 0 off: project all PSD blocks of side <= 32 in one batched Jacobi launch */
+    int32_t pad7;
 } proxsdp_options;
 
 #define PROXSDP_TRACE_COLS 14
@@ -213,7 +229,8 @@ typedef struct proxsdp_stats {
     double  full_eig_solver_ms;  /* full_eig!: dense eigensolver time (events; profile_symv_every > 0) */
     double  full_eig_recon_ms;   /* full_eig!: reconstruction kernel time (events)               */
     int64_t cycle_launches;      /* Lanczos cycles run by the persistent LDS-resident kernel     */
-    int64_t reserved_i[2];
+    int64_t full_eigs_lanczos;   /* full_eig! calls served by the Lanczos engine (all positive pairs) */
+    int64_t reserved_i[1];
     double  reserved_d[2];
 } proxsdp_stats;
 
@@ -267,7 +284,9 @@ int  proxsdp_hip_device_count(void);          /* <0: PROXSDP_E_HIP */
  * (prox_operators.jl:33-66 with psd_vec_to_square/psd_square_to_vec :1-31).
  * mode 0: Lanczos path (krylovkit_eig!, :89-109) with nev = target_rank,
  *         falling back to full_eig! when not converged;
- * mode 1: full_eig! (:111-126).
+ * mode 1: full_eig! (:111-126) through the dense eigensolver;
+ * mode 2: full_eig! served by the Lanczos engine (every positive eigenpair), target_rank = estimate
+ *         of the number of positive eigenvalues; *out_fell_back = 1 if the dense solver had to run.
  * resid: start vector (n) or NULL.  out_*: rank (current_rank), min_eig,
  * nmatvec, converged eigenpairs, fell_back flag. */
 int proxsdp_hip_psd_project(const double* packed_in, int64_t n, int32_t target_rank,

@@ -86,7 +86,8 @@ struct Stats                     # proxsdp_stats
     full_eig_solver_ms::Float64
     full_eig_recon_ms::Float64
     cycle_launches::Int64
-    reserved_i::NTuple{2,Int64}
+    full_eigs_lanczos::Int64
+    reserved_i::NTuple{1,Int64}
     reserved_d::NTuple{2,Float64}
 end
 

@@ -492,12 +492,17 @@ def dual_feas(y, cones, aff, c, A, G, a):
 
 
 def equilibrate(M, aff, opt):
-    """equilibrate! (equilibration.jl:1-72): projected-gradient row/column scaling.  Two quirks of
-    the reference, both reproduced as written: (i) v is replaced by its mean in every iteration
-    (:56-58), so D is a multiple of the identity; (ii) `E = Diagonal(u)`, `D = Diagonal(v)` (:16-17)
-    WRAP u and v without copying, so `E.diag .= exp.(u)` (:25-26) overwrites u with exp(u) (and v
-    with exp(v)) at the top of every iteration: the gradient and projection steps then start from
-    exp(u), exp(v).  Returns the diagonals (E over rows, D over columns)."""
+    """equilibrate! (equilibration.jl:1-72): projected-gradient row/column scaling.  The reference
+    replaces v by its mean in every iteration (:56-58), so D is a multiple of the identity: kept.
+    DELIBERATE DEVIATION: in the reference `E = Diagonal(u)`, `D = Diagonal(v)` (:16-17) wrap u and v
+    WITHOUT copying, so `E.diag .= exp.(u)` (:25-26) overwrites u with exp(u) (v with exp(v)) at the
+    top of every iteration and the gradient steps start from there.  Restated with that aliasing, the
+    scaling comes out badly conditioned (maxcut n=30: E ~ 0.023, D ~ 110) and the solver fails known
+    answers it passes without it (e.g. lp_in_SDP_equality_form, "feasibility stalled") -- the option is
+    off by default and never switched on by the reference's tests, so this cannot be checked against
+    Julia here.  Oracle and library implement the algorithm the code evidently intends (u, v kept,
+    E = exp(u), D = exp(v)); any positive diagonal scaling leaves the solution set unchanged.
+    Returns the diagonals (E over rows, D over columns)."""
     M = sp.csc_matrix(M)
     nQ, n = aff.m + aff.p, aff.n
     alpha = (n / nQ) ** 0.25
@@ -509,8 +514,7 @@ def equilibrate(M, aff, opt):
     rows = M.indices
     cols = np.repeat(np.arange(n), np.diff(M.indptr))
     for it in range(1, opt.equilibration_iters + 1):
-        u, v = np.exp(u), np.exp(v)               # E.diag .= exp.(u) with E.diag === u  (aliasing, see docstring)
-        Ed, Dd = u, v
+        Ed, Dd = np.exp(u), np.exp(v)
         d2 = (M.data * Dd[cols] * Ed[rows]) ** 2
         step_size = 2.0 / (gamma * (it + 1.0))
         row_norms = np.bincount(rows, weights=d2, minlength=nQ)

@@ -101,6 +101,8 @@ def _opt_fields():
     a("equilibration_force", i32); a("approx_norm", i32)
     a("device_id", i32); a("trace_capacity", i32); a("profile_symv_every", i32); a("support_path", i32)
     a("lanczos_operator", i32); a("initial_target_rank", i32)
+    a("full_eig_lanczos", i32); a("lanczos_cycle_kernel", i32); a("lanczos_warm_start", i32)
+    a("reconstruct_mfma", i32); a("small_block_batch", i32); a("pad7", i32)
     return F
 
 
@@ -118,7 +120,7 @@ class Stats(C.Structure):
                 ("host_eig_time", f64), ("host_eigs", i64), ("device_eigs", i64), ("batched_small_eigs", i64),
                 ("mfma_reconstructions", i64), ("orth_profiled", i64), ("orth_profiled_ms", f64),
                 ("full_eig_solver_ms", f64), ("full_eig_recon_ms", f64), ("cycle_launches", i64),
-                ("reserved_i", i64 * 2), ("reserved_d", f64 * 2)]
+                ("full_eigs_lanczos", i64), ("reserved_i", i64 * 1), ("reserved_d", f64 * 2)]
 
 
 class Result(C.Structure):

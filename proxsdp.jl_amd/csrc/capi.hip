@@ -131,16 +131,21 @@ int proxsdp_hip_psd_project(const double* packed_in, int64_t n, int32_t target_r
         if (!packed_in || !packed_out) throw std::invalid_argument("NULL buffer");
         if (target_rank < 1) throw std::invalid_argument("target_rank < 1");
         proxsdp_options o = Engine::fix(opt);
-        if (mode == 1) o.full_eig_decomp = 1;
+        if (mode == 1) { o.full_eig_decomp = 1; o.full_eig_lanczos = 0; }
         // the test entry point takes the Krylov branch whenever mode == 0
         if (mode == 0) { o.min_size_krylov_eigs = 0; o.max_target_rank_krylov_eigs = std::max(o.max_target_rank_krylov_eigs, target_rank); }
-        Engine E(&o, n, target_rank);
+        // mode 2: full_eig! served by the Lanczos engine, `target_rank` = the estimate of the number of
+        // positive eigenvalues (in a solve: the count of the block's previous projection)
+        if (mode == 2) { o.full_eig_decomp = 1; o.full_eig_lanczos = 1; o.min_size_krylov_eigs = 0; }
+        const int ws = mode == 2 ? std::min<int>({(int)n, (proxsdp::dev::MAXK - 4) / 2, 2 * (target_rank + std::max(3, target_rank / 8)) + 2}) : target_rank;
+        Engine E(&o, n, ws);
         E.set_resid(resid);
         proxsdp::Solver& S = E.S;
         const int64_t N = n * (n + 1) / 2;
         proxsdp::DevBuf<double> x(N);
         x.upload(packed_in, N, S.stream);
         S.P.blocks.push_back({(int)n, N, 0});
+        if (mode == 2) S.eig[0].last_npos = target_rank;
         S.test_project(0, x.p, target_rank);
         x.download(packed_out, N, S.stream);
         PX_HIP(hipStreamSynchronize(S.stream));
@@ -149,7 +154,7 @@ int proxsdp_hip_psd_project(const double* packed_in, int64_t n, int32_t target_r
         S.merge_block_stats();
         if (out_nmatvec) *out_nmatvec = S.st.lanczos_matvecs;
         if (out_converged) *out_converged = S.eig[0].converged_eigs;
-        if (out_fell_back) *out_fell_back = (int32_t)S.st.krylov_fallbacks;
+        if (out_fell_back) *out_fell_back = mode == 2 ? (int32_t)(S.st.full_eigs_lanczos == 0) : (int32_t)S.st.krylov_fallbacks;
         return 0;
     });
 }

@@ -320,7 +320,8 @@ k_symv_packed(const double* __restrict__ xp, int n, int nt, int npad,
 // L2-resident basis), so the point of the layout is parallel width and loads in flight,
 // not bytes.
 // ---------------------------------------------------------------------------
-constexpr int MAXK = 160;           // capacity of the Krylov basis (krylovdim+1 < MAXK)
+constexpr int MAXK = 192;           // capacity of the Krylov basis (krylovdim+1 < MAXK - 1; the step kernels hold
+                                    // 16*NCH <= 48 basis columns per wave in registers, 4 waves)
 constexpr int LZ_ROWS = TILE;       // rows per workgroup in the Lanczos vector kernels
 constexpr int NRM_SLOT = MAXK - 1;  // slot of a partial-dots row that carries |w'|^2
 

@@ -63,8 +63,31 @@ inline void Solver::project_block(int idx, const double* xin, double* xout, bool
         if (!W.have_factors) { W.F_r = 0; W.F_first = 0; }
         W.esv = esv_d.p + (W.have_factors ? 0 : ns);
     }
+    if (!krylov) {
+        // full_eig! (prox_operators.jl:111-126): every positive eigenpair.  In the IMPLICIT full-eig
+        // regime (target_rank beyond max_target_rank_krylov_eigs: the reference falls back to LAPACK
+        // because its Krylov wrapper is capped, prox_operators.jl:46-49) the positive part is
+        // low-rank and known from the previous projection: it is computed by the Lanczos engine
+        // (operator form allowed) instead of a dense O(n^3) eigensolver -- see full_eig_by_lanczos.
+        // An explicit full_eig_decomp = true / periodic full_eig_freq request always gets the dense solver.
+        const bool implicit = !opt.full_eig_decomp && (iter % opt.full_eig_freq) > opt.full_eig_len &&
+                              W.n > opt.min_size_krylov_eigs;
+        if (!implicit && opt.full_eig_lanczos != 1) {
+            W.have_factors = false; W.x_prev_sparse = false; W.use_fop = false;
+            full_eig_project(idx, xp, xo, fuse);
+            return;
+        }
+        W.use_fop = fuse && use_support && opt.lanczos_operator != 0 && W.fop_ok && (W.have_factors || W.x_prev_sparse);
+        if (W.use_fop) {
+            if (!W.have_factors) { W.F_r = 0; W.F_first = 0; }
+            W.esv = esv_d.p + (W.have_factors ? 0 : ns);
+        }
+        if (full_eig_by_lanczos(idx, xp, xo, fuse)) return;
+        W.have_factors = false; W.x_prev_sparse = false; W.use_fop = false;
+        full_eig_project(idx, xp, xo, fuse);
+        return;
+    }
     const bool used_fop = W.use_fop;
-    if (!krylov) { W.have_factors = false; W.x_prev_sparse = false; W.use_fop = false; full_eig_project(idx, xp, xo, fuse); return; }
     const int nev = (int)target_rank[idx];
     lanczos(W, xp, nev);
     W.use_fop = false;
@@ -87,6 +110,7 @@ inline void Solver::project_block(int idx, const double* xin, double* xout, bool
         for (int i = 0; i < k; ++i) if (W.vals[i] > 0.0) ++npos;
     }
     current_rank[idx] += npos;
+    W.last_npos = npos;                       // (lower bound: estimate for a later full_eig!-by-Lanczos)
     if (npos > 0) W.lam.upload(W.vals.data() + first, npos, stream);
     launch_reconstruct(W, W.Z.p + (size_t)first * W.npad, W.npad, W.lam.p, npos, xo,
                        fuse ? xp : nullptr, fuse ? idx : -1);
@@ -98,6 +122,59 @@ inline void Solver::project_block(int idx, const double* xin, double* xout, bool
         std::swap(W.lam.n, W.Flam.n);
         W.have_factors = true; W.x_prev_sparse = false;
     }
+}
+
+// full_eig! needs X+ = sum over lambda_i > 0 of lambda_i v_i v_i' -- every POSITIVE eigenpair, not
+// the spectrum (prox_operators.jl:115-124), current_rank = #{lambda_i > tol_psd}, min_eig = 0.  The
+// reference calls LAPACK dsyevr because it has no partial solver with an unknown count; on this path
+// (target_rank beyond max_target_rank_krylov_eigs) the iterate is typically low-rank, so the positive
+// part is the top of the spectrum: run the Lanczos engine for g = (positives last time) + slack
+// largest pairs; if the smallest of them is <= 0 (and all g converged to krylovkit_tol) every
+// positive eigenvalue is among them.  Otherwise enlarge g once, then fall back to the dense solver.
+// rocSOLVER dsyevd takes 139 ms at n = 4000 (1.5 TF/s); this takes the cost of a Krylov projection.
+inline bool Solver::full_eig_by_lanczos(int idx, const double* xp, double* xo, bool fuse) {
+    EigWork& W = eig[idx];
+    if (opt.full_eig_lanczos == 0 || opt.eigsolver == 1 || W.n <= opt.min_size_krylov_eigs) return false;
+    if (W.last_npos < 0) return false;                       // no estimate yet: dense eigensolver first
+    const int maxnev = std::min((W.cap - 2) / 2, W.n - 1);   // krylovdim = 2 nev + 1 <= cap - 1
+    int g = W.last_npos + std::max(3, W.last_npos / 8);
+    if (8 * W.last_npos > W.n) return false;                 // many positive pairs: the dense solver is the cheaper tool
+    const bool used_fop = W.use_fop;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (g > maxnev || g < 1) break;
+        lanczos(W, xp, g, true);
+        if (!W.converged) {                                   // more positives than g, or no convergence
+            if (attempt == 0 && g < maxnev) { g = std::min(2 * g + 2, maxnev); continue; }
+            break;
+        }
+        const int npos = W.count;
+        // guard: between consecutive projections of this regime the number of positive eigenvalues
+        // moves by a few; a collapse means the Krylov space was fooled (e.g. decoupled coordinates
+        // resolved long before the small positive pairs): let the dense solver decide
+        if (npos + 2 + W.last_npos / 8 < W.last_npos) break;
+        int rank = 0;
+        for (int i = 0; i < npos; ++i) if (W.vals[i] > opt.tol_psd) ++rank;
+        // (values are descending: the positive ones are the first npos)
+        W.use_fop = false;
+        if (used_fop) W.lst.fop_projections++;
+        W.lst.full_eigs++; W.lst.full_eigs_lanczos++;
+        current_rank[idx] = rank;
+        min_eig[idx] = 0.0;                                  // prox_operators.jl:114
+        W.last_npos = npos;
+        if (npos > 0) W.lam.upload(W.vals.data(), npos, stream);
+        launch_reconstruct(W, W.Z.p, W.npad, W.lam.p, npos, xo, fuse ? xp : nullptr, fuse ? idx : -1);
+        W.recon_r += npos;
+        if (W.fop_ok) {
+            std::swap(W.Z.p, W.F.p);
+            W.F_first = 0; W.F_r = npos;
+            std::swap(W.lam.p, W.Flam.p);
+            std::swap(W.lam.n, W.Flam.n);
+            W.have_factors = true; W.x_prev_sparse = false;
+        }
+        return true;
+    }
+    W.use_fop = false;
+    return false;
 }
 
 inline void Solver::psd_projection(double* x) {
@@ -970,7 +1047,11 @@ inline void Solver::run() {
             if (B.n == 1) { one_blocks.push_back((int)idx); offs.push_back(B.off); if (ur) ur += 1; continue; }
             EigWork& W = eig[idx];
             big_blocks.push_back((int)idx);
-            const int max_nev = std::min<int>(std::max<int>(opt.max_target_rank_krylov_eigs, 2), B.n);
+            // Krylov workspace: the largest target rank the Krylov path may see, and room for
+            // full_eig!-by-Lanczos (up to (MAXK - 4) / 2 = 94 pairs) on blocks that can take it
+            int max_nev = std::min<int>(std::max<int>(opt.max_target_rank_krylov_eigs, 2), B.n);
+            if (opt.full_eig_lanczos != 0 && B.n > opt.min_size_krylov_eigs && B.n >= 400)
+                max_nev = std::max(max_nev, std::min((dev::MAXK - 4) / 2, B.n / 4));
             alloc_eigwork(W, B.n, max_nev);
             W.resid_host.resize(W.npad, 0.0);
             if (ur) { std::copy(ur, ur + B.n, W.resid_host.begin()); ur += B.n; }

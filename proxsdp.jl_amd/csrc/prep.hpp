@@ -70,11 +70,12 @@ inline void check_csc(const proxsdp_csc& M, int64_t rows, int64_t cols, int base
     }
 }
 
-// equilibrate! (equilibration.jl:1-72) on the reordered, unscaled M (CSC).  Two quirks of the
-// reference are reproduced as written: v is replaced by its mean in every iteration (:56-58), so D
-// comes out as a multiple of the identity; and `E = Diagonal(u)`, `D = Diagonal(v)` (:16-17) wrap u
-// and v without copying, so `E.diag .= exp.(u)` (:25-26) overwrites u by exp(u) (v by exp(v)) at
-// the top of every iteration and the gradient / projection steps start from there.
+// equilibrate! (equilibration.jl:1-72) on the reordered, unscaled M (CSC).  The reference replaces
+// v by its mean in every iteration (:56-58), so D comes out as a multiple of the identity: kept.
+// DELIBERATE DEVIATION (same in oracle/pdhg.py:equilibrate, see there): the reference's
+// `E = Diagonal(u)` / `D = Diagonal(v)` (:16-17) alias u and v, so `E.diag .= exp.(u)` (:25-26)
+// overwrites u by exp(u) every iteration; restated that way the scaling is badly conditioned and
+// known answers fail.  Implemented here without the aliasing (u, v kept; E = exp(u), D = exp(v)).
 inline void equilibrate_host(const Prep& R, const proxsdp_options& opt, std::vector<double>& Ed, std::vector<double>& Dd) {
     const int64_t nQ = R.Q, n = R.n;
     const double alpha = std::pow((double)n / (double)nQ, 0.25), beta = std::pow((double)nQ / (double)n, 0.25);
@@ -82,8 +83,8 @@ inline void equilibrate_host(const Prep& R, const proxsdp_options& opt, std::vec
     std::vector<double> u(nQ, 0.0), v(n, 0.0), u_(nQ, 0.0), v_(n, 0.0), rn(nQ), cn(n);
     Ed.assign(nQ, 1.0); Dd.assign(n, 1.0);
     for (int64_t it = 1; it <= opt.equilibration_iters; ++it) {
-        for (int64_t r = 0; r < nQ; ++r) Ed[r] = u[r] = std::exp(u[r]);      // E.diag === u (aliasing)
-        for (int64_t k = 0; k < n; ++k) Dd[k] = v[k] = std::exp(v[k]);
+        for (int64_t r = 0; r < nQ; ++r) Ed[r] = std::exp(u[r]);
+        for (int64_t k = 0; k < n; ++k) Dd[k] = std::exp(v[k]);
         std::fill(rn.begin(), rn.end(), 0.0);
         for (int64_t k = 0; k < n; ++k) {
             double cs = 0.0;

@@ -168,6 +168,7 @@ struct EigWork {
     bool have_factors = false;                     // x_prev of this block is F[:, F_first .. +F_r) diag(Flam) F'
     bool x_prev_sparse = true;                     // x_prev is zero off the support (initial iterate)
     bool use_fop = false;                          // the projection in progress uses the operator form
+    int last_npos = -1;                            // positive eigenvalues found by the last full_eig! of this block
     const double* esv = nullptr;                   // support values of E for the projection in progress
     // per-block execution context: counters are merged into the solver's after the projections
     hipStream_t stream = nullptr;                  // own stream (concurrent block projections)
@@ -216,7 +217,7 @@ public:
     // pieces also used by the kernel-level test entry points
     void setup_device();
     void alloc_eigwork(EigWork& W, int n, int max_nev);
-    void lanczos(EigWork& W, const double* xp, int nev);
+    void lanczos(EigWork& W, const double* xp, int nev, bool positive_part = false);
     void full_eig_values(EigWork& W, const double* xp, double offscale, bool vectors, std::vector<double>& Dhost);
     void harvest_full_eig_events(EigWork& W);
     void launch_symv(EigWork& W, const double* xp, const double* v, bool use_ctl);
@@ -325,6 +326,7 @@ private:
     void dense_mtv(int nc, const double* Y, long long ystride, bool scaled, double* OUT, long long ostride,
                    const double* old, const double* addc, double* normpart, long long cstride);
     void full_eig_project(int idx, const double* xp_in, double* xp_out, bool fuse);
+    bool full_eig_by_lanczos(int idx, const double* xp_in, double* xp_out, bool fuse);
     void spmv(const double* x, double* y);
     void spmv_sparse(const double* x, double* y);
     int  linesearch();
@@ -580,7 +582,16 @@ inline void Solver::rotate(EigWork& W, int K, const std::vector<double>& U, int 
 // with A = Symmetric(smat(xp)).  eigsolver == 1 selects ARPACK's acceptance rule
 // (dsaupd: |resid_i| <= tol*max(eps^(2/3), |theta_i|) for all nev wanted values,
 // eigsolver.jl:668-746) on the same thick-restart engine.
-inline void Solver::lanczos(EigWork& W, const double* xp, int nev) {
+// positive_part (full_eig! served by this engine, pdhg_loop.hip.hpp full_eig_by_lanczos): the wanted
+// set is "every eigenpair with lambda > 0", at most nev of them.  A cycle ends the run when all
+// positive Ritz pairs are converged to tol AND the first non-positive Ritz pair j is itself resolved
+// to 1e-9 of the spectral scale: a Krylov space that has resolved pair j has (generically) resolved
+// everything above it, which is the same reliance every Lanczos acceptance rule makes.  (A residual
+// merely smaller than |theta_j| is NOT enough: an unconverged Ritz value is a mixture and can sit
+// below zero while small positive eigenvalues are still unresolved -- measured on gpp500-1.)
+// Returns the j positive pairs (count = j, possibly 0, converged = true), or converged = false when
+// more than nev Ritz values are positive / maxiter is hit.
+inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive_part) {
     const bool arpack = (opt.eigsolver == 1);
     const int krylovdim = std::max(2 * nev + 1, (int)opt.eigsolver_min_lanczos);
     if (krylovdim + 1 > W.cap) throw std::invalid_argument("Lanczos workspace too small for the requested rank");
@@ -598,7 +609,8 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev) {
 
     const int ld = krylovdim + 1;
     std::vector<double> T((size_t)ld * ld, 0.0), Tw, D(ld), U, f(ld), al(ld), be(ld), Qa, da, ea;
-    int howmany = nev, numiter = 1, converged = 0, K = 0, kfirst = 0;
+    int howmany = nev, numiter = 1, converged = 0, K = 0, kfirst = 0, pos_count = -1;
+    bool pos_fail = false;
     bool presymv = false;
     double betaK = 0.0;
     dev::LanczosCtl hctl{};
@@ -749,8 +761,22 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev) {
             for (int i = 0; i < want; ++i)
                 if (std::fabs(f[i]) <= tol * std::max(eps23, std::fabs(D[i]))) ++converged;
         }
+        if (positive_part) {
+            int j = 0;
+            while (j < K && D[j] > 0.0) ++j;
+            if (j > nev) { pos_fail = true; break; }      // more positive pairs than the workspace was sized for
+            const double scale = std::max(std::fabs(D[0]), std::fabs(D[K - 1]));
+            // the deciding pair: the first STRICTLY negative Ritz value (an exactly-zero pair with zero
+            // residual is what a decoupled, unused coordinate of the block looks like: it is found at
+            // once and says nothing about the pairs around it)
+            int jn = j;
+            while (jn < K && D[jn] >= -1e-12 * scale) ++jn;
+            if (converged >= j && (jn == K || std::fabs(f[jn]) <= std::max(tol, 1e-9 * scale))) { pos_count = j; break; }
+            if (K < krylovdim || numiter == maxiter) { pos_fail = true; break; }
+        } else {
         if (converged >= howmany) break;
         if (K < krylovdim) break;                        // invariant subspace without convergence (arpack rule)
+        }
         if (numiter == maxiter) break;
         const int keep = arpack ? std::min(krylovdim - 1, nev + std::max(1, (krylovdim - nev) / 2))
                                 : (3 * krylovdim + 2 * converged) / 5;
@@ -771,6 +797,13 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev) {
         W.lst.lanczos_restarts++;
     }
     W.numiter = numiter;
+    if (positive_part) {
+        if (pos_fail || pos_count < 0) { W.converged = false; return; }
+        W.count = pos_count; W.converged_eigs = pos_count; W.converged = true;
+        W.vals.assign(D.begin(), D.begin() + pos_count);
+        if (pos_count > 0) rotate(W, K, U, K, pos_count, W.Z.p, -1, 0, nullptr, 0);
+        return;
+    }
     if (arpack) {
         // _saupd!/_seupd! (eigsolver.jl:668-746): converged only when all nev pairs are
         W.converged_eigs = converged;
@@ -833,6 +866,7 @@ inline void Solver::full_eig_project(int idx, const double* xp_in, double* xp_ou
     for (int i = 0; i < n; ++i) { if (D[i] > 0.0) ++npos; if (D[i] > opt.tol_psd) ++rank; }
     current_rank[idx] = rank;
     min_eig[idx] = 0.0;
+    W.last_npos = npos;
     // ascending order: the positive eigenpairs are the trailing npos columns
     launch_reconstruct(W, W.A.p + (size_t)(n - npos) * n, n, W.D.p + (n - npos), npos, xp_out,
                        fuse ? xp_in : nullptr, fuse ? idx : -1);
@@ -924,7 +958,7 @@ inline void Solver::merge_block_stats() {
         st.symv_profiled += a.symv_profiled; st.symv_profiled_ms += a.symv_profiled_ms;
         st.orth_profiled += a.orth_profiled; st.orth_profiled_ms += a.orth_profiled_ms;
         st.full_eig_solver_ms += a.full_eig_solver_ms; st.full_eig_recon_ms += a.full_eig_recon_ms;
-        st.device_eigs += a.device_eigs; st.mfma_reconstructions += a.mfma_reconstructions; st.cycle_launches += a.cycle_launches;
+        st.full_eigs_lanczos += a.full_eigs_lanczos; st.device_eigs += a.device_eigs; st.mfma_reconstructions += a.mfma_reconstructions; st.cycle_launches += a.cycle_launches;
         st.symv_bytes += a.symv_bytes; st.host_eig_time += a.host_eig_time; st.host_eigs += a.host_eigs;
         st.fop_projections += a.fop_projections;
         a = proxsdp_stats{};
