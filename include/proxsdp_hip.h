@@ -179,9 +179,11 @@ typedef struct proxsdp_options {
                                   * positive eigenvalues, compute them with the Lanczos engine (all pairs down to the
                                   * first eigenvalue <= 0, converged to krylovkit_tol) and fall back to the dense
                                   * eigensolver otherwise; 0 = always the dense eigensolver.  Same projection. */
-    int32_t lanczos_cycle_kernel;/* -1 auto, 0 off, 1 on: run a whole Lanczos cycle (operator form) in ONE persistent
-                                  * launch whose workgroups keep their rows of the basis in LDS and exchange partial
-                                  * dots in-launch, instead of two launches per step.  Same arithmetic per step. */
+    int32_t lanczos_cycle_kernel;/* 1 = run a whole Lanczos cycle (operator form) in ONE persistent launch whose <= 32
+                                  * workgroups sit on one XCD, keep their rows of the basis in LDS and exchange partial
+                                  * dots through that XCD's L2, instead of two launches per step (same arithmetic per
+                                  * step; falls back to the step kernels if its bounded spins time out).  -1 auto = 0 =
+                                  * off: measured gain 1.3x per step, +5 % iterations/s. */
     int32_t lanczos_warm_start;  /* 0 (default): every projection starts from the fixed start vector, as the
                                   * reference does (krylovkit_reset_resid = false).  1: start from the normalised sum of
                                   * the previous projection's Ritz vectors (+ 1e-3 x the fixed vector).  Changes the
@@ -230,8 +232,9 @@ typedef struct proxsdp_stats {
     double  full_eig_recon_ms;   /* full_eig!: reconstruction kernel time (events)               */
     int64_t cycle_launches;      /* Lanczos cycles run by the persistent LDS-resident kernel     */
     int64_t full_eigs_lanczos;   /* full_eig! calls served by the Lanczos engine (all positive pairs) */
-    int64_t reserved_i[1];
-    double  reserved_d[2];
+    int64_t cycle_steps;         /* Lanczos steps run inside those launches                       */
+    double  cycle_ms;            /* their summed kernel time (events; profile_symv_every > 0)     */
+    double  reserved_d[1];
 } proxsdp_stats;
 
 /* Result (structs.jl:60-81).  Arrays are caller-allocated with the stated

@@ -87,8 +87,9 @@ struct Stats                     # proxsdp_stats
     full_eig_recon_ms::Float64
     cycle_launches::Int64
     full_eigs_lanczos::Int64
-    reserved_i::NTuple{1,Int64}
-    reserved_d::NTuple{2,Float64}
+    cycle_steps::Int64
+    cycle_ms::Float64
+    reserved_d::NTuple{1,Float64}
 end
 
 mutable struct CResult           # proxsdp_result

@@ -781,6 +781,11 @@ inline void Solver::setup_support() {
             W.tpart.alloc((size_t)dev::MAXK * W.pld); W.tpart.zero(stream);
             W.ebuf.alloc(W.npad); W.ebuf.zero(stream);
             W.apartf.alloc(W.pld); W.apartf.zero(stream);
+            // persistent cycle kernel: granule buffers [64 workgroups][CY_CMAX][2], zero = never-valid tag
+            W.xg1.alloc((size_t)32 * dev::CY_CMAX); W.xg1.zero(stream);
+            W.xg2.alloc((size_t)32 * (dev::CY_CMAX + 128)); W.xg2.zero(stream);           // + the R rows of w'
+            W.xf1.alloc(32); W.xf1.zero(stream); W.xf2.alloc(32); W.xf2.zero(stream);     // flags: zero = never-valid epoch
+            W.cy_err.alloc(1); W.cy_err.zero(stream);
             PX_HIP(hipStreamSynchronize(stream));                 // host vectors go out of scope
             W.fop_ok = true;
         }
@@ -1342,6 +1347,15 @@ inline void Solver::run() {
     PX_HIP(hipStreamSynchronize(stream));
     for (EigWork& W : eig) harvest_full_eig_events(W);
     merge_block_stats();
+    if (cy_dbg.n) {
+        long long t[8];
+        cy_dbg.download(t, 8, stream);
+        PX_HIP(hipStreamSynchronize(stream));
+        std::fprintf(stderr, "[cycle ticks/step @100MHz] close+opA %.1f X1 %.1f phaseB %.1f X2 %.1f | %.1f %.1f (steps %lld)\n",
+                     (double)t[0] / st.cycle_steps, (double)t[1] / st.cycle_steps, (double)t[2] / st.cycle_steps,
+                     (double)t[3] / st.cycle_steps, (double)t[4] / st.cycle_steps, (double)t[5] / st.cycle_steps, (long long)st.cycle_steps);
+        std::fprintf(stderr, "[cycle] XCC id mask of the active workgroups: 0x%llx\n", (unsigned long long)t[7]);
+    }
     st.loop_time = now_s() - t_loop0;
     if (warm.joinable()) warm.join();
 

@@ -30,6 +30,7 @@
 
 #include "host_util.hpp"
 #include "kernels.hip.hpp"
+#include "lanczos_cycle.hip.hpp"
 #include "prep.hpp"
 
 namespace proxsdp {
@@ -169,6 +170,15 @@ struct EigWork {
     bool x_prev_sparse = true;                     // x_prev is zero off the support (initial iterate)
     bool use_fop = false;                          // the projection in progress uses the operator form
     int last_npos = -1;                            // positive eigenvalues found by the last full_eig! of this block
+    // persistent Lanczos cycle kernel (lanczos_cycle.hip.hpp): granule buffers, epoch counter, error word
+    DevBuf<double> xg1, xg2;
+    DevBuf<unsigned> xf1, xf2;
+    DevBuf<int> cy_err;
+    PinnedBuf cy_err_host;                         // pinned mirror of cy_err (first 4 bytes)
+    unsigned cy_epoch = 1;
+    bool cy_disabled = false;
+    hipEvent_t cye[2] = {nullptr, nullptr};
+    bool cye_pending = false;
     const double* esv = nullptr;                   // support values of E for the projection in progress
     // per-block execution context: counters are merged into the solver's after the projections
     hipStream_t stream = nullptr;                  // own stream (concurrent block projections)
@@ -204,6 +214,7 @@ public:
             for (auto e : W.evo.e0) (void)hipEventDestroy(e);
             for (auto e : W.evo.e1) (void)hipEventDestroy(e);
             for (auto e : W.fe) if (e) (void)hipEventDestroy(e);
+            for (auto e : W.cye) if (e) (void)hipEventDestroy(e);
             if (W.done) (void)hipEventDestroy(W.done);
             if (W.stream) (void)hipStreamDestroy(W.stream);
         }
@@ -220,6 +231,10 @@ public:
     void lanczos(EigWork& W, const double* xp, int nev, bool positive_part = false);
     void full_eig_values(EigWork& W, const double* xp, double offscale, bool vectors, std::vector<double>& Dhost);
     void harvest_full_eig_events(EigWork& W);
+    bool cycle_plan(const EigWork& W, int krylovdim, int& R, int& G, bool& f_in_lds) const;
+    void launch_cycle(EigWork& W, int kfirst, int krylovdim, double tol, int R, int G, bool f_in_lds);
+    int cycle_lds_cap = 0;                        // dynamic LDS granted to k_lz_cycle (setup_device)
+    DevBuf<long long> cy_dbg;                     // PROXSDP_HIP_DEBUG_CYCLE: per-phase tick sums
     void launch_symv(EigWork& W, const double* xp, const double* v, bool use_ctl);
     void launch_symv_finish(EigWork& W, const double* xp, int kclose, double tol, bool use_carry);
     void launch_reconstruct(EigWork& W, const double* Z, int ldz, const double* lam, int r, double* xp_out,
@@ -415,8 +430,80 @@ inline void Solver::setup_device() {
     rotate_lds_cap = (hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_lz_rotate),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) == hipSuccess)
                          ? 144 * 1024 : 60 * 1024;
+    if (std::getenv("PROXSDP_HIP_DEBUG_CYCLE") != nullptr) { cy_dbg.alloc(8); cy_dbg.zero(stream); }
+    cycle_lds_cap = 0;
+    for (int kb : {160, 156, 152, 144, 128, 96, 64}) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_lz_cycle<128>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kb * 1024) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_lz_cycle<64>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kb * 1024) == hipSuccess) {
+            cycle_lds_cap = kb * 1024;
+            break;
+        }
+        (void)hipGetLastError();
+    }
     PX_ROC(rocblas_create_handle(&blas));
     PX_ROC(rocblas_set_stream(blas, stream));
+}
+
+// persistent cycle kernel: rows per workgroup, grid and whether the previous factors fit in LDS
+inline bool Solver::cycle_plan(const EigWork& W, int krylovdim, int& R, int& G, bool& f_in_lds) const {
+    if (std::getenv("PROXSDP_HIP_DEBUG_CYCLE") != nullptr)
+        std::fprintf(stderr, "[cycle_plan] knob %d disabled %d cap %d par %d fop %d ov %d xg %zu kd %d Fr %d ellw %d npad %d\n",
+                     (int)opt.lanczos_cycle_kernel, (int)W.cy_disabled, cycle_lds_cap, (int)parallel_blocks, (int)W.use_fop,
+                     (int)(W.ov.wr_ptr != nullptr), W.xg1.n, krylovdim, W.F_r, W.ell_w, W.npad);
+    // auto (-1) = off: measured 10.9 us per Lanczos step against 14.1 us for the step kernels at n = 4000,
+    // K = 25 -- +5 % iterations/s, not worth an assumption about workgroup placement by default
+    if (opt.lanczos_cycle_kernel != 1 || W.cy_disabled || cycle_lds_cap == 0 || parallel_blocks) return false;
+    if (!W.use_fop || W.ov.wr_ptr != nullptr || W.xg1.n == 0) return false;
+    if (krylovdim + 2 > dev::CY_CMAX - 2 || W.F_r > 126) return false;
+    const size_t cap = (size_t)cycle_lds_cap - 512;
+    for (int r : {128, 64}) {
+        const int S = dev::NWAVE / (r / 64);
+        if (W.ell_w > dev::CY_NE * S) continue;
+        const int g = ceil_div(W.npad, r);
+        if (g > 32) continue;                               // one XCD: 32 CUs, one workgroup each
+        for (bool fl : {true, false}) {
+            if (dev::cycle_lds_bytes(krylovdim, W.F_r, r, g, fl) <= cap) { R = r; G = g; f_in_lds = fl; return true; }
+        }
+    }
+    return false;
+}
+
+inline void Solver::launch_cycle(EigWork& W, int kfirst, int krylovdim, double tol, int R, int G, bool f_in_lds) {
+    dev::CycleArgs a{};
+    a.V = W.V.p; a.ldv = W.npad; a.n = W.n; a.npad = W.npad;
+    a.kfirst = kfirst; a.kd = krylovdim; a.tol = tol;
+    a.Vp = W.F.p + (size_t)W.F_first * W.npad; a.rp = W.F_r; a.lam = W.Flam.p;
+    a.ell_col = W.ell_col.p; a.ell_sidx = W.ell_sidx.p; a.ell_w = W.ell_w; a.esv = W.esv;
+    a.arrow = W.arrow_p;
+    a.alphas = W.alphas_p; a.betas = W.betas_p; a.ctl = W.ctl_p;
+    a.x1 = W.xg1.p; a.x2 = W.xg2.p; a.xs1 = dev::CY_CMAX; a.xs2 = dev::CY_CMAX + 128;
+    a.f1 = W.xf1.p; a.f2 = W.xf2.p;
+    a.epoch0 = W.cy_epoch;
+    a.R = R; a.G = G; a.f_in_lds = f_in_lds ? 1 : 0;
+    a.err = W.cy_err.p;
+    a.dbg = cy_dbg.p;
+    W.cy_epoch += 2u * (unsigned)(krylovdim - kfirst) + 8u;
+    if (W.cy_epoch > 0xF0000000u) {                        // tags would wrap: start over on zeroed buffers
+        W.xf1.zero(stream); W.xf2.zero(stream); W.cy_epoch = 1; a.epoch0 = 1;
+        W.cy_epoch += 2u * (unsigned)(krylovdim - kfirst) + 8u;
+    }
+    const size_t lds = dev::cycle_lds_bytes(krylovdim, W.F_r, R, G, f_in_lds);
+    const bool prof = opt.profile_symv_every > 0;
+    if (prof) {
+        if (W.cye[0] == nullptr) { PX_HIP(hipEventCreate(&W.cye[0])); PX_HIP(hipEventCreate(&W.cye[1])); }
+        if (R == 128) hipExtLaunchKernelGGL(dev::k_lz_cycle<128>, dim3(8 * G), dim3(dev::TPB), lds, stream, W.cye[0], W.cye[1], 0, a);
+        else hipExtLaunchKernelGGL(dev::k_lz_cycle<64>, dim3(8 * G), dim3(dev::TPB), lds, stream, W.cye[0], W.cye[1], 0, a);
+        W.cye_pending = true;
+    } else {
+        if (R == 128) hipLaunchKernelGGL(dev::k_lz_cycle<128>, dim3(8 * G), dim3(dev::TPB), lds, stream, a);
+        else hipLaunchKernelGGL(dev::k_lz_cycle<64>, dim3(8 * G), dim3(dev::TPB), lds, stream, a);
+    }
+    W.lst.cycle_launches++;
+    W.lst.cycle_steps += krylovdim - kfirst;
+    W.lst.symv_launches += krylovdim - kfirst;
+    W.lst.symv_bytes += (double)(krylovdim - kfirst) * (8.0 * (double)W.N + 16.0 * (double)W.n);
 }
 
 // rocSOLVER's first dsyevd in a process pays ~3 s of code-object loading.  The exit path
@@ -614,7 +701,16 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive
     bool presymv = false;
     double betaK = 0.0;
     dev::LanczosCtl hctl{};
+    int cyR = 0, cyG = 0;
+    bool cyF = false;
+    const bool cyc = cycle_plan(W, krylovdim, cyR, cyG, cyF);
+    int cy_err_host = 0;
+    if (cyc && W.cy_err_host.p == nullptr) { W.cy_err_host.alloc(1); W.cy_err_host.p[0] = 0.0; }
     while (true) {
+        if (cyc) {
+            launch_cycle(W, kfirst, krylovdim, step_tol, cyR, cyG, cyF);
+            PX_HIP(hipMemcpyAsync(W.cy_err_host.p, W.cy_err.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+        } else {
         for (int k = kfirst; k < krylovdim; ++k) {
             if (k == kfirst) {
                 if (!presymv) launch_symv(W, xp, W.V.p + (size_t)k * W.npad, true);   // v_k is ready (start)
@@ -673,7 +769,8 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive
         // final now: enqueue it before the host round trip so the GPU works during the K x K
         // eigensolve (wasted only when this cycle turns out to be the last one)
         // -- speculated only when this block's previous projection needed a restart too
-        const bool speculate = W.prev_numiter > 1 || numiter > 1;
+        }
+        const bool speculate = !cyc && (W.prev_numiter > 1 || numiter > 1);
         if (speculate) {
             launch_symv(W, xp, W.V.p + (size_t)krylovdim * W.npad, true);
             W.lst.symv_launches--; W.lst.symv_bytes -= 8.0 * (double)W.N + 16.0 * (double)W.n;   // counted when used
@@ -694,6 +791,21 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive
             householder_tridiag(n1, Qa.data(), da.data(), ea.data());
         }
         PX_HIP(hipStreamSynchronize(stream));
+        if (W.cye_pending) {
+            W.cye_pending = false;
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, W.cye[0], W.cye[1]) == hipSuccess) W.lst.cycle_ms += ms;
+        }
+        if (cyc) std::memcpy(&cy_err_host, W.cy_err_host.p, sizeof(int));
+        if (cyc && cy_err_host != 0) {
+            // a spin inside the persistent kernel timed out (its workgroups were not all resident):
+            // switch this block to the step kernels for the rest of the solve and redo the projection
+            W.cy_disabled = true;
+            W.cy_err.zero(stream);
+            W.lst.lanczos_calls--;
+            lanczos(W, xp, nev, positive_part);
+            return;
+        }
         std::copy(W.rec_host, W.rec_host + krylovdim, al.begin());
         std::copy(W.rec_host + dev::MAXK, W.rec_host + dev::MAXK + krylovdim, be.begin());
         std::memcpy(&hctl, W.rec_host + 2 * dev::MAXK, sizeof(hctl));
@@ -959,6 +1071,7 @@ inline void Solver::merge_block_stats() {
         st.orth_profiled += a.orth_profiled; st.orth_profiled_ms += a.orth_profiled_ms;
         st.full_eig_solver_ms += a.full_eig_solver_ms; st.full_eig_recon_ms += a.full_eig_recon_ms;
         st.full_eigs_lanczos += a.full_eigs_lanczos; st.device_eigs += a.device_eigs; st.mfma_reconstructions += a.mfma_reconstructions; st.cycle_launches += a.cycle_launches;
+        st.cycle_steps += a.cycle_steps; st.cycle_ms += a.cycle_ms;
         st.symv_bytes += a.symv_bytes; st.host_eig_time += a.host_eig_time; st.host_eigs += a.host_eigs;
         st.fop_projections += a.fop_projections;
         a = proxsdp_stats{};
