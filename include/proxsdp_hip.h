@@ -314,6 +314,10 @@ int proxsdp_hip_symv_packed(const double* packed, int64_t n, const double* v, do
  * (fill! + rank-1 dgemm loop, prox_operators.jl:92-106, then :17-31) */
 int proxsdp_hip_reconstruct(const double* Z, const double* lambda, int64_t n, int32_t r,
                             double* packed_out, int32_t repeat, double* ms);
+/* the same with the kernel chosen explicitly: mfma = 0 scalar-FMA kernel (LDS-staged), 1 = fp64 MFMA
+ * SYRK (v_mfma_f64_16x16x4_f64), -1 = the library's choice (options.reconstruct_mfma auto) */
+int proxsdp_hip_reconstruct_kernel(const double* Z, const double* lambda, int64_t n, int32_t r, int32_t mfma,
+                                   double* packed_out, int32_t repeat, double* ms);
 
 /* Mx = M x (pdhg.jl:634) and Mty = M' y (pdhg.jl:556) for M given as CSC */
 int proxsdp_hip_spmv(const proxsdp_csc* M, int32_t index_base, int32_t transpose,

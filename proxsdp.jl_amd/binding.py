@@ -179,6 +179,7 @@ def lib():
                                        C.POINTER(i32), C.POINTER(i32), pi64, C.POINTER(i32)]
     L.proxsdp_hip_symv_packed.argtypes = [pf64, i64, pf64, pf64, i32, pf64]
     L.proxsdp_hip_reconstruct.argtypes = [pf64, pf64, i64, i32, pf64, i32, pf64]
+    L.proxsdp_hip_reconstruct_kernel.argtypes = [pf64, pf64, i64, i32, i32, pf64, i32, pf64]
     L.proxsdp_hip_spmv.argtypes = [C.POINTER(CSC), i32, i32, pf64, pf64]
     L.proxsdp_host_symeig.argtypes = [i32, pf64, pf64]
     L.proxsdp_host_start_vector.argtypes = [i64, i64, i32, pf64]
@@ -415,14 +416,15 @@ def residuals(x, x_old, Mty, Mty_old, c, tau, y, y_old, Mx, Mx_old, bh, p, sigma
     return out
 
 
-def reconstruct(Z, lam, n, repeat=0):
+def reconstruct(Z, lam, n, repeat=0, mfma=-1):
+    """mfma: -1 the library's choice, 0 scalar-FMA kernel, 1 fp64 MFMA SYRK"""
     L = lib()
     Zc = np.asfortranarray(Z, dtype=np.float64)
     lam = _f(lam)
     r = len(lam)
     out = np.zeros(n * (n + 1) // 2)
     ms = f64(0.0)
-    _check(L.proxsdp_hip_reconstruct(Zc.ctypes.data_as(pf64), _p(lam), n, r, _p(out), repeat, C.byref(ms)))
+    _check(L.proxsdp_hip_reconstruct_kernel(Zc.ctypes.data_as(pf64), _p(lam), n, r, mfma, _p(out), repeat, C.byref(ms)))
     return (out, ms.value) if repeat else out
 
 

@@ -227,10 +227,17 @@ int proxsdp_hip_symv_packed(const double* packed, int64_t n, const double* v, do
 
 int proxsdp_hip_reconstruct(const double* Z, const double* lambda, int64_t n, int32_t r,
                             double* packed_out, int32_t repeat, double* ms) {
+    return proxsdp_hip_reconstruct_kernel(Z, lambda, n, r, -1, packed_out, repeat, ms);
+}
+
+int proxsdp_hip_reconstruct_kernel(const double* Z, const double* lambda, int64_t n, int32_t r, int32_t mfma,
+                                   double* packed_out, int32_t repeat, double* ms) {
     return guarded([&]() -> int {
         if ((r > 0 && (!Z || !lambda)) || !packed_out) throw std::invalid_argument("NULL buffer");
         if (r < 0) throw std::invalid_argument("r < 0");
-        Engine E(nullptr, n, 2);
+        proxsdp_options o = Engine::fix(nullptr);
+        o.reconstruct_mfma = mfma;
+        Engine E(&o, n, 2);
         proxsdp::Solver& S = E.S;
         proxsdp::EigWork& W = S.eig[0];
         const int64_t N = n * (n + 1) / 2;

@@ -960,6 +960,121 @@ k_reconstruct_packed(const double* __restrict__ Z, int ldz, const double* __rest
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same rank-r reconstruction on the fp64 matrix cores: a SYRK on the packed triangle,
+//   xp[(i,j)] = s_ij * sum_k Z[i,k] lambda_k Z[j,k],
+// tiled for v_mfma_f64_16x16x4_f64 (BASELINE north_star: "MFMA-tiled V Lam+ V' rank-r SYRK").
+// One workgroup per 64x64 tile (I <= J) of the block triangle, XCD-aware tile order as above; wave
+// w owns the 16 tile COLUMNS [16w, 16w+16) of block J and all 64 tile rows of block I: four 16x16
+// accumulators.  The product is formed transposed, D[jj][ii] = sum_k (lambda_k Z[J+jj,k]) Z[I+ii,k]:
+// in the f64 MFMA's C/D layout (col = lane & 15, row = (lane >> 4) + 4 reg) a lane then holds 16
+// consecutive ROWS ii of the output for its columns, so every store instruction writes 128-byte
+// contiguous pieces of packed columns.  A and B fragments are ONE double per lane (A[i = l & 15]
+// [k = l >> 4]); 16-k chunks of the two 64-row slabs of Z are staged in LDS (double-buffered, the
+// next chunk's global loads fly during the current chunk's 16 MFMAs per wave), 5 conflict-free
+// ds_read_b64 per 4 MFMAs instead of the scalar kernel's 17 LDS reads per 16 FMAs.  fp64 MFMA runs at the fp64 vector rate on
+// gfx950 (78.6 TF), so this is about feeding the FMAs, not about a higher peak: the scalar kernel is
+// LDS-issue-bound from r ~ 16 on, this one reaches the write roofline up to r ~ 64 and the MFMA
+// roofline beyond (full_eig!: r+ ~ n/2).
+// FUSE_RES as in k_reconstruct_packed.
+// ---------------------------------------------------------------------------
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+constexpr int MF_KC = 16;            // k per staged chunk (32: 2 workgroups per CU instead of 4, measured slower)
+constexpr int MF_LD = TILE + 16;     // LDS row stride (doubles): k-rows 160 dwords apart -> the two k of a 32-lane group hit disjoint banks
+template <bool FUSE_RES>
+__global__ void __launch_bounds__(TPB)
+k_reconstruct_mfma(const double* __restrict__ Z, int ldz, const double* __restrict__ lam, int r,
+                   int n, double* __restrict__ xp, const double* __restrict__ xold,
+                   const unsigned* __restrict__ mask, long long mask_off, double* __restrict__ respart,
+                   int rstride) {
+    __shared__ double sA[2][MF_KC][MF_LD];      // lambda_k Z[J*64 + row, k]   (columns of the output)
+    __shared__ double sB[2][MF_KC][MF_LD];      // Z[I*64 + row, k]            (rows of the output)
+    __shared__ double s_red[NWAVE];
+    const int nt_ = (n + TILE - 1) / TILE;
+    const int tile = xcd_tile(blockIdx.x, nt_ * (nt_ + 1) / 2);
+    if (tile >= nt_ * (nt_ + 1) / 2) return;
+    int I, J;
+    tile_coords(tile, I, J);
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int l15 = lane & 15, l4 = lane >> 4;
+    // staging role: row = lane, k = w + 4 u (u < 4) of the chunk
+    const int gja = J * TILE + lane, gib = I * TILE + lane;
+    const bool ja_ok = gja < n, ib_ok = gib < n;
+    const double* __restrict__ zA = Z + (ja_ok ? gja : 0);
+    const double* __restrict__ zB = Z + (ib_ok ? gib : 0);
+    constexpr int MF_U = MF_KC / NWAVE;
+    double pa[MF_U], pb[MF_U];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < MF_U; ++u) {
+            const int k = k0 + w + 4 * u;
+            const bool kok = k < r;
+            const long long ko = (long long)(kok ? k : 0) * ldz;
+            const double lk = lam[kok ? k : 0];
+            pa[u] = (kok && ja_ok) ? zA[ko] * lk : 0.0;
+            pb[u] = (kok && ib_ok) ? zB[ko] : 0.0;
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < MF_U; ++u) { sA[buf][w + 4 * u][lane] = pa[u]; sB[buf][w + 4 * u][lane] = pb[u]; }
+    };
+    v4f64 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[b] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    // the old iterate / mask of the FUSE_RES epilogue are requested by the epilogue itself (the MFMA
+    // loop leaves no registers idle for them at r >= 12; below that the scalar kernel is used)
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = 0; k0 < r; k0 += MF_KC) {
+        const bool more = k0 + MF_KC < r;
+        if (more) fetch(k0 + MF_KC);                       // global loads in flight during the MFMAs below
+#pragma unroll
+        for (int q = 0; q < MF_KC / 4; ++q) {
+            const double a = sA[cur][4 * q + l4][w * 16 + l15];
+            double bv[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bv[b] = sB[cur][4 * q + l4][b * 16 + l15];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[b], acc[b], 0, 0, 0);
+        }
+        if (more) {
+            stash(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+    // D[jj][ii]: jj = l4 + 4 reg (column of block J inside this wave's 16), ii = l15 (row inside 16-row block b)
+    double m0 = 0.0, m1 = 0.0;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int gj = J * TILE + w * 16 + l4 + 4 * reg;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int gi = I * TILE + b * 16 + l15;
+            if (gj < n && gi <= gj) {
+                const long long idx = (long long)gj * (gj + 1) / 2 + gi;
+                const double xn = ((gi == gj) ? 1.0 : SQRT2) * acc[b][reg];
+                if (FUSE_RES) {
+                    const double xo = xold[idx];
+                    const long long gidx = mask_off + idx;
+                    const bool on = (mask[gidx >> 5] >> (gidx & 31)) & 1u;
+                    if (!on) { m0 = fmax(m0, fabs(xn - xo)); m1 = fmax(m1, fabs(xo)); }
+                }
+                xp[idx] = xn;
+            }
+        }
+    }
+    if (FUSE_RES) {
+        const double r0 = block_max(m0, s_red);
+        const double r1 = block_max(m1, s_red);
+        if (threadIdx.x == 0) { respart[blockIdx.x] = r0; respart[rstride + blockIdx.x] = r1; }
+    }
+}
+
 // packed svec -> dense column-major upper triangle (only for the full-eig
 // fallback, which hands the matrix to rocSOLVER): psd_vec_to_square :1-16
 __global__ void __launch_bounds__(TPB)

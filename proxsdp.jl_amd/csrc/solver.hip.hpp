@@ -621,6 +621,21 @@ inline void Solver::launch_symv_finish(EigWork& W, const double* xp, int kclose,
 inline void Solver::launch_reconstruct(EigWork& W, const double* Z, int ldz, const double* lam, int r, double* xp_out,
                                        const double* xp_old, int blk) {
     const int ntile = 8 * ceil_div(W.nt * (W.nt + 1) / 2, 8);     // padded to the 8 XCDs (xcd_tile)
+    // fp64 MFMA SYRK from rank 16 on in auto mode (measured cross-over at n = 4000: equal at 12-16,
+    // 1.17x at 26, 1.32x at 63, 1.7x at n/2)
+    const bool mfma = opt.reconstruct_mfma == 1 || (opt.reconstruct_mfma < 0 && r >= 16);
+    if (mfma) {
+        W.lst.mfma_reconstructions++;
+        if (use_support && xp_old != nullptr && blk >= 0)
+            hipLaunchKernelGGL(dev::k_reconstruct_mfma<true>, dim3(ntile), dim3(dev::TPB), 0, stream,
+                               Z, ldz, lam, r, W.n, xp_out, xp_old, mask_d.p, (long long)P.blocks[blk].off,
+                               respart_d.p + tile_base[blk], rstride);
+        else
+            hipLaunchKernelGGL(dev::k_reconstruct_mfma<false>, dim3(ntile), dim3(dev::TPB), 0, stream,
+                               Z, ldz, lam, r, W.n, xp_out, (const double*)nullptr, (const unsigned*)nullptr, 0LL,
+                               (double*)nullptr, 0);
+        return;
+    }
     if (use_support && xp_old != nullptr && blk >= 0)
         hipLaunchKernelGGL(dev::k_reconstruct_packed<true>, dim3(ntile), dim3(dev::TPB), 0, stream,
                            Z, ldz, lam, r, W.n, xp_out, xp_old, mask_d.p, (long long)P.blocks[blk].off,

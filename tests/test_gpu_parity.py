@@ -62,14 +62,33 @@ def test_symv_is_symmetric_and_linear_at_full_size():
         assert abs(vals @ u - Xu[i]) <= 1e-11 * np.linalg.norm(vals) * np.linalg.norm(u)
 
 
-@pytest.mark.parametrize("n,r", [(5, 0), (5, 1), (64, 3), (65, 16), (200, 17), (257, 40), (513, 2)])
+@pytest.mark.parametrize("n,r", [(5, 0), (5, 1), (64, 3), (65, 16), (200, 17), (257, 40), (513, 2), (130, 130), (333, 7)])
 def test_reconstruct_matches_dense(n, r):
+    """both reconstruction kernels: the LDS-staged scalar-FMA one and the fp64 MFMA SYRK
+    (v_mfma_f64_16x16x4_f64; asymmetric Z x lambda, so a transposed C/D map would show)"""
     rng = np.random.default_rng(n + r)
     Z = rng.standard_normal((n, r))
     lam = rng.uniform(0.1, 5.0, r)
-    out = B.reconstruct(Z, lam, n)
     ref = svec((Z * lam) @ Z.T) if r else np.zeros(n * (n + 1) // 2)
-    assert np.allclose(out, ref, rtol=1e-13, atol=1e-13 * max(1.0, np.abs(ref).max()))
+    for mfma in (0, 1, -1):
+        out = B.reconstruct(Z, lam, n, mfma=mfma)
+        assert np.allclose(out, ref, rtol=1e-13, atol=1e-13 * max(1.0, np.abs(ref).max())), mfma
+
+
+def test_reconstruct_mfma_at_full_size_and_high_rank():
+    """n = 4000 at r = 63 (target rank ~ sqrt n) and r = 600 (full_eig!-sized positive part): MFMA
+    kernel == scalar kernel to rounding, and a few entries against the definition"""
+    n = 4000
+    rng = np.random.default_rng(7)
+    for r in (63, 600):
+        Z = rng.standard_normal((n, r)) / np.sqrt(n)
+        lam = rng.uniform(0.1, 5.0, r)
+        a = B.reconstruct(Z, lam, n, mfma=0)
+        b = B.reconstruct(Z, lam, n, mfma=1)
+        assert np.allclose(a, b, rtol=1e-12, atol=1e-13 * np.abs(a).max())
+        for (i, j) in ((0, 0), (5, 77), (63, 64), (1999, 3999), (3999, 3999)):
+            v = (Z[i] * lam) @ Z[j] * (1.0 if i == j else math.sqrt(2.0))
+            assert abs(b[j * (j + 1) // 2 + i] - v) <= 1e-12 * max(1.0, abs(v))
 
 
 def test_spmv_both_orientations():
