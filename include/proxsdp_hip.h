@@ -289,7 +289,8 @@ int  proxsdp_hip_device_count(void);          /* <0: PROXSDP_E_HIP */
  *         falling back to full_eig! when not converged;
  * mode 1: full_eig! (:111-126) through the dense eigensolver;
  * mode 2: full_eig! served by the Lanczos engine (every positive eigenpair), target_rank = estimate
- *         of the number of positive eigenvalues; *out_fell_back = 1 if the dense solver had to run.
+ *         of the number of positive eigenvalues; *out_fell_back = 1 if the dense solver had to run;
+ * mode 3: full_eig! by the batched small-block Jacobi kernel (2 <= n <= 64); *out_converged = #{lambda > 0}.
  * resid: start vector (n) or NULL.  out_*: rank (current_rank), min_eig,
  * nmatvec, converged eigenpairs, fell_back flag. */
 int proxsdp_hip_psd_project(const double* packed_in, int64_t n, int32_t target_rank,

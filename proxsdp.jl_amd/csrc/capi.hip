@@ -146,6 +146,28 @@ int proxsdp_hip_psd_project(const double* packed_in, int64_t n, int32_t target_r
         x.upload(packed_in, N, S.stream);
         S.P.blocks.push_back({(int)n, N, 0});
         if (mode == 2) S.eig[0].last_npos = target_rank;
+        if (mode == 3) {                                    // batched small-block Jacobi kernel on this one block
+            if (n < 2 || n > 64) throw std::invalid_argument("mode 3: 2 <= n <= 64");
+            proxsdp::DevBuf<long long> off(1); proxsdp::DevBuf<int> side(1), rk(2);
+            const long long o0 = 0; const int s0 = (int)n;
+            off.upload(&o0, 1, S.stream); side.upload(&s0, 1, S.stream);
+            const size_t lds = ((size_t)2 * n * (n | 1) + 64) * sizeof(double) + 64 * sizeof(int);
+            if (lds > 48 * 1024)
+                PX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(proxsdp::dev::k_small_psd_project),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(proxsdp::dev::k_small_psd_project, dim3(1), dim3(proxsdp::dev::TPB), lds, S.stream,
+                               x.p, (const long long*)off.p, (const int*)side.p, o.tol_psd, rk.p, rk.p + 1);
+            int hr[2] = {0, 0};
+            rk.download(hr, 2, S.stream);
+            x.download(packed_out, N, S.stream);
+            PX_HIP(hipStreamSynchronize(S.stream));
+            if (out_rank) *out_rank = hr[0];
+            if (out_min_eig) *out_min_eig = 0.0;
+            if (out_nmatvec) *out_nmatvec = 0;
+            if (out_converged) *out_converged = hr[1];
+            if (out_fell_back) *out_fell_back = 0;
+            return 0;
+        }
         S.test_project(0, x.p, target_rank);
         x.download(packed_out, N, S.stream);
         PX_HIP(hipStreamSynchronize(S.stream));

@@ -1075,6 +1075,129 @@ k_reconstruct_mfma(const double* __restrict__ Z, int ldz, const double* __restri
     }
 }
 
+// ---------------------------------------------------------------------------
+// Batched projection of SMALL PSD blocks (2 <= n <= 64): full_eig! (prox_operators.jl:111-126) for
+// every block in ONE launch, one workgroup per block.  The reference (and the large-block path here)
+// calls a dense eigensolver per block per iteration -- on multi-block SDPLIB models (truss, control,
+// arch, qap: tens to hundreds of blocks of side 2..20) that is a serial chain of tiny LAPACK / rocSOLVER
+// calls.  Here: the block is unpacked into LDS, diagonalised by a parallel-order cyclic Jacobi
+// (n/2 disjoint rotations per round, round-robin schedule, eigenvectors accumulated; stops when
+// off(A)^2 <= 1e-32 |diag|^2), and X+ = sum over lambda_k > 0 of lambda_k v_k v_k' is written back in
+// packed form.  Jacobi's eigenpairs are accurate to a few ulp, as dsyevr's are.
+// out: rank[b] = #{lambda > tol_psd} (current_rank), npos[b] = #{lambda > 0}.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(TPB)
+k_small_psd_project(double* __restrict__ x, const long long* __restrict__ offs, const int* __restrict__ sides,
+                    double tol_psd, int* __restrict__ rank_out, int* __restrict__ npos_out) {
+    extern __shared__ __attribute__((aligned(16))) double sj_mem[];
+    __shared__ double s_red[NWAVE];
+    __shared__ int s_cnt[2];
+    const int n = sides[blockIdx.x];
+    double* __restrict__ xp = x + offs[blockIdx.x];
+    const int ld = n | 1;                              // odd stride: conflict-free row and column walks
+    double* A = sj_mem;                                // n x ld
+    double* V = A + n * ld;                            // n x ld
+    double* cs = V + n * ld;                           // c[i], s[i] of the round's pairs (2 x 32)
+    int* pq = (int*)(cs + 64);                         // p[i], q[i]
+    const int tid = threadIdx.x;
+    for (int t = tid; t < n * n; t += TPB) {
+        const int i = t % n, j = t / n;
+        const int lo = min(i, j), hi = max(i, j);
+        const double v = xp[(long long)hi * (hi + 1) / 2 + lo];
+        A[i * ld + j] = (i == j) ? v : v * INV_SQRT2;
+        V[i * ld + j] = (i == j) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    const int m = n + (n & 1);                         // players of the round-robin (one dummy when n is odd)
+    const int np = m / 2;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        // convergence: off-diagonal mass against the diagonal
+        double off = 0.0, dg = 0.0;
+        for (int t = tid; t < n * n; t += TPB) {
+            const int i = t % n, j = t / n;
+            const double v = A[i * ld + j];
+            if (i == j) dg += v * v; else off += v * v;
+        }
+        const double offs_ = block_sum(off, s_red);
+        if (tid == 0) cs[0] = offs_;
+        __syncthreads();
+        const double dgs = block_sum(dg, s_red);
+        if (tid == 0) cs[1] = dgs;
+        __syncthreads();
+        if (cs[0] <= 1e-32 * cs[1] || cs[0] == 0.0) break;
+        __syncthreads();
+        for (int rd = 0; rd < m - 1; ++rd) {
+            // the round's disjoint pairs and their rotations
+            if (tid < np) {
+                int p, q;
+                if (tid == 0) { p = m - 1; q = rd; }
+                else { p = (rd + tid) % (m - 1); q = (rd - tid + (m - 1)) % (m - 1); }
+                if (p > q) { const int t = p; p = q; q = t; }
+                double c = 1.0, s = 0.0;
+                if (q < n) {
+                    const double apq = A[p * ld + q];
+                    if (apq != 0.0) {
+                        const double tau = (A[q * ld + q] - A[p * ld + p]) / (2.0 * apq);
+                        const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                        c = 1.0 / sqrt(1.0 + t * t);
+                        s = t * c;
+                    }
+                } else { q = -1; }
+                pq[tid] = p; pq[32 + tid] = q; cs[tid] = c; cs[32 + tid] = s;
+            }
+            __syncthreads();
+            // rows: A <- J' A
+            for (int t = tid; t < np * n; t += TPB) {
+                const int i = t / n, k = t - i * n;
+                const int p = pq[i], q = pq[32 + i];
+                if (q >= 0) {
+                    const double c = cs[i], s = cs[32 + i];
+                    const double ap = A[p * ld + k], aq = A[q * ld + k];
+                    A[p * ld + k] = c * ap - s * aq;
+                    A[q * ld + k] = s * ap + c * aq;
+                }
+            }
+            __syncthreads();
+            // columns: A <- A J, V <- V J
+            for (int t = tid; t < np * n; t += TPB) {
+                const int i = t / n, k = t - i * n;
+                const int p = pq[i], q = pq[32 + i];
+                if (q >= 0) {
+                    const double c = cs[i], s = cs[32 + i];
+                    const double ap = A[k * ld + p], aq = A[k * ld + q];
+                    A[k * ld + p] = c * ap - s * aq;
+                    A[k * ld + q] = s * ap + c * aq;
+                    const double vp = V[k * ld + p], vq = V[k * ld + q];
+                    V[k * ld + p] = c * vp - s * vq;
+                    V[k * ld + q] = s * vp + c * vq;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // eigenvalues on the diagonal; counts, then X+ in packed form
+    if (tid == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
+    __syncthreads();
+    if (tid < n) {
+        const double lamk = A[tid * ld + tid];
+        cs[tid] = lamk > 0.0 ? lamk : 0.0;
+        if (lamk > tol_psd) atomicAdd(&s_cnt[0], 1);
+        if (lamk > 0.0) atomicAdd(&s_cnt[1], 1);
+    }
+    __syncthreads();
+    const int N = n * (n + 1) / 2;
+    for (int t = tid; t < N; t += TPB) {
+        int j = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while ((j + 1) * (j + 2) / 2 <= t) ++j;
+        while (j * (j + 1) / 2 > t) --j;
+        const int i = t - j * (j + 1) / 2;
+        double acc = 0.0;
+        for (int k = 0; k < n; ++k) acc += cs[k] * V[i * ld + k] * V[j * ld + k];
+        xp[t] = (i == j) ? acc : acc * SQRT2;
+    }
+    if (tid == 0) { rank_out[blockIdx.x] = s_cnt[0]; npos_out[blockIdx.x] = s_cnt[1]; }
+}
+
 // packed svec -> dense column-major upper triangle (only for the full-eig
 // fallback, which hands the matrix to rocSOLVER): psd_vec_to_square :1-16
 __global__ void __launch_bounds__(TPB)

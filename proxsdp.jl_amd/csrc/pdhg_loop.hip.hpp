@@ -184,7 +184,34 @@ inline void Solver::psd_projection(double* x) {
                            x, one_off.p, (int)one_blocks.size(), one_min.p);
         for (int idx : one_blocks) current_rank[idx] = 0;
     }
-    run_blocks(big_blocks, [this, x](int idx) { project_block(idx, x, x, false); });
+    if (!small_blocks.empty()) {
+        project_small_blocks(x);
+        run_blocks(large_blocks, [this, x](int idx) { project_block(idx, x, x, false); });
+    } else {
+        run_blocks(big_blocks, [this, x](int idx) { project_block(idx, x, x, false); });
+    }
+}
+
+// all small PSD blocks in one launch (kernels.hip.hpp k_small_psd_project); ranks come back with the
+// iteration's next synchronisation (pinned buffer)
+inline void Solver::project_small_blocks(double* x) {
+    harvest_small_ranks();
+    const int nb = (int)small_blocks.size();
+    const int ld = small_maxn | 1;
+    const size_t lds = ((size_t)2 * small_maxn * ld + 64) * sizeof(double) + 64 * sizeof(int);
+    hipLaunchKernelGGL(dev::k_small_psd_project, dim3(nb), dim3(dev::TPB), lds, stream,
+                       x, (const long long*)small_off.p, (const int*)small_side.p, opt.tol_psd, small_rank.p, small_rank.p + nb);
+    PX_HIP(hipMemcpyAsync(small_rank_host.p, small_rank.p, (size_t)2 * nb * sizeof(int), hipMemcpyDeviceToHost, stream));
+    small_pending = true;
+    st.full_eigs += nb; st.batched_small_eigs += nb;
+    for (int idx : small_blocks) { current_rank[idx] = 0; min_eig[idx] = 0.0; }
+}
+// (called after a stream synchronisation has happened since the launch: every iteration ends with one)
+inline void Solver::harvest_small_ranks() {
+    if (!small_pending) return;
+    small_pending = false;
+    const int* r = reinterpret_cast<const int*>(small_rank_host.p);
+    for (size_t q = 0; q < small_blocks.size(); ++q) current_rank[small_blocks[q]] = r[q];
 }
 
 // primal_step! (pdhg.jl:611-637)
@@ -479,6 +506,7 @@ inline void Solver::cache_solution(const std::vector<double>& cvec) {
     }
     std::vector<double> deq, din, dcone;
     double dfeas = dual_feas_host(y, cvec, &deq, &din, &dcone);
+    harvest_small_ranks();
     long long fr = 0;
     for (long long r : current_rank) fr += r;
     if (sharded()) {                         // dual feasibility and rank over all shards
@@ -1052,6 +1080,11 @@ inline void Solver::run() {
             if (B.n == 1) { one_blocks.push_back((int)idx); offs.push_back(B.off); if (ur) ur += 1; continue; }
             EigWork& W = eig[idx];
             big_blocks.push_back((int)idx);
+            // side 2..64 and never on the Krylov path: batched Jacobi projection (dense vector path)
+            if (opt.small_block_batch != 0 && B.n <= 64 && B.n <= opt.min_size_krylov_eigs && !sharded())
+                small_blocks.push_back((int)idx);
+            else
+                large_blocks.push_back((int)idx);
             // Krylov workspace: the largest target rank the Krylov path may see, and room for
             // full_eig!-by-Lanczos (up to (MAXK - 4) / 2 = 94 pairs) on blocks that can take it
             int max_nev = std::min<int>(std::max<int>(opt.max_target_rank_krylov_eigs, 2), B.n);
@@ -1068,15 +1101,20 @@ inline void Solver::run() {
             for (int i = 0; i < B.n; ++i) W.resid_host[i] /= nr;
             W.resid.upload(W.resid_host.data(), W.npad, stream);
         }
+        if (small_blocks.size() < 2 && opt.small_block_batch < 0) {          // auto: a batch needs several blocks
+            large_blocks = big_blocks; small_blocks.clear();
+        }
         // several eigensolver-sized blocks: project them concurrently, one worker thread and one
         // stream per block (the per-block Lanczos chains are launch-latency-bound, so they overlap
         // almost perfectly: MIMO n=512 x 8 on one GPU).  PROXSDP_HIP_BLOCK_THREADS=0 disables.
         {
             const char* e = std::getenv("PROXSDP_HIP_BLOCK_THREADS");
             int nthreads = e ? atoi(e) : 8;
-            nthreads = std::min<int>(nthreads, (int)big_blocks.size());
+            // (blocks handled by the batched small-block kernel need no worker / stream of their own)
+            const std::vector<int>& pool_blocks = small_blocks.empty() ? big_blocks : large_blocks;
+            nthreads = std::min<int>(nthreads, (int)pool_blocks.size());
             if (nthreads >= 2) {
-                for (int idx : big_blocks) {
+                for (int idx : pool_blocks) {
                     PX_HIP(hipStreamCreate(&eig[idx].stream));
                     PX_HIP(hipEventCreateWithFlags(&eig[idx].done, hipEventDisableTiming));
                 }
@@ -1085,6 +1123,18 @@ inline void Solver::run() {
                 start_workers(nthreads);
                 parallel_blocks = true;
             }
+        }
+        if (!small_blocks.empty()) {
+            std::vector<long long> so; std::vector<int> ss;
+            for (int idx : small_blocks) { so.push_back(P.blocks[idx].off); ss.push_back(P.blocks[idx].n); small_maxn = std::max(small_maxn, P.blocks[idx].n); }
+            small_off.alloc(so.size()); small_side.alloc(ss.size()); small_rank.alloc(2 * ss.size());
+            small_off.upload(so.data(), so.size(), stream); small_side.upload(ss.data(), ss.size(), stream);
+            small_rank_host.alloc(ss.size() + 1);
+            const size_t lds = ((size_t)2 * small_maxn * (small_maxn | 1) + 64) * sizeof(double) + 64 * sizeof(int);
+            if (lds > 48 * 1024)
+                PX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_small_psd_project),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            PX_HIP(hipStreamSynchronize(stream));
         }
         if (!offs.empty()) {
             one_off.alloc(offs.size()); one_min.alloc(offs.size());

@@ -302,6 +302,15 @@ private:
     int xc = 0, mtyc = 0, yc = 0, mxc = 0;     // index of the "current" buffer of each ping-pong pair
     std::vector<int> one_blocks;               // indices of 1x1 PSD blocks
     std::vector<int> big_blocks;               // indices of the blocks that are projected by an eigensolver
+    // blocks of side 2..64 below min_size_krylov_eigs: one batched Jacobi launch on the dense vector path
+    std::vector<int> small_blocks, large_blocks;
+    DevBuf<long long> small_off;
+    DevBuf<int> small_side, small_rank;        // small_rank: [rank | npos] per block
+    PinnedBuf small_rank_host;
+    int small_maxn = 0;
+    bool small_pending = false;
+    void project_small_blocks(double* x);
+    void harvest_small_ranks();
     std::vector<double> hscal;
     bool csr_wave = false;
     int rotate_lds_cap = 60 * 1024;           // dynamic LDS granted to k_lz_rotate (setup_device)
@@ -1054,7 +1063,9 @@ inline void Solver::stop_workers() {
 // up, otherwise in sequence on the solver's stream.  Returns after all host work is done and
 // the solver's stream has been made to wait for the block streams.
 inline void Solver::run_blocks(const std::vector<int>& blocks, const std::function<void(int)>& job) {
-    if (!parallel_blocks || blocks.size() < 2) {
+    bool have_streams = true;
+    for (int idx : blocks) have_streams = have_streams && eig[idx].stream != nullptr;
+    if (!parallel_blocks || blocks.size() < 2 || !have_streams) {
         for (int idx : blocks) job(idx);
         merge_block_stats();
         return;
