@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PROXSDP_HIP_ABI_VERSION 3
+#define PROXSDP_HIP_ABI_VERSION 4
 
 /* error codes (negative return values) */
 #define PROXSDP_E_INVALID  (-1)   /* invalid argument / inconsistent problem data */
@@ -111,6 +111,22 @@ typedef struct proxsdp_problem {
     const double* M_dense;
     int32_t M_dense_on_device;
     int32_t reserved1;
+    /* optional, block-sharded solves only: COUPLING ROWS -- rows of [A;G] with entries in the variables
+     * of more than one shard.  Every shard lists the same n_coupling rows (its own
+     * 0-BASED row numbers, whatever index_base: 0..p-1 equalities, p..p+m-1 inequalities; a shard without entries in such a row still
+     * carries it, empty, with the same right-hand side) in the SAME order.  Per iteration the library
+     * hands the shard's partial (M x) of these rows to
+     *     reduce_vec_fn(reduce_ctx, buf, n_coupling, on_device)
+     * which must replace buf[] by the element-wise SUM over all shards (one RCCL all-reduce on a
+     * device buffer when reduce_vec_on_device = 1, host memory otherwise) and return 0 after the
+     * result is in place.  coupling_owned[k] = 1 on exactly ONE shard per row: that shard counts
+     * the row in the scalar sums (b'y, |y+ - y|^2, ...), the others skip it. */
+    int64_t n_coupling;
+    const int64_t* coupling_rows;
+    const int32_t* coupling_owned;
+    int (*reduce_vec_fn)(void* ctx, double* buf, int64_t len, int32_t on_device);
+    int32_t reduce_vec_on_device;
+    int32_t reserved2;
 } proxsdp_problem;
 
 /* Options (options.jl:1-132): same names, same defaults (proxsdp_hip_default_options).

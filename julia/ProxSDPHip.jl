@@ -51,6 +51,12 @@ struct Problem                   # proxsdp_problem
     M_dense::Ptr{Float64}        # optional dense A (row-major p x n); C_NULL = use the CSC A
     M_dense_on_device::Int32
     reserved1::Int32
+    n_coupling::Int64            # coupling rows of a block-sharded solve (0 otherwise)
+    coupling_rows::Ptr{Int64}
+    coupling_owned::Ptr{Int32}
+    reduce_vec_fn::Ptr{Cvoid}
+    reduce_vec_on_device::Int32
+    reserved2::Int32
 end
 
 struct Stats                     # proxsdp_stats

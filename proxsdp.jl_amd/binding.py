@@ -53,10 +53,13 @@ class Problem(C.Structure):
                 ("n_soc", i64), ("soc_ptr", pi64), ("soc_idx", pi64),
                 ("index_base", i32), ("reserved0", i32), ("eig_resid", pf64),
                 ("reduce_ctx", C.c_void_p), ("reduce_fn", C.c_void_p),
-                ("M_dense", C.c_void_p), ("M_dense_on_device", i32), ("reserved1", i32)]
+                ("M_dense", C.c_void_p), ("M_dense_on_device", i32), ("reserved1", i32),
+                ("n_coupling", i64), ("coupling_rows", pi64), ("coupling_owned", C.POINTER(i32)),
+                ("reduce_vec_fn", C.c_void_p), ("reduce_vec_on_device", i32), ("reserved2", i32)]
 
 
 REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, pf64, i32, pf64, i32)
+REDUCE_VEC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, i64, i32)
 
 
 def _opt_fields():
@@ -184,7 +187,7 @@ def lib():
     L.proxsdp_host_symeig.argtypes = [i32, pf64, pf64]
     L.proxsdp_host_start_vector.argtypes = [i64, i64, i32, pf64]
     L.proxsdp_host_preprocess.argtypes = [C.POINTER(Problem), pi64, pi64, pf64, pf64]
-    if L.proxsdp_hip_abi_version() != 3:
+    if L.proxsdp_hip_abi_version() != 4:
         raise ProxSDPHipError(-1, "ABI version mismatch")
     _lib = L
     return L
@@ -306,12 +309,15 @@ class SolveResult:
         return [dict(zip(TRACE_NAMES, row)) for row in self.trace]
 
 
-def solve(prob, options=None, eig_resid=None, trace_capacity=0, reduce=None):
+def solve(prob, options=None, eig_resid=None, trace_capacity=0, reduce=None, coupling=None):
     """proxsdp_hip_solve: replaces chambolle_pock(aff, con, options) (MOI_wrapper.jl:310).
     Returns the minimisation objective; sign/constant fix-up is the caller's
     (MOI_wrapper.jl:336-337), see optimizer.Optimizer.
     reduce: optional callable(sums: np.ndarray, maxs: np.ndarray) -> None that all-reduces
-    the two arrays in place over the shards of a block-sharded solve (see sharded.py)."""
+    the two arrays in place over the shards of a block-sharded solve (see sharded.py).
+    coupling: optional dict(rows=int64 array of this shard's row numbers, owned=int32 0/1 array,
+    reduce_vec=callable(ptr: int, length: int, on_device: bool) -> None summing the buffer in place over
+    the shards, on_device=bool) -- the rows shared with other shards (proxsdp_problem.coupling_rows)."""
     L = lib()
     o = options if options is not None else default_options()
     if trace_capacity:
@@ -332,6 +338,26 @@ def solve(prob, options=None, eig_resid=None, trace_capacity=0, reduce=None):
         M.keep.append(cb)
         M.P.reduce_fn = C.cast(cb, C.c_void_p)
         M.P.reduce_ctx = None
+    if coupling is not None and len(coupling["rows"]) > 0:
+        rows = _i(coupling["rows"])                 # 0-based row numbers of [A;G], whatever index_base
+        owned = np.ascontiguousarray(coupling["owned"], dtype=np.int32)
+        rv = coupling["reduce_vec"]
+
+        def _cbv(ctx, ptr, length, on_device):
+            try:
+                rv(int(ptr), int(length), bool(on_device))
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+        cbv = REDUCE_VEC_FN(_cbv)
+        M.keep += [rows, owned, cbv]
+        M.P.n_coupling = len(rows)
+        M.P.coupling_rows = _p(rows, pi64)
+        M.P.coupling_owned = owned.ctypes.data_as(C.POINTER(i32))
+        M.P.reduce_vec_fn = C.cast(cbv, C.c_void_p)
+        M.P.reduce_vec_on_device = 1 if coupling.get("on_device") else 0
     n, p, m = M.P.n, M.P.p, M.P.m
     arrays = [np.zeros(max(k, 1)) for k in (n, n, p, m, p, m)]
     trace = np.zeros((max(o.trace_capacity, 1), TRACE_COLS))

@@ -1481,7 +1481,8 @@ struct TrialBatch {                 // up to 4 linesearch candidates per launch
 __global__ void __launch_bounds__(TPB)
 k_dual_trial_batch(const double* __restrict__ y, const double* __restrict__ Mx, const double* __restrict__ Mx_old,
                    const double* __restrict__ bh, int p, int Q, TrialBatch tb,
-                   double* __restrict__ ycand, long long ystride, double* __restrict__ part, long long cstride) {
+                   double* __restrict__ ycand, long long ystride, double* __restrict__ part, long long cstride,
+                   const double* __restrict__ roww = nullptr) {
     __shared__ double sm[NWAVE];
     const int c = blockIdx.y;
     const double bt = tb.bt[c], theta = tb.theta[c];
@@ -1494,7 +1495,8 @@ k_dual_trial_batch(const double* __restrict__ y, const double* __restrict__ Mx, 
         const double yn = ybar - bt * proj;
         yout[i] = yn;
         const double d = yn - yi;
-        ss += d * d;
+        // roww: 0 for a coupling row another shard accounts for (block-sharded solve), else 1
+        ss += (roww != nullptr ? roww[i] : 1.0) * (d * d);
     }
     const double tot = block_sum(ss, sm);
     if (threadIdx.x == 0) part[(long long)c * cstride + blockIdx.x] = tot;
@@ -1556,7 +1558,8 @@ __device__ __forceinline__ void
 residual_y_body(const double* __restrict__ ycand, long long ystride, const double* __restrict__ yold,
                 const double* __restrict__ Mx, const double* __restrict__ Mx_old,
                 const double* __restrict__ bh, int p, int Q, const TrialBatch& tb,
-                double* __restrict__ part, int pstride, long long cstride, int gx, double* __restrict__ sm) {
+                double* __restrict__ part, int pstride, long long cstride, int gx, double* __restrict__ sm,
+                const double* __restrict__ roww) {
     if ((int)blockIdx.x >= gx) return;
     const int c = blockIdx.y;
     const double sigma = tb.sigma[c];
@@ -1568,8 +1571,9 @@ residual_y_body(const double* __restrict__ ycand, long long ystride, const doubl
         const double pnew = yi - sigma * mx;
         m0 = fmax(m0, fabs(pnew - pold));
         m1 = fmax(m1, fabs(pold));
-        if (i < p) { m2 = fmax(m2, fabs(mx - rhs)); s4 += rhs * yi; }
-        else       { m3 = fmax(m3, mx - rhs);       s5 += rhs * yi; }
+        const double wgt = roww != nullptr ? roww[i] : 1.0;
+        if (i < p) { m2 = fmax(m2, fabs(mx - rhs)); s4 += wgt * (rhs * yi); }
+        else       { m3 = fmax(m3, mx - rhs);       s5 += wgt * (rhs * yi); }
     }
     const double r0 = block_max(m0, sm), r1 = block_max(m1, sm), r2 = block_max(m2, sm), r3 = block_max(m3, sm);
     const double r4 = block_sum(s4, sm), r5 = block_sum(s5, sm);
@@ -1591,14 +1595,15 @@ k_residual_xy_batch(const double* __restrict__ xnew, const int* __restrict__ sup
                     const double* __restrict__ ycand, long long ystride, const double* __restrict__ yold,
                     const double* __restrict__ Mx, const double* __restrict__ Mx_old,
                     const double* __restrict__ bh, int p, int Q, int gq,
-                    TrialBatch tb, double* __restrict__ part, int pstride, long long cstride) {
+                    TrialBatch tb, double* __restrict__ part, int pstride, long long cstride,
+                    const double* __restrict__ roww = nullptr) {
     __shared__ double sm[NWAVE];
     if (blockIdx.z == 0)
         residual_xS_body(xnew, supp, ns, xsave, xold_coef, MtyScand, mstride, MtyS_old, cS, tb,
                          part + 2 * (long long)pstride, pstride, cstride, gs, sm);
     else
         residual_y_body(ycand, ystride, yold, Mx, Mx_old, bh, p, Q, tb,
-                        part + 5 * (long long)pstride, pstride, cstride, gq, sm);
+                        part + 5 * (long long)pstride, pstride, cstride, gq, sm, roww);
 }
 
 // non-PSD tail of x (SOC + free variables): x_new = x_trial copied to the other buffer,
@@ -1840,6 +1845,18 @@ k_combine_multi(const double* __restrict__ part, int stride, int cnt, unsigned l
     }
     const double r = mx ? block_max(a, sm) : block_sum(a, sm);
     if (threadIdx.x == 0) out[q] = r;
+}
+
+// coupling rows of a block-sharded solve: buf[k] = v[rows[k]] and back
+__global__ void __launch_bounds__(TPB)
+k_gather_rows(const double* __restrict__ v, const int* __restrict__ rows, int cnt, double* __restrict__ buf) {
+    const int k = blockIdx.x * TPB + threadIdx.x;
+    if (k < cnt) buf[k] = v[rows[k]];
+}
+__global__ void __launch_bounds__(TPB)
+k_scatter_rows(double* __restrict__ v, const int* __restrict__ rows, int cnt, const double* __restrict__ buf) {
+    const int k = blockIdx.x * TPB + threadIdx.x;
+    if (k < cnt) v[rows[k]] = buf[k];
 }
 
 // v .*= d (removing the equilibration at the exit path, pdhg.jl:751-755)

@@ -46,6 +46,26 @@ inline void Solver::setup_long_rows(const std::vector<int>& rp) {
     PX_HIP(hipStreamSynchronize(stream));
 }
 
+// block-sharded solve: the coupling rows of M x hold this shard's partial sums; all-reduce them
+// (RCCL on the device buffer, or through host memory) -- SURVEY.md section 8e
+inline void Solver::reduce_coupling(double* Mx_dev) {
+    const int nc = (int)coup_rows.size();
+    hipLaunchKernelGGL(dev::k_gather_rows, dim3(ceil_div(nc, dev::TPB)), dim3(dev::TPB), 0, stream,
+                       (const double*)Mx_dev, (const int*)coup_rows_d.p, nc, coup_buf_d.p);
+    if (reduce_vec_on_device) {
+        PX_HIP(hipStreamSynchronize(stream));               // the collective runs on the caller's stream
+        if (reduce_vec_fn(reduce_ctx, coup_buf_d.p, nc, 1) != 0) throw std::runtime_error("reduce_vec_fn failed");
+    } else {
+        coup_host.resize(nc);
+        coup_buf_d.download(coup_host.data(), nc, stream);
+        PX_HIP(hipStreamSynchronize(stream));
+        reduce_vec_host(coup_host);
+        coup_buf_d.upload(coup_host.data(), nc, stream);
+    }
+    hipLaunchKernelGGL(dev::k_scatter_rows, dim3(ceil_div(nc, dev::TPB)), dim3(dev::TPB), 0, stream,
+                       Mx_dev, (const int*)coup_rows_d.p, nc, (const double*)coup_buf_d.p);
+}
+
 // psd_projection! (prox_operators.jl:33-66), one block: reads the packed block of xin,
 // writes the projected block into xout (xin == xout on the dense path)
 inline void Solver::project_block(int idx, const double* xin, double* xout, bool fuse) {
@@ -232,6 +252,7 @@ inline void Solver::primal_step_dev() {
                                xcur, xnew, (long long)P.sdplen, (long long)P.n, mask_d.p,
                                respart_d.p + tile_base.back(), rstride);
         spmv(xnew, Mxbuf[1 - mxc].p);
+        if (!coup_rows.empty()) reduce_coupling(Mxbuf[1 - mxc].p);
         return;
     }
     const double* xi = xbuf[xc].p;
@@ -503,6 +524,12 @@ inline void Solver::cache_solution(const std::vector<double>& cvec) {
     for (int64_t k = 0; k < P.n; ++k) {
         const double xk = x[k];
         for (int64_t q = P.colptr[k]; q < P.colptr[k + 1]; ++q) slack[P.rowidx[q]] += P.val_orig[q] * xk;
+    }
+    if (!coup_rows.empty()) {                                 // M x of a coupling row: sum of the shards' partials
+        std::vector<double> part_(coup_rows.size());
+        for (size_t k = 0; k < coup_rows.size(); ++k) part_[k] = slack[coup_rows[k]];
+        reduce_vec_host(part_);
+        for (size_t k = 0; k < coup_rows.size(); ++k) slack[coup_rows[k]] = part_[k];
     }
     std::vector<double> deq, din, dcone;
     double dfeas = dual_feas_host(y, cvec, &deq, &din, &dcone);
@@ -881,7 +908,7 @@ inline int Solver::linesearch_residual_support() {
         tb.nc = nc;
         hipLaunchKernelGGL(dev::k_dual_trial_batch, dim3(gq, nc), dim3(dev::TPB), 0, stream,
                            ybuf[yc].p, Mxbuf[1 - mxc].p, Mxbuf[mxc].p, bh_d.p, (int)P.p, (int)P.Q, tb,
-                           ycand_d.p, ystride, bpart.p, cstride);
+                           ycand_d.p, ystride, bpart.p, cstride, (const double*)roww_d.p);
         hipLaunchKernelGGL(dev::k_spmvT_S_batch, dim3(gs, nc), dim3(dev::TPB), 0, stream,
                            csc_ptr.p, csc_row.p, csc_val.p, supp_d.p, ns, ycand_d.p, ystride,
                            MtyS_cand.p, mstride, MtyS_cur.p, bpart.p + PSTRIDE, cstride);
@@ -889,7 +916,7 @@ inline int Solver::linesearch_residual_support() {
                            xbuf[1 - xc].p, supp_d.p, ns, xsave_d.p, xold_coef, MtyS_cand.p, mstride, MtyS_cur.p,
                            cS_d.p, gs,
                            ycand_d.p, ystride, ybuf[yc].p, Mxbuf[1 - mxc].p, Mxbuf[mxc].p, bh_d.p, (int)P.p, (int)P.Q, gq,
-                           tb, bpart.p, PSTRIDE, cstride);
+                           tb, bpart.p, PSTRIDE, cstride, (const double*)roww_d.p);
         // per candidate: q0,q1 sums | q2,q3 max, q4 sum | q5..q8 max, q9,q10 sum
         unsigned long long ismax = 0;
         for (int c = 0; c < nc; ++c) ismax |= 0x1ECull << (11 * c);      // bits 2,3,5,6,7,8
@@ -923,7 +950,7 @@ inline int Solver::linesearch_residual_support() {
                                        xbuf[1 - xc].p, supp_d.p, ns, xsave_d.p, xold_coef,
                                        MtyS_cand.p + (size_t)c * mstride, mstride, MtyS_cur.p, cS_d.p, gs,
                                        ycand_d.p + (size_t)c * ystride, ystride, ybuf[yc].p, Mxbuf[1 - mxc].p, Mxbuf[mxc].p,
-                                       bh_d.p, (int)P.p, (int)P.Q, gq, t1, bpart.p, PSTRIDE, cstride);
+                                       bh_d.p, (int)P.p, (int)P.Q, gq, t1, bpart.p, PSTRIDE, cstride, (const double*)roww_d.p);
                     hipLaunchKernelGGL(dev::k_combine_multi, dim3(11 + 2), dim3(dev::TPB), 0, stream,
                                        (const double*)bpart.p, PSTRIDE, std::max(gq, gs), 0x1ECull, bscal.p, 11,
                                        (const double*)respart_d.p, rstride, n_res_wg, bscal.p + NC * 11);
@@ -1012,7 +1039,14 @@ inline void Solver::run() {
         target_rank[idx] = std::min<long long>(std::max(opt.initial_target_rank, 1), P.blocks[idx].n);
     time_limit = opt.time_limit;
     {   // global constants (sums over shards of a block-sharded solve; local values otherwise)
-        std::vector<double> sums = {(double)P.n, (double)P.p, (double)P.m, P.norm_b * P.norm_b, P.norm_h * P.norm_h,
+        double pw = (double)P.p, mw = (double)P.m, nb2 = P.norm_b * P.norm_b, nh2 = P.norm_h * P.norm_h;
+        for (size_t k = 0; k < coup_rows.size(); ++k) {          // a coupling row counts on its owner only
+            if (coup_owned[k]) continue;
+            const int r = coup_rows[k];
+            if (r < P.p) { pw -= 1.0; nb2 -= P.b_orig[r] * P.b_orig[r]; }
+            else { mw -= 1.0; nh2 -= P.h_orig[r - P.p] * P.h_orig[r - P.p]; }
+        }
+        std::vector<double> sums = {(double)P.n, pw, mw, std::max(nb2, 0.0), std::max(nh2, 0.0),
                                     P.norm_c * P.norm_c, P.frob * P.frob};
         std::vector<double> maxs = {(nb > 0 || !P.socs.empty()) ? 1.0 : 0.0};
         reduce(sums, maxs);
@@ -1052,6 +1086,14 @@ inline void Solver::run() {
         std::copy(P.b.begin(), P.b.end(), bh.begin());
         std::copy(P.h.begin(), P.h.end(), bh.begin() + P.p);
         bh_d.upload(bh.data(), P.Q, stream);
+        PX_HIP(hipStreamSynchronize(stream));
+    }
+    if (!coup_rows.empty()) {
+        coup_rows_d.alloc(coup_rows.size()); coup_buf_d.alloc(coup_rows.size()); roww_d.alloc(std::max<int64_t>(P.Q, 1));
+        std::vector<double> rw(P.Q, 1.0);
+        for (size_t k = 0; k < coup_rows.size(); ++k) if (!coup_owned[k]) rw[coup_rows[k]] = 0.0;
+        coup_rows_d.upload(coup_rows.data(), coup_rows.size(), stream);
+        roww_d.upload(rw.data(), P.Q, stream);
         PX_HIP(hipStreamSynchronize(stream));
     }
     part.alloc((size_t)NQ * PSTRIDE); part.zero(stream);

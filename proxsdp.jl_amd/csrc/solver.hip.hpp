@@ -200,6 +200,18 @@ public:
         user_resid = prob.eig_resid;
         reduce_fn = prob.reduce_fn;
         reduce_ctx = prob.reduce_ctx;
+        if (prob.n_coupling > 0) {
+            if (!prob.reduce_fn || !prob.reduce_vec_fn || !prob.coupling_rows || !prob.coupling_owned)
+                throw std::invalid_argument("coupling rows need reduce_fn, reduce_vec_fn, coupling_rows and coupling_owned");
+            reduce_vec_fn = prob.reduce_vec_fn;
+            reduce_vec_on_device = prob.reduce_vec_on_device != 0;
+            for (int64_t k = 0; k < prob.n_coupling; ++k) {
+                const int64_t r = prob.coupling_rows[k];
+                if (r < 0 || r >= prob.p + prob.m) throw std::invalid_argument("coupling row out of range");
+                coup_rows.push_back((int)r);
+                coup_owned.push_back(prob.coupling_owned[k] != 0);
+            }
+        }
     }
     // engine-only instance for the kernel-level test entry points (no problem data)
     Solver(const proxsdp_options& opt_in, proxsdp_result& res_out) : opt(opt_in), res(res_out) {
@@ -262,6 +274,19 @@ public:
     int (*reduce_fn)(void*, double*, int32_t, double*, int32_t) = nullptr;
     void* reduce_ctx = nullptr;
     bool sharded() const { return reduce_fn != nullptr; }
+    // coupling rows of a block-sharded solve (include/proxsdp_hip.h): partial M x summed over the shards
+    int (*reduce_vec_fn)(void*, double*, int64_t, int32_t) = nullptr;
+    bool reduce_vec_on_device = false;
+    std::vector<int> coup_rows;
+    std::vector<char> coup_owned;
+    DevBuf<int> coup_rows_d;
+    DevBuf<double> coup_buf_d, roww_d;
+    std::vector<double> coup_host;
+    void reduce_coupling(double* Mx_dev);          // Mx[coupling rows] <- sum over shards
+    void reduce_vec_host(std::vector<double>& v) {
+        if (v.empty()) return;
+        if (reduce_vec_fn(reduce_ctx, v.data(), (int64_t)v.size(), 0) != 0) throw std::runtime_error("reduce_vec_fn failed");
+    }
     void reduce(std::vector<double>& sums, std::vector<double>& maxs) {
         if (!reduce_fn) return;
         if (reduce_fn(reduce_ctx, sums.data(), (int32_t)sums.size(), maxs.data(), (int32_t)maxs.size()) != 0)

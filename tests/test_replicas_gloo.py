@@ -59,12 +59,21 @@ def test_split_block_diagonal():
     assert (s0.A != a.A).nnz == 0 and (s0.G != a.G).nnz == 0 and np.array_equal(s0.c, a.c)
     assert (s1.A != b.A).nnz == 0 and np.array_equal(s1.b, b.b) and s1.G.shape[0] == 0
     assert np.array_equal(np.sort(np.concatenate([m0["vars"], m1["vars"]])), np.arange(pr.n))
-    # a row coupling the two blocks is rejected
+    assert m0["coupling"] is None and m1["coupling"] is None
+    # a row coupling the two blocks: rejected on request, otherwise carried by BOTH shards (each with
+    # its own columns), listed in `coupling`, owned by the lowest shard that touches it
     import scipy.sparse as sp
-    bad = problems.Problem(n=pr.n, A=sp.vstack([pr.A, sp.csr_matrix(([1.0, 1.0], ([0, 0], [0, pr.n - 1])), shape=(1, pr.n))]).tocsc(),
-                           b=np.append(pr.b, 0.0), G=pr.G, h=pr.h, c=pr.c, psd=pr.psd)
+    cp = problems.Problem(n=pr.n, A=sp.vstack([pr.A, sp.csr_matrix(([1.0, 2.0], ([0, 0], [0, pr.n - 1])), shape=(1, pr.n))]).tocsc(),
+                          b=np.append(pr.b, 7.0), G=pr.G, h=pr.h, c=pr.c, psd=pr.psd)
     with pytest.raises(ValueError):
-        sharded.split_block_diagonal(bad, [0, 1], 0)
+        sharded.split_block_diagonal(cp, [0, 1], 0, allow_coupling=False)
+    c0, k0 = sharded.split_block_diagonal(cp, [0, 1], 0)
+    c1, k1 = sharded.split_block_diagonal(cp, [0, 1], 1)
+    assert c0.A.shape[0] == a.A.shape[0] + 1 and c1.A.shape[0] == b.A.shape[0] + 1
+    assert np.array_equal(k0["coupling"]["rows"], [a.A.shape[0]]) and np.array_equal(k1["coupling"]["rows"], [b.A.shape[0]])
+    assert k0["coupling"]["owned"].tolist() == [1] and k1["coupling"]["owned"].tolist() == [0]
+    assert c0.b[-1] == 7.0 and c1.b[-1] == 7.0
+    assert c0.A[-1].nnz == 1 and c0.A[-1, 0] == 1.0 and c1.A[-1].nnz == 1 and c1.A[-1, c1.n - 1] == 2.0
 
 
 def _reduce_worker(rank, world, port, q):
@@ -76,7 +85,11 @@ def _reduce_worker(rank, world, port, q):
     red = sharded.make_reduce(dist)
     sums = np.array([1.0 + rank, 10.0]); maxs = np.array([float(rank), -1.0 - rank, 5.0])
     red(sums, maxs)
-    q.put((rank, sums.tolist(), maxs.tolist()))
+    # the coupling-row all-reduce on a host buffer (gloo path of proxsdp_problem.reduce_vec_fn)
+    redv = sharded.make_reduce_vec(dist)
+    buf = np.array([1.0 + rank, 2.0, -3.0 * rank])
+    redv(buf.ctypes.data, len(buf), False)
+    q.put((rank, sums.tolist(), maxs.tolist(), buf.tolist()))
     dist.destroy_process_group()
 
 
@@ -91,5 +104,37 @@ def test_sharded_reduce_two_ranks():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, sums, maxs in out:
+    for rank, sums, maxs, buf in out:
         assert sums == [3.0, 20.0] and maxs == [1.0, -1.0, 5.0]
+        assert buf == [3.0, 4.0, -3.0]
+
+
+def _fail_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from proxsdp_jl_amd import problems, sharded
+    dist = replicas.init("gloo", rank, world)
+    pr = problems.maxcut(5, seed=2)                     # ONE block for two ranks
+    try:
+        sharded.solve_sharded(pr, dist, rank, world)
+        q.put((rank, "no error"))
+    except ValueError as e:
+        q.put((rank, "ValueError"))
+    except RuntimeError as e:
+        q.put((rank, "RuntimeError"))
+    dist.destroy_process_group()
+
+
+def test_sharded_solve_fails_on_every_rank_together():
+    """more ranks than PSD blocks: every rank raises before any solve collective (no deadlock)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 90)
+    procs = [ctx.Process(target=_fail_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(o[1] in ("ValueError", "RuntimeError") for o in out)
