@@ -1023,8 +1023,24 @@ k_reconstruct_mfma(const double* __restrict__ Z, int ldz, const double* __restri
     v4f64 acc[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[b] = (v4f64){0.0, 0.0, 0.0, 0.0};
-    // the old iterate / mask of the FUSE_RES epilogue are requested by the epilogue itself (the MFMA
-    // loop leaves no registers idle for them at r >= 12; below that the scalar kernel is used)
+    // FUSE_RES: the old iterate and the support mask of this lane's 16 output entries are requested
+    // first, so that the 8 N bytes of x_old stream in under the MFMA loop (a load per entry inside the
+    // store loop made the kernel latency-bound: 73 us instead of 39 at r = 63)
+    double xo[16];
+    unsigned mk[16];
+    if (FUSE_RES) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int gjc = min(J * TILE + w * 16 + l4 + 4 * reg, n - 1);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int gic = min(I * TILE + b * 16 + l15, gjc);
+                const long long idxc = (long long)gjc * (gjc + 1) / 2 + gic;      // always a valid entry
+                xo[reg * 4 + b] = xold[idxc];
+                mk[reg * 4 + b] = mask[(mask_off + idxc) >> 5];
+            }
+        }
+    }
     fetch(0);
     stash(0);
     __syncthreads();
@@ -1059,10 +1075,10 @@ k_reconstruct_mfma(const double* __restrict__ Z, int ldz, const double* __restri
                 const long long idx = (long long)gj * (gj + 1) / 2 + gi;
                 const double xn = ((gi == gj) ? 1.0 : SQRT2) * acc[b][reg];
                 if (FUSE_RES) {
-                    const double xo = xold[idx];
+                    const double xov = xo[reg * 4 + b];
                     const long long gidx = mask_off + idx;
-                    const bool on = (mask[gidx >> 5] >> (gidx & 31)) & 1u;
-                    if (!on) { m0 = fmax(m0, fabs(xn - xo)); m1 = fmax(m1, fabs(xo)); }
+                    const bool on = (mk[reg * 4 + b] >> (gidx & 31)) & 1u;
+                    if (!on) { m0 = fmax(m0, fabs(xn - xov)); m1 = fmax(m1, fabs(xov)); }
                 }
                 xp[idx] = xn;
             }

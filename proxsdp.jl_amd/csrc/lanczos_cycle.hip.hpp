@@ -232,6 +232,7 @@ k_lz_cycle(CycleArgs a) {
     const bool timing = a.dbg != nullptr;
     long long tk[6] = {0, 0, 0, 0, 0, 0};
     long long t0 = timing ? wall_clock64() : 0;
+    const long long wc0 = t0, sc0 = timing ? clock64() : 0;
 #define CY_TICK(q) if (timing) { const long long t1 = wall_clock64(); tk[q] += t1 - t0; t0 = t1; }
 
     for (int k = kfirst; k <= kd; ++k) {
@@ -442,7 +443,10 @@ k_lz_cycle(CycleArgs a) {
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         atomicOr((unsigned long long*)(a.dbg + 7), 1ull << (xcc & 15));
-        if (g == 0) for (int q = 0; q < 6; ++q) atomicAdd((unsigned long long*)(a.dbg + q), (unsigned long long)tk[q]);
+        if (g == 0) {
+            tk[4] = wall_clock64() - wc0; tk[5] = clock64() - sc0;      // shader cycles per 10 ns tick -> clock
+            for (int q = 0; q < 6; ++q) atomicAdd((unsigned long long*)(a.dbg + q), (unsigned long long)tk[q]);
+        }
     }
     // ---- write back the new basis columns and the scalars
     // columns kfirst+1 .. lastcol were created in this cycle (column kstop does not exist when stopped)

@@ -1446,7 +1446,8 @@ inline void Solver::run() {
         std::fprintf(stderr, "[cycle ticks/step @100MHz] close+opA %.1f X1 %.1f phaseB %.1f X2 %.1f | %.1f %.1f (steps %lld)\n",
                      (double)t[0] / st.cycle_steps, (double)t[1] / st.cycle_steps, (double)t[2] / st.cycle_steps,
                      (double)t[3] / st.cycle_steps, (double)t[4] / st.cycle_steps, (double)t[5] / st.cycle_steps, (long long)st.cycle_steps);
-        std::fprintf(stderr, "[cycle] XCC id mask of the active workgroups: 0x%llx\n", (unsigned long long)t[7]);
+        std::fprintf(stderr, "[cycle] XCC id mask of the active workgroups: 0x%llx; shader clock during the cycles: %.0f MHz\n",
+                     (unsigned long long)t[7], t[4] > 0 ? 100.0 * (double)t[5] / (double)t[4] : 0.0);
     }
     st.loop_time = now_s() - t_loop0;
     if (warm.joinable()) warm.join();

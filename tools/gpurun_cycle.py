@@ -9,7 +9,7 @@ iters = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 extra = json.loads(sys.argv[3]) if len(sys.argv) > 3 else {}
 pr = problems.maxcut(n, seed=0)
 res = {}
-for cy in ((0, 1) if len(sys.argv) < 5 else (1,)):
+for cy in ((0, 1) if len(sys.argv) < 5 else (int(sys.argv[4]) if sys.argv[4].isdigit() else 1,)):
     o = Optimizer(max_iter=iters, lanczos_cycle_kernel=cy, support_path=1, profile_symv_every=16, **extra)
     s = o.optimize(pr, trace_capacity=iters)
     st = s.stats
@@ -21,7 +21,7 @@ for cy in ((0, 1) if len(sys.argv) < 5 else (1,)):
                           restarts=int(st["lanczos_restarts"]), cycle_launches=int(st["cycle_launches"]),
                           cycle_steps=int(st["cycle_steps"]), cycle_us_per_step=1e3 * st["cycle_ms"] / max(1, st["cycle_steps"]),
                           fop=int(st["fop_projections"]), obj=float(t[-1, 1]), host_eig_s=st["host_eig_time"])))
-if 0 not in res: sys.exit(0)
+if 0 not in res or 1 not in res: sys.exit(0)
 a, b = res[0], res[1]
 m = min(len(a), len(b))
 for col, nm in ((1, "prim_obj"), (2, "dual_obj"), (7, "step"), (13, "matvecs"), (11, "trials")):
