@@ -63,7 +63,7 @@ def main():
                     help="max_target_rank_krylov_eigs for the time-to-tol leg (metric: rank ~ sqrt(n))")
     ap.add_argument("--profile-every", type=int, default=16)
     ap.add_argument("--support-path", type=int, default=-1, help="-1 auto, 0 dense vector passes, 1 support-aware")
-    ap.add_argument("--workload", choices=["maxcut", "mimo", "randsdp"], default="maxcut",
+    ap.add_argument("--workload", choices=["maxcut", "mimo", "randsdp", "sdplib"], default="maxcut",
                     help="maxcut: the metric's instance, replicas for N>1; mimo: BASELINE config 4, a block-diagonal "
                          "model of --blocks MIMO n=512 instances, PSD blocks sharded over the ranks; randsdp: BASELINE "
                          "config 3, dense equality rows generated in HBM (--rand-n 2000 --rand-m 4000 = 64 GB)")
@@ -107,6 +107,8 @@ def main():
         return bench_mimo(args, torch, dist, rank, world, dev_id, backend)
     if args.workload == "randsdp":
         return bench_randsdp(args, torch, dist, rank, world, dev_id, backend)
+    if args.workload == "sdplib":
+        return bench_sdplib(args, torch, dist, rank, world, dev_id, backend)
     n = args.n
     K, W = args.steps, args.warmup
     pr = problems.maxcut(n, seed=replicas.replica_seed(args.seed, rank))
@@ -404,6 +406,59 @@ def bench_randsdp(args, torch, dist, rank, world, dev_id, backend):
                          "bytes_per_launch": bytes_pass, "avg_launch_ms": pass_ms,
                          "launches": int(st["dense_passes"])},
             "generate_s": t_gen, "solve_wall_s": wall, "init_s": st["init_time"], "exit_s": st["exit_time"]}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def bench_sdplib(args, torch, dist, rank, world, dev_id, backend):
+    """BASELINE config 5: SDPLIB maxG51 / gpp500-1 (test/base_sdplib.jl model) on the FULL-RANK
+    fallback eig path, full_eig_decomp = true: every iteration is full_eig! (prox_operators.jl:111-126) =
+    dense eigensolver (rocSOLVER dsyevd) + rank-r+ reconstruction (fp64 MFMA SYRK, r+ ~ n/2 early on).
+    Single PSD block: replicas for N > 1.  value = iterations/s of maxG51; gpp500-1 beside it."""
+    from proxsdp_jl_amd import problems, replicas
+    from proxsdp_jl_amd.optimizer import Optimizer
+    K, W = args.steps, args.warmup
+    gold = os.path.join(ROOT, "tests", "golden", "sdplib")
+
+    def leg(fname):
+        pr = problems.sdplib(os.path.join(gold, fname + ".dat-s"))
+        n = pr.psd_sides()[0]
+        N = n * (n + 1) // 2
+        opt = Optimizer(max_iter=W + K, device_id=dev_id, full_eig_decomp=1, profile_symv_every=1)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        sol = opt.optimize(pr, trace_capacity=W + K)
+        torch.cuda.synchronize()
+        tr, st = sol.trace, sol.stats
+        if len(tr) < W + K:
+            raise SystemExit(f"{fname}: solve stopped after {len(tr)} iterations")
+        t = float(tr[W + K - 1, 12] - (tr[W - 1, 12] if W > 0 else 0.0))
+        its = max(1, int(sol.iter))
+        eig_ms, rec_ms = st["full_eig_solver_ms"] / its, st["full_eig_recon_ms"] / its
+        rplus = int(sol.final_rank)
+        flops = (10.0 / 3.0) * n ** 3
+        return {"instance": fname, "n": n, "value": K / t, "unit": "iterations/s", "ms_per_step": 1e3 * t / K,
+                "dense_eigensolver_ms_per_step": eig_ms, "reconstruction_ms_per_step": rec_ms,
+                "dense_eigensolver_share": eig_ms / (1e3 * t / K), "full_eigs": int(st["full_eigs"]),
+                "positive_eigenvalues_last": rplus, "mfma_reconstructions": int(st["mfma_reconstructions"]),
+                "roofline": {"bound": "mfma", "kernel": "rocsolver_dsyevd (library) -- (10/3) n^3 flops (SURVEY 8d F_iter)",
+                             "achieved": flops / (eig_ms * 1e-3) / 1e12 if eig_ms > 0 else None, "peak": 78.6,
+                             "unit": "TFLOP/s", "frac": flops / (eig_ms * 1e-3) / 1e12 / 78.6 if eig_ms > 0 else None,
+                             "traffic": None}}, K, t
+
+    a, k1, t1 = leg("maxG51")
+    b, _, _ = leg("gpp500-1")
+    total_steps, t_steps = replicas.aggregate(dist, k1, t1, device="cuda" if dist is not None else "cpu")
+    if rank == 0:
+        print(json.dumps({
+            "metric": "PDHG iterations/sec, SDPLIB maxG51 (n=1000) on the full-rank fallback eig path (full_eig_decomp=true)",
+            "value": total_steps / t_steps, "unit": "iterations/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": 1e3 * t_steps / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "SDPLIB files (tests/golden/sdplib)",
+            "config": {"workload": "SDPLIB maxG51 / gpp500-1, reference harness model (one merged PSD block), "
+                                   "full_eig_decomp=true", "parallelism": "replicas x%d" % world},
+            "roofline": a["roofline"], "maxG51": a, "gpp500-1": b}))
     if dist is not None:
         dist.destroy_process_group()
 

@@ -206,7 +206,9 @@ typedef struct proxsdp_options {
                                   * Krylov space, not what is converged (krylovkit_tol). */
     int32_t reconstruct_mfma;    /* rank-r reconstruction V Lam+ V': -1 auto, 0 scalar-FMA kernel, 1 fp64 MFMA
                                   * (v_mfma_f64_16x16x4_f64) kernel */
-    int32_t small_block_batch;   /* -1 auto, 0 off: project all PSD blocks of side <= 32 in one batched Jacobi launch */
+    int32_t small_block_batch;   /* project the small PSD blocks in ONE batched Jacobi launch instead of one dense
+                                  * eigensolver call each: -1 auto (>= 2 blocks of side 2..32), 1 = every block of side
+                                  * 2..64, 0 off */
     int32_t pad7;
 } proxsdp_options;
 
