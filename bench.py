@@ -234,6 +234,10 @@ def main():
         out["time_to_tol"] = tol_leg(time_limit=300.0, max_target_rank_krylov_eigs=args.krylov_rank)
         if args.default_time_limit > 0:
             out["time_to_tol_default_options"] = tol_leg(time_limit=args.default_time_limit)
+        # library-only knob: every projection's Lanczos starts from the previous projection's Ritz vectors
+        # instead of the reference's fixed start vector (same krylovkit_tol, fewer restarts)
+        out["time_to_tol_warm_start"] = tol_leg(time_limit=300.0, max_target_rank_krylov_eigs=args.krylov_rank,
+                                                lanczos_warm_start=1)
 
     if solo and not args.no_cpu:
         import oracle                                           # baseline leg only

@@ -252,7 +252,7 @@ typedef struct proxsdp_stats {
     int64_t full_eigs_lanczos;   /* full_eig! calls served by the Lanczos engine (all positive pairs) */
     int64_t cycle_steps;         /* Lanczos steps run inside those launches                       */
     double  cycle_ms;            /* their summed kernel time (events; profile_symv_every > 0)     */
-    double  reserved_d[1];
+    int64_t warm_starts;         /* projections started from the previous Ritz vectors (lanczos_warm_start) */
 } proxsdp_stats;
 
 /* Result (structs.jl:60-81).  Arrays are caller-allocated with the stated

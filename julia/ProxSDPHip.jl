@@ -95,7 +95,7 @@ struct Stats                     # proxsdp_stats
     full_eigs_lanczos::Int64
     cycle_steps::Int64
     cycle_ms::Float64
-    reserved_d::NTuple{1,Float64}
+    warm_starts::Int64
 end
 
 mutable struct CResult           # proxsdp_result

@@ -123,7 +123,7 @@ class Stats(C.Structure):
                 ("host_eig_time", f64), ("host_eigs", i64), ("device_eigs", i64), ("batched_small_eigs", i64),
                 ("mfma_reconstructions", i64), ("orth_profiled", i64), ("orth_profiled_ms", f64),
                 ("full_eig_solver_ms", f64), ("full_eig_recon_ms", f64), ("cycle_launches", i64),
-                ("full_eigs_lanczos", i64), ("cycle_steps", i64), ("cycle_ms", f64), ("reserved_d", f64 * 1)]
+                ("full_eigs_lanczos", i64), ("cycle_steps", i64), ("cycle_ms", f64), ("warm_starts", i64)]
 
 
 class Result(C.Structure):

@@ -338,6 +338,33 @@ k_lz_begin(double* __restrict__ V0, const double* __restrict__ resid, int npad, 
     if (i == 0) { ctl->stop = 0; ctl->kstop = 0; ctl->carry = 0.0; }
 }
 
+// library-only warm start (options.lanczos_warm_start): the start vector of a projection is the sum
+// of the previous projection's Ritz vectors plus 1e-3 x the fixed start vector (so that the Krylov
+// space still reaches directions the previous factors do not span), normalised.  Two launches:
+// rows + per-workgroup sums of squares, then every workgroup adds the partials in the same order.
+__global__ void __launch_bounds__(TPB)
+k_lz_warm_sum(double* __restrict__ V0, const double* __restrict__ F, int ldf, int rp, const double* __restrict__ resid,
+              int npad, double* __restrict__ part) {
+    __shared__ double sm[NWAVE];
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    double v = 0.0;
+    if (i < npad) {
+        for (int c = 0; c < rp; ++c) v += F[(long long)c * ldf + i];
+        v += 1e-3 * resid[i];
+        V0[i] = v;
+    }
+    const double tot = block_sum(v * v, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(TPB)
+k_lz_warm_scale(double* __restrict__ V0, int npad, const double* __restrict__ part, int nparts, LanczosCtl* __restrict__ ctl) {
+    double ss = 0.0;
+    for (int q = 0; q < nparts; ++q) ss += part[q];               // same order in every thread
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i < npad) V0[i] = V0[i] / sqrt(ss);
+    if (i == 0) { ctl->stop = 0; ctl->kstop = 0; ctl->carry = 0.0; }
+}
+
 // y = smat(xp) v from the mat-vec partial slots (test seam / residual checks):
 // w = (sum of slots) / sqrt2, fixed order.
 __global__ void __launch_bounds__(TPB)

@@ -841,6 +841,7 @@ inline void Solver::setup_support() {
             W.xg2.alloc((size_t)32 * (dev::CY_CMAX + 128)); W.xg2.zero(stream);           // + the R rows of w'
             W.xf1.alloc(32); W.xf1.zero(stream); W.xf2.alloc(32); W.xf2.zero(stream);     // flags: zero = never-valid epoch
             W.cy_err.alloc(1); W.cy_err.zero(stream);
+            W.warm_part.alloc(ceil_div(W.npad, dev::TPB)); W.warm_part.zero(stream);
             PX_HIP(hipStreamSynchronize(stream));                 // host vectors go out of scope
             W.fop_ok = true;
         }

@@ -171,7 +171,7 @@ struct EigWork {
     bool use_fop = false;                          // the projection in progress uses the operator form
     int last_npos = -1;                            // positive eigenvalues found by the last full_eig! of this block
     // persistent Lanczos cycle kernel (lanczos_cycle.hip.hpp): granule buffers, epoch counter, error word
-    DevBuf<double> xg1, xg2;
+    DevBuf<double> xg1, xg2, warm_part;
     DevBuf<unsigned> xf1, xf2;
     DevBuf<int> cy_err;
     PinnedBuf cy_err_host;                         // pinned mirror of cy_err (first 4 bytes)
@@ -740,6 +740,17 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive
     if (arpack && (!(0 < nev && nev < W.n) || krylovdim > W.n)) return;   // dsaupd info=-1/-3 -> error -> fallback
 
     const double step_tol = arpack ? 0.0 : tol;       // invariant-subspace test inside the recurrence
+    if (opt.lanczos_warm_start != 0 && !positive_part && W.fop_ok && W.have_factors && W.F_r > 0 && W.tpart.n > 0) {
+        // start from the previous projection's Ritz vectors (library-only knob; the reference starts
+        // every projection from the same fixed vector, krylovkit_reset_resid = false)
+        const int nb = ceil_div(W.npad, dev::TPB);
+        hipLaunchKernelGGL(dev::k_lz_warm_sum, dim3(nb), dim3(dev::TPB), 0, stream,
+                           W.V.p, (const double*)(W.F.p + (size_t)W.F_first * W.npad), W.npad, W.F_r,
+                           (const double*)W.resid.p, W.npad, W.warm_part.p);
+        hipLaunchKernelGGL(dev::k_lz_warm_scale, dim3(nb), dim3(dev::TPB), 0, stream,
+                           W.V.p, W.npad, (const double*)W.warm_part.p, nb, W.ctl_p);
+        W.lst.warm_starts++;
+    } else
     hipLaunchKernelGGL(dev::k_lz_begin, dim3(ceil_div(W.npad, dev::TPB)), dim3(dev::TPB), 0, stream,
                        W.V.p, (const double*)W.resid.p, W.npad, W.ctl_p);
 
@@ -1121,7 +1132,7 @@ inline void Solver::merge_block_stats() {
         st.symv_profiled += a.symv_profiled; st.symv_profiled_ms += a.symv_profiled_ms;
         st.orth_profiled += a.orth_profiled; st.orth_profiled_ms += a.orth_profiled_ms;
         st.full_eig_solver_ms += a.full_eig_solver_ms; st.full_eig_recon_ms += a.full_eig_recon_ms;
-        st.full_eigs_lanczos += a.full_eigs_lanczos; st.device_eigs += a.device_eigs; st.mfma_reconstructions += a.mfma_reconstructions; st.cycle_launches += a.cycle_launches;
+        st.full_eigs_lanczos += a.full_eigs_lanczos; st.warm_starts += a.warm_starts; st.device_eigs += a.device_eigs; st.mfma_reconstructions += a.mfma_reconstructions; st.cycle_launches += a.cycle_launches;
         st.cycle_steps += a.cycle_steps; st.cycle_ms += a.cycle_ms;
         st.symv_bytes += a.symv_bytes; st.host_eig_time += a.host_eig_time; st.host_eigs += a.host_eigs;
         st.fop_projections += a.fop_projections;

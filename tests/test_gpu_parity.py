@@ -860,6 +860,25 @@ def test_batched_small_block_projection_against_lapack(n):
         assert info["rank"] == int((w > 1e-7).sum())
 
 
+def test_warm_start_knob_reaches_the_same_optimum_with_fewer_restarts():
+    """lanczos_warm_start = 1 (library-only): start vector = normalised sum of the previous projection's Ritz
+    vectors + 1e-3 x the fixed vector.  Eigenpairs are still converged to krylovkit_tol, so the iterates
+    agree until rounding-level differences grow; the solve converges to the same objective (1e-4, the
+    north-star criterion) with fewer Lanczos restarts."""
+    pr = P.maxcut(600, seed=4)
+    a = Optimizer(support_path=1)
+    sa = a.optimize(pr, trace_capacity=400)
+    b = Optimizer(support_path=1, lanczos_warm_start=1)
+    sb = b.optimize(pr, trace_capacity=400)
+    print("default", sa.iter, a.objective_value(), sa.stats["lanczos_restarts"], sa.stats["lanczos_matvecs"],
+          "| warm", sb.iter, b.objective_value(), sb.stats["lanczos_restarts"], sb.stats["lanczos_matvecs"], sb.stats["warm_starts"])
+    assert sa.status == sb.status == 1
+    assert abs(a.objective_value() - b.objective_value()) <= 1e-4 * (1 + abs(a.objective_value()))
+    assert sb.stats["warm_starts"] > 0 and sa.stats["warm_starts"] == 0
+    assert sb.stats["lanczos_matvecs"] < sa.stats["lanczos_matvecs"]
+    assert np.allclose(sa.trace[:40, 1], sb.trace[:40, 1], rtol=1e-6, atol=1e-9)
+
+
 def _trace_cols(ref_trace):
     return np.array([[t["prim_obj"], t["dual_obj"], t["gap"], t["feas"], t["primal_step"], t["trials"]]
                      for t in ref_trace])
