@@ -137,7 +137,7 @@ int proxsdp_hip_psd_project(const double* packed_in, int64_t n, int32_t target_r
         // mode 2: full_eig! served by the Lanczos engine, `target_rank` = the estimate of the number of
         // positive eigenvalues (in a solve: the count of the block's previous projection)
         if (mode == 2) { o.full_eig_decomp = 1; o.full_eig_lanczos = 1; o.min_size_krylov_eigs = 0; }
-        const int ws = mode == 2 ? std::min<int>({(int)n, (proxsdp::dev::MAXK - 4) / 2, 2 * (target_rank + std::max(3, target_rank / 8)) + 2}) : target_rank;
+        const int ws = mode == 2 ? std::min<int>({(int)n, 94, 2 * (target_rank + std::max(3, target_rank / 8)) + 2}) : target_rank;
         Engine E(&o, n, ws);
         E.set_resid(resid);
         proxsdp::Solver& S = E.S;

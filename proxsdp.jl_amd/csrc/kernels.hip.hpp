@@ -320,8 +320,9 @@ k_symv_packed(const double* __restrict__ xp, int n, int nt, int npad,
 // L2-resident basis), so the point of the layout is parallel width and loads in flight,
 // not bytes.
 // ---------------------------------------------------------------------------
-constexpr int MAXK = 192;           // capacity of the Krylov basis (krylovdim+1 < MAXK - 1; the step kernels hold
-                                    // 16*NCH <= 48 basis columns per wave in registers, 4 waves)
+constexpr int MAXK = 260;           // capacity of the Krylov basis (krylovdim + 1 <= 256: the step kernels hold
+                                    // 16*NCH <= 64 basis columns per wave in registers, 4 waves, and map
+                                    // thread j <-> basis column j) => target rank <= 127
 constexpr int LZ_ROWS = TILE;       // rows per workgroup in the Lanczos vector kernels
 constexpr int NRM_SLOT = MAXK - 1;  // slot of a partial-dots row that carries |w'|^2
 
@@ -1888,6 +1889,17 @@ k_combine_multi(const double* __restrict__ part, int stride, int cnt, unsigned l
     }
     const double r = mx ? block_max(a, sm) : block_sum(a, sm);
     if (threadIdx.x == 0) out[q] = r;
+}
+
+// the accepted linesearch candidate becomes the iterate: y <- y_c and (M'y)|S <- (M'y_c)|S in ONE launch
+// (two device-to-device copies cost two runtime copy kernels, 4.2 us each, per iteration)
+__global__ void __launch_bounds__(TPB)
+k_copy2(double* __restrict__ d1, const double* __restrict__ s1, long long n1,
+        double* __restrict__ d2, const double* __restrict__ s2, long long n2) {
+    const long long stride = (long long)gridDim.x * TPB;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n1 + n2; i += stride) {
+        if (i < n1) d1[i] = s1[i]; else d2[i - n1] = s2[i - n1];
+    }
 }
 
 // coupling rows of a block-sharded solve: buf[k] = v[rows[k]] and back

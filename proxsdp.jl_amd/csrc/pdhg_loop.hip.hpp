@@ -960,11 +960,10 @@ inline int Solver::linesearch_residual_support() {
                     reduce_candidates(1);
                     s_acc = hbscal.data();
                 }
-                // y <- y_c, Mty <- Mty_c
-                PX_HIP(hipMemcpyAsync(ybuf[1 - yc].p, ycand_d.p + (size_t)c * ystride, (size_t)P.Q * 8,
-                                      hipMemcpyDeviceToDevice, stream));
-                PX_HIP(hipMemcpyAsync(MtyS_cur.p, MtyS_cand.p + (size_t)c * mstride, (size_t)ns * 8,
-                                      hipMemcpyDeviceToDevice, stream));
+                // y <- y_c, Mty <- Mty_c  (one launch)
+                hipLaunchKernelGGL(dev::k_copy2, dim3(grid_for((long long)P.Q + ns)), dim3(dev::TPB), 0, stream,
+                                   ybuf[1 - yc].p, (const double*)(ycand_d.p + (size_t)c * ystride), (long long)P.Q,
+                                   MtyS_cur.p, (const double*)(MtyS_cand.p + (size_t)c * mstride), (long long)ns);
                 break;
             }
             primal_step = tb.tau[c] * opt.linsearch_decay;
@@ -1132,10 +1131,10 @@ inline void Solver::run() {
             else
                 large_blocks.push_back((int)idx);
             // Krylov workspace: the largest target rank the Krylov path may see, and room for
-            // full_eig!-by-Lanczos (up to (MAXK - 4) / 2 = 94 pairs) on blocks that can take it
+            // full_eig!-by-Lanczos (up to 94 pairs) on blocks that can take it
             int max_nev = std::min<int>(std::max<int>(opt.max_target_rank_krylov_eigs, 2), B.n);
             if (opt.full_eig_lanczos != 0 && B.n > opt.min_size_krylov_eigs && B.n >= 400)
-                max_nev = std::max(max_nev, std::min((dev::MAXK - 4) / 2, B.n / 4));
+                max_nev = std::max(max_nev, std::min(94, B.n / 4));
             alloc_eigwork(W, B.n, max_nev);
             W.resid_host.resize(W.npad, 0.0);
             if (ur) { std::copy(ur, ur + B.n, W.resid_host.begin()); ur += B.n; }

@@ -424,8 +424,8 @@ inline void Solver::alloc_eigwork(EigWork& W, int n, int max_nev) {
     W.nwg = ceil_div(n, dev::TPB);
     int kd = std::max(2 * max_nev + 1, (int)opt.eigsolver_min_lanczos);
     W.cap = kd + 1;
-    if (W.cap >= dev::NRM_SLOT)
-        throw std::invalid_argument("krylov dimension exceeds the library limit (raise dev::MAXK)");
+    if (W.cap > 256)
+        throw std::invalid_argument("krylov dimension exceeds the library limit (krylovdim <= 255, i.e. target rank <= 127)");
     W.V.alloc((size_t)W.npad * W.cap);
     W.Z.alloc((size_t)W.npad * W.cap);
     W.w.alloc(W.npad);
@@ -631,9 +631,9 @@ inline void Solver::launch_symv_finish(EigWork& W, const double* xp, int kclose,
     }
     hipEvent_t e0 = prof ? W.ev.e0[slot] : nullptr, e1 = prof ? W.ev.e1[slot] : nullptr;
     if (W.use_fop) {
-        const int nchf = (kclose + 1 <= 64) ? 1 : (kclose + 1 <= 128) ? 2 : 3;
-        auto kern = (W.F_r <= 64) ? (nchf == 1 ? dev::k_fop_finish<1, 1> : nchf == 2 ? dev::k_fop_finish<1, 2> : dev::k_fop_finish<1, 3>)
-                                  : (nchf == 1 ? dev::k_fop_finish<2, 1> : nchf == 2 ? dev::k_fop_finish<2, 2> : dev::k_fop_finish<2, 3>);
+        const int nchf = (kclose + 1 <= 64) ? 1 : (kclose + 1 <= 128) ? 2 : (kclose + 1 <= 192) ? 3 : 4;
+        auto kern = (W.F_r <= 64) ? (nchf == 1 ? dev::k_fop_finish<1, 1> : nchf == 2 ? dev::k_fop_finish<1, 2> : nchf == 3 ? dev::k_fop_finish<1, 3> : dev::k_fop_finish<1, 4>)
+                                  : (nchf == 1 ? dev::k_fop_finish<2, 1> : nchf == 2 ? dev::k_fop_finish<2, 2> : nchf == 3 ? dev::k_fop_finish<2, 3> : dev::k_fop_finish<2, 4>);
         launch_prof(prof, e0, e1, kern, dim3(2 * W.nt), stream,
                     (const double*)W.w.p, W.V.p, W.npad, kclose, (const double*)lz_hpart(W, kclose), W.pld,
                     (const double*)W.hsum1.p, W.alphas_p, W.betas_p, W.ctl_p, tol, use_carry ? 1 : 0, W.nt,
@@ -641,8 +641,8 @@ inline void Solver::launch_symv_finish(EigWork& W, const double* xp, int kclose,
                     (const int*)W.ell_col.p, (const int*)W.ell_sidx.p, W.ell_w, W.npad, W.esv, W.tpart.p, W.ebuf.p,
                     W.apartf.p, W.hred.p, W.ov);
     } else {
-        const int nchf = (kclose + 1 <= 64) ? 1 : (kclose + 1 <= 128) ? 2 : 3;
-        auto ksf = nchf == 1 ? dev::k_symv_finish<1> : nchf == 2 ? dev::k_symv_finish<2> : dev::k_symv_finish<3>;
+        const int nchf = (kclose + 1 <= 64) ? 1 : (kclose + 1 <= 128) ? 2 : (kclose + 1 <= 192) ? 3 : 4;
+        auto ksf = nchf == 1 ? dev::k_symv_finish<1> : nchf == 2 ? dev::k_symv_finish<2> : nchf == 3 ? dev::k_symv_finish<3> : dev::k_symv_finish<4>;
         launch_prof(prof, e0, e1, ksf, dim3(W.nt + ntile), stream,
                     xp, W.n, W.nt, W.npad, W.Ppart.p, (const double*)W.w.p, W.V.p, W.npad, kclose,
                     (const double*)lz_hpart(W, kclose), W.pld, (const double*)W.hsum1.p, W.alphas_p, W.betas_p, W.ctl_p,
@@ -788,7 +788,7 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive
                 fo.Vp = W.F.p + (size_t)W.F_first * W.npad; fo.lam = W.Flam.p; fo.rp = W.F_r;
                 fo.tpart = W.tpart.p; fo.ebuf = W.ebuf.p; fo.apart = W.apartf.p;
             }
-            const int nch = (k + 1 <= 64) ? 1 : (k + 1 <= 128) ? 2 : 3;
+            const int nch = (k + 1 <= 64) ? 1 : (k + 1 <= 128) ? 2 : (k + 1 <= 192) ? 3 : 4;
             const int nchp = !W.use_fop ? 0 : (W.F_r <= 64 ? 1 : 2);
             const bool prof_o = opt.profile_symv_every > 0 && (W.lst.symv_launches % opt.profile_symv_every) == 1;
             size_t oslot = 0;
@@ -818,10 +818,13 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive
                 case 8: launch_orth(dev::k_lz_orth<2, 2>); break;
                 case 9: launch_orth(dev::k_lz_orth<3, 0>); break;
                 case 10: launch_orth(dev::k_lz_orth<3, 1>); break;
-                default: launch_orth(dev::k_lz_orth<3, 2>); break;
+                case 11: launch_orth(dev::k_lz_orth<3, 2>); break;
+                case 12: launch_orth(dev::k_lz_orth<4, 0>); break;
+                case 13: launch_orth(dev::k_lz_orth<4, 1>); break;
+                default: launch_orth(dev::k_lz_orth<4, 2>); break;
             }
         }
-        auto klf = (krylovdim <= 64) ? dev::k_lz_finish<1> : (krylovdim <= 128) ? dev::k_lz_finish<2> : dev::k_lz_finish<3>;
+        auto klf = (krylovdim <= 64) ? dev::k_lz_finish<1> : (krylovdim <= 128) ? dev::k_lz_finish<2> : (krylovdim <= 192) ? dev::k_lz_finish<3> : dev::k_lz_finish<4>;
         hipLaunchKernelGGL(klf, dim3(W.nt), dim3(dev::TPB), 0, stream,
                            W.w.p, W.n, W.V.p, W.npad, krylovdim - 1, lz_hpart(W, krylovdim - 1), W.pld, W.hsum1.p,
                            W.alphas_p, W.betas_p, W.ctl_p, step_tol, (krylovdim - 1 > kfirst) ? 1 : 0, W.hred.p);

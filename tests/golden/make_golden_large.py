@@ -11,6 +11,7 @@ Run from the repo root:  python tests/golden/make_golden_large.py [trace4000] [s
 The inputs are regenerated from the seed by the tests through the same generator
 (proxsdp_jl_amd.problems.maxcut)."""
 import json
+import os
 import pathlib
 import sys
 import time
@@ -34,7 +35,7 @@ def rows_of(r):
 def trace4000():
     pr = P.maxcut(4000, seed=0)
     o = Options()
-    o.max_iter = 30
+    o.max_iter = int(os.environ.get("TRACE4000_ITERS", "30"))
     mv = []
 
     def cb(it, xin, xout, p, arc):

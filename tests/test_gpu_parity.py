@@ -155,6 +155,10 @@ def test_vector_kernels_against_oracle_functions():
     (257, 4, [90.0, 60.0, 33.0, 12.0, 5.0]),
     (300, 12, [50, 40, 30, 20, 10, 9, 8, 7, 6.5, 6, 5.5, 5.2]),
     (1000, 3, [500.0, 20.0, 19.5, 19.0]),
+    # Krylov basis beyond 128 and 192 columns (NCH = 3 / 4 step kernels): nev = 80 -> krylovdim 161,
+    # nev = 120 -> krylovdim 241 (the library's limit is krylovdim 255, target rank 127 = sqrt(16000))
+    (600, 80, list(np.linspace(400.0, 40.0, 84))),
+    (1000, 120, list(np.linspace(900.0, 60.0, 124))),
 ])
 def test_lanczos_matches_oracle_and_dense(n, nev, top):
     x = planted_packed(n, 11, top, bulk=(-5.0, 1.0))
