@@ -368,6 +368,11 @@ int proxsdp_hip_residuals(const double* x, const double* x_old, const double* Mt
  * overwritten by eigenvectors; d ascending) -- the K x K Rayleigh quotient of
  * the thick-restart Lanczos */
 int proxsdp_host_symeig(int32_t k, double* a, double* d);
+/* the same with the helper threads of the eigenvector accumulation chosen explicitly: 0 = serial,
+ * t > 0 = at least t helper threads,
+ * -1 = the library's choice (helpers from k >= 96 when PROXSDP_HIP_EIG_THREADS > 0; default 0: they were
+ * measured slower on the MI355X host).  Both give bit-identical results. */
+int proxsdp_host_symeig_threads(int32_t k, double* a, double* d, int32_t threads);
 /* eigen-decomposition of a thick-restarted Rayleigh quotient
  *   T = [diag(D) f 0; f' al[m] be[m] e1'; 0 be[m] e1 tridiag(al[m+1..], be[m+1..])]   (K x K)
  * through the two-phase path the Lanczos driver uses (arrow part reduced first, QL afterwards);

@@ -467,12 +467,13 @@ def spmv(M, x, transpose=False):
 
 
 # ----------------------------------------------------------------- host-only helpers (no GPU)
-def host_symeig(A):
+def host_symeig(A, threads=-1):
+    """threads: -1 the library's choice (helper threads from k >= 96), 0 serial -- bit-identical results"""
     L = lib()
     a = np.asfortranarray(A, dtype=np.float64).copy(order="F")
     k = a.shape[0]
     d = np.zeros(k)
-    _check(L.proxsdp_host_symeig(k, a.ctypes.data_as(pf64), _p(d)))
+    _check(L.proxsdp_host_symeig_threads(k, a.ctypes.data_as(pf64), _p(d), threads))
     return d, a
 
 

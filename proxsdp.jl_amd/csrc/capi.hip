@@ -382,8 +382,12 @@ int proxsdp_hip_residuals(const double* x, const double* x_old, const double* Mt
 }
 
 int proxsdp_host_symeig(int32_t k, double* a, double* d) {
+    return proxsdp_host_symeig_threads(k, a, d, -1);
+}
+
+int proxsdp_host_symeig_threads(int32_t k, double* a, double* d, int32_t threads) {
     if (k < 0 || !a || !d) { g_last_error = "invalid argument"; return PROXSDP_E_INVALID; }
-    int rc = proxsdp::symeig_dense(k, a, d);
+    int rc = proxsdp::symeig_dense(k, a, d, false, threads);
     if (rc != 0) { g_last_error = "QL iteration did not converge"; return PROXSDP_E_INTERNAL; }
     return 0;
 }

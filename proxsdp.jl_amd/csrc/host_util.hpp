@@ -12,12 +12,20 @@
 //  * option table     : name -> field map for RawOptimizerAttribute semantics
 //                       (/root/reference/src/MOI_wrapper.jl:84-103).
 #pragma once
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <cstddef>
+#include <mutex>
+#include <thread>
 #include <vector>
 #include <algorithm>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include "../../include/proxsdp_hip.h"
 
 namespace proxsdp {
@@ -128,10 +136,134 @@ inline void householder_tridiag(int n, double* a, double* d, double* e) {
     e[0] = 0.0;
 }
 
+// ---- helper threads for the eigenvector accumulation of large Rayleigh quotients -----------------
+// At K = 127 (target rank 63) one QL eigensolve is ~0.9 ms of which the scalar rotation recurrence
+// (sqrt / divide chain on d, e) is ~0.3 ms and applying the ~14 000 rotations to the K x K eigenvector
+// matrix the rest.  The recurrence never reads the eigenvector matrix, so the calling thread runs it
+// ALONE, logging every sweep's rotations, while a few helper threads replay the log on disjoint ROW
+// SLICES of the matrix (rows are independent under column rotations).  Every entry sees exactly the
+// arithmetic of the serial loop: bit-identical results.  Helpers sleep on a condition variable
+// between eigensolves and spin only while one is in flight.  PROXSDP_HIP_EIG_THREADS (default 0 =
+// serial; used from n >= 96).  MEASURED ON THE MI355X BOX (256 hardware threads, rank-63 window):
+// 2 / 4 / 8 helpers make the eigensolve 6-9x SLOWER (3.7-5.1 ms instead of 0.56 ms per iteration:
+// condition-variable wake-ups and cross-core traffic on 127-row columns), so the helpers are OFF
+// by default; the code is kept because it is bit-identical and may pay on hosts with cheap wake-ups.
+struct QlSweep { int lo, hi, off; };                     // rotations i = hi-1 .. lo, (c, s) at log[off + (hi-1-i)]
+struct QlJob {
+    int n = 0;
+    double* a = nullptr;
+    const QlSweep* sweeps = nullptr;
+    const double* cs = nullptr;                          // interleaved c, s
+    std::atomic<int> ready{0};                           // sweeps published so far
+    std::atomic<int> total{-1};                          // number of sweeps, once known
+    int parts = 1;                                       // row slices: 0 = the caller, 1.. = the helpers
+};
+inline void ql_replay(const QlJob& J, int r0, int r1) {
+    const int n = J.n;
+    double* a = J.a;
+    int done = 0;
+    for (;;) {
+        const int tot = J.total.load(std::memory_order_acquire);
+        int avail = J.ready.load(std::memory_order_acquire);
+        if (done >= avail) {
+            if (tot >= 0 && done >= tot) return;
+#if defined(__x86_64__)
+            _mm_pause();
+#endif
+            continue;
+        }
+        for (; done < avail; ++done) {
+            const QlSweep& S = J.sweeps[done];
+            const double* cs = J.cs + 2 * (size_t)S.off;
+            for (int i = S.hi - 1, q = 0; i >= S.lo; --i, ++q) {
+                const double c = cs[2 * q], s = cs[2 * q + 1];
+                double* __restrict__ ci = a + (size_t)i * n;
+                double* __restrict__ ci1 = a + (size_t)(i + 1) * n;
+                for (int k = r0; k < r1; ++k) {
+                    const double h = ci1[k];
+                    ci1[k] = s * ci[k] + c * h;
+                    ci[k] = c * ci[k] - s * h;
+                }
+            }
+        }
+    }
+}
+class QlPool {
+public:
+    static QlPool& get() { static QlPool p; return p; }
+    int helpers() const { return (int)th_.size(); }
+    // at least t helper threads (explicit request of a caller, e.g. the bit-identity test)
+    void ensure(int t) {
+        if (!busy_.try_lock()) return;
+        t = std::min(t, 16);
+        while ((int)th_.size() < t) { const int i = (int)th_.size(); th_.emplace_back([this, i]() { loop(i); }); }
+        busy_.unlock();
+    }
+    // run job J on the helpers (row slices 1..T of T+1; slice 0 is replayed by the caller afterwards)
+    bool start(QlJob* J) {
+        if (th_.empty() || !busy_.try_lock()) return false;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            J->parts = (int)th_.size() + 1;
+            job_ = J; ++gen_; pending_ = (int)th_.size();
+        }
+        cv_.notify_all();
+        return true;
+    }
+    void finish() {
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [this]() { return pending_ == 0; });
+        job_ = nullptr;
+        lk.unlock();
+        busy_.unlock();
+    }
+private:
+    QlPool() {
+        const char* e = std::getenv("PROXSDP_HIP_EIG_THREADS");
+        int t = e ? std::atoi(e) : 0;
+        const int hw = (int)std::thread::hardware_concurrency();
+        if (hw > 0) t = std::min(t, std::max(0, hw - 2));
+        t = std::max(0, std::min(t, 16));
+        for (int i = 0; i < t; ++i) th_.emplace_back([this, i]() { loop(i); });
+    }
+    ~QlPool() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : th_) if (t.joinable()) t.join();
+    }
+    void loop(int idx) {
+        long long seen = 0;
+        for (;;) {
+            QlJob* J;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&]() { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_; J = job_;
+            }
+            const int parts = J->parts, n = J->n;
+            const int r0 = (int)((long long)n * (idx + 1) / parts), r1 = (int)((long long)n * (idx + 2) / parts);
+            ql_replay(*J, r0, r1);
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (--pending_ == 0) done_cv_.notify_all();
+            }
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_, busy_;
+    std::condition_variable cv_, done_cv_;
+    QlJob* job_ = nullptr;
+    long long gen_ = 0;
+    int pending_ = 0;
+    bool stop_ = false;
+};
+
 // Phase 2: implicit-shift QL on the tridiagonal (d, e as left by phase 1), accumulating the
 // rotations into the n x n matrix a (which must hold the transform so far: Q, or the identity).
 // On exit columns of a are orthonormal eigenvectors, d ascending.  Returns 0, or 1 if QL failed.
-inline int ql_implicit(int n, double* a, double* d, double* e_in) {
+// threads: -1 = the pool's choice (helpers from n >= 96), 0 = serial.
+inline int ql_implicit(int n, double* a, double* d, double* e_in, int threads = -1) {
     auto V = [&](int i, int j) -> double& { return a[(size_t)j * n + i]; };
     std::vector<double> e(e_in, e_in + n);
     for (int i = 1; i < n; ++i) e[i - 1] = e[i];
@@ -139,6 +271,24 @@ inline int ql_implicit(int n, double* a, double* d, double* e_in) {
     double f = 0.0, tst1 = 0.0;
     const double eps = 2.220446049250313e-16;
     int rc = 0;
+    // ---- optional helpers: the recurrence below only logs its rotations
+    QlJob job;
+    static thread_local std::vector<QlSweep> sweeps;            // reused across calls (no 1 MB malloc per eigensolve)
+    static thread_local std::vector<double> cslog;
+    cslog.clear();
+    bool logged = false;
+    if (threads != 0 && n >= 96) {
+        QlPool& pool = QlPool::get();
+        if (threads > 0) pool.ensure(threads);
+        if (pool.helpers() > 0) {
+            if (sweeps.size() < (size_t)200 * n + 8) sweeps.resize((size_t)200 * n + 8);   // <= 200 QL iterations per eigenvalue
+            cslog.reserve((size_t)8 * n * n);                    // ~0.85 n^2 rotations expected (2 doubles each)
+            job.n = n; job.a = a; job.sweeps = sweeps.data();
+            logged = true;
+        }
+    }
+    int nsweep = 0;
+    bool started = false;
     for (int l = 0; l < n; ++l) {
         tst1 = std::max(tst1, std::fabs(d[l]) + std::fabs(e[l]));
         int m = l;
@@ -160,6 +310,13 @@ inline int ql_implicit(int n, double* a, double* d, double* e_in) {
                 f += h;
                 p = d[m];
                 double c = 1.0, c2 = c, c3 = c, el1 = e[l + 1], s = 0.0, s2 = 0.0;
+                const size_t off = cslog.size() / 2;
+                if (logged && cslog.size() + 2 * (size_t)(m - l) > cslog.capacity()) {
+                    // (never expected: 4 n^2 rotations reserved; finish serially if it happens)
+                    if (started) { job.total.store(nsweep, std::memory_order_release); ql_replay(job, 0, n / job.parts); QlPool::get().finish(); started = false; }
+                    else { job.total.store(nsweep, std::memory_order_release); ql_replay(job, 0, n); }
+                    logged = false;
+                }
                 for (int i = m - 1; i >= l; --i) {
                     c3 = c2; c2 = c; s2 = s;
                     g = c * e[i];
@@ -170,11 +327,26 @@ inline int ql_implicit(int n, double* a, double* d, double* e_in) {
                     c = p / r;
                     p = c * d[i] - s * g;
                     d[i + 1] = h + s * (c * g + s * d[i]);
-                    for (int k = 0; k < n; ++k) {
-                        h = V(k, i + 1);
-                        V(k, i + 1) = s * V(k, i) + c * h;
-                        V(k, i) = c * V(k, i) - s * h;
+                    if (logged) { cslog.push_back(c); cslog.push_back(s); }
+                    else {
+                        // (explicit no-alias column pointers: this loop must vectorise -- measured 2.2x on the
+                        // whole eigensolve at K = 127 against a version the compiler left scalar)
+                        double* __restrict__ ci = a + (size_t)i * n;
+                        double* __restrict__ ci1 = a + (size_t)(i + 1) * n;
+                        const double cc = c, ss = s;
+                        for (int k = 0; k < n; ++k) {
+                            const double hk = ci1[k];
+                            ci1[k] = ss * ci[k] + cc * hk;
+                            ci[k] = cc * ci[k] - ss * hk;
+                        }
                     }
+                }
+                if (logged) {
+                    sweeps[nsweep] = QlSweep{l, m, (int)off};
+                    ++nsweep;
+                    job.cs = cslog.data();                       // (capacity reserved: the pointer never moves)
+                    job.ready.store(nsweep, std::memory_order_release);
+                    if (!started) started = QlPool::get().start(&job);
                 }
                 p = -s * s2 * c3 * el1 * e[l] / dl1;
                 e[l] = s * p;
@@ -183,6 +355,15 @@ inline int ql_implicit(int n, double* a, double* d, double* e_in) {
         }
         d[l] = d[l] + f;
         e[l] = 0.0;
+    }
+    if (logged) {
+        job.total.store(nsweep, std::memory_order_release);
+        if (started) {
+            ql_replay(job, 0, n / job.parts);                         // the caller's own row slice
+            QlPool::get().finish();
+        } else {
+            ql_replay(job, 0, n);                                      // pool busy (another solver thread): serial replay
+        }
     }
     // ---- sort ascending
     for (int i = 0; i < n - 1; ++i) {
@@ -196,7 +377,7 @@ inline int ql_implicit(int n, double* a, double* d, double* e_in) {
     return rc;
 }
 
-inline int symeig_dense(int n, double* a, double* d, bool tridiagonal = false) {
+inline int symeig_dense(int n, double* a, double* d, bool tridiagonal = false, int threads = -1) {
     if (n <= 0) return 0;
     if (n == 1) { d[0] = a[0]; a[0] = 1.0; return 0; }
     std::vector<double> e(n, 0.0);
@@ -209,7 +390,7 @@ inline int symeig_dense(int n, double* a, double* d, bool tridiagonal = false) {
     } else {
         householder_tridiag(n, a, d, e.data());
     }
-    return ql_implicit(n, a, d, e.data());
+    return ql_implicit(n, a, d, e.data(), threads);
 }
 
 // Eigen-decomposition of the restarted Rayleigh quotient

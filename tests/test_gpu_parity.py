@@ -433,10 +433,12 @@ def test_iteration_traces_match_golden(name, golden_dir):
 
 
 def test_metric_instance_first_iterations_match_oracle_trace(golden_dir):
-    """The metric's own instance (Max-Cut ER n=4000, seed 0, reference default options): the first 30
-    PDHG iterations against the oracle trace committed by tests/golden/make_golden_large.py (156 s of
-    CPU there).  Includes iteration 2 (55 mat-vecs: three thick restarts) and iteration 10 (one
-    restart); same mat-vec count per iteration, same linesearch trials, objectives / steps to 1e-9."""
+    """The metric's own instance (Max-Cut ER n=4000, seed 0, reference default options): the first
+    PDHG iterations (as many as the committed fixture holds: TRACE4000_ITERS of
+    tests/golden/make_golden_large.py, minutes of CPU there) against the oracle trace.  Includes
+    iteration 2 (55 mat-vecs: three thick restarts), iteration 10 (one restart) and every later restart
+    and rank update in the window; same mat-vec count per iteration, same linesearch trials and rank
+    schedule, objectives / steps to 1e-9."""
     gold = json.loads((golden_dir / "trace_maxcut_n4000.json").read_text())
     pr = P.maxcut(gold["n"], seed=gold["seed"])
     rows = np.array(gold["rows"])

@@ -213,6 +213,26 @@ def test_bindings_mirror_the_header_field_by_field(cname, jname, cls):
     assert jf == cf
 
 
+@pytest.mark.parametrize("k", [96, 127, 190, 255])
+def test_threaded_eigenvector_accumulation_is_bit_identical_to_serial(k):
+    """host_util.hpp ql_implicit: from k >= 96 the rotation recurrence runs alone on the calling thread
+    while helper threads replay the logged rotations on disjoint row slices of the eigenvector matrix.
+    Same arithmetic per entry => the same bits as the serial loop; and a correct decomposition."""
+    import time
+    rng = np.random.default_rng(k)
+    T = np.diag(rng.standard_normal(k)) + np.diag(rng.uniform(0.5, 1.5, k - 1), 1)
+    T = T + np.triu(T, 1).T
+    T[: k // 2, k // 2] += 0.3 * rng.standard_normal(k // 2)        # an arrow column, as after a thick restart
+    T = np.triu(T) + np.triu(T, 1).T
+    t0 = time.time(); d0, U0 = B.host_symeig(T, threads=0); t_serial = time.time() - t0
+    t0 = time.time(); d1, U1 = B.host_symeig(T, threads=3); t_thr = time.time() - t0         # three helper threads, on request
+    assert np.array_equal(d0, d1) and np.array_equal(U0, U1)
+    assert np.allclose(d1, np.linalg.eigvalsh(T), rtol=0, atol=1e-12 * np.abs(T).max())
+    assert np.allclose(U1.T @ U1, np.eye(k), atol=1e-13)
+    assert np.abs(T @ U1 - U1 * d1).max() <= 1e-12 * np.abs(T).max() * k
+    print(k, "serial %.3f ms, with helpers %.3f ms" % (1e3 * t_serial, 1e3 * t_thr))
+
+
 @pytest.mark.parametrize("K,m", [(25, 15), (53, 31), (127, 76), (5, 1), (9, 8)])
 def test_two_phase_eigensolver_of_the_restarted_rayleigh_quotient(K, m):
     """host_util.hpp symeig_tridiag_from: the arrow part [diag(D) f; f' .] is Householder-reduced
