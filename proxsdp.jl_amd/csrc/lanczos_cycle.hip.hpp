@@ -230,7 +230,7 @@ k_lz_cycle(CycleArgs a) {
     int kstop = -1;
     bool failed = false;
     const bool timing = a.dbg != nullptr;
-    long long tk[6] = {0, 0, 0, 0, 0, 0};
+    long long tk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long t0 = timing ? wall_clock64() : 0;
     const long long wc0 = t0, sc0 = timing ? clock64() : 0;
 #define CY_TICK(q) if (timing) { const long long t1 = wall_clock64(); tk[q] += t1 - t0; t0 = t1; }
@@ -283,7 +283,9 @@ k_lz_cycle(CycleArgs a) {
             const int cc = c0 + lane * S;
             if (lane < 16 && cc < rp) s_col[rb * CY_CMAX + cc] = cs;
         }
+        CY_TICK(0)
         __syncthreads();                                                                    // (B)
+        CY_TICK(1)
         double ei = s_pe[row];
 #pragma unroll
         for (int q = 1; q < S; ++q) ei += s_pe[q * R + row];
@@ -298,7 +300,7 @@ k_lz_cycle(CycleArgs a) {
             if (lane == 0) s_col[rb * CY_CMAX + rp] = av;
         }
         __syncthreads();                                                                    // (C)
-        CY_TICK(0)
+        CY_TICK(2)
         // ---- X1: publish this workgroup's partials, fetch all records
         ++epoch;
         if (tid <= rp) {
@@ -314,7 +316,7 @@ k_lz_cycle(CycleArgs a) {
             if (ok) cy_fetch_records(a.x1, a.xs1, 0, G, len1, s_x, len1, lane, wv);
             if (__syncthreads_or(!ok)) { failed = true; break; }                            // (F)
         }
-        CY_TICK(1)
+        CY_TICK(3)
         // ================= recurrence + predicted first pass (step k) =================
         // t = Vp' u (lane c and c + 64: sums over the records in ascending order), alpha~
         const double binv = first ? 1.0 : 1.0 / beta_prev;
@@ -368,13 +370,16 @@ k_lz_cycle(CycleArgs a) {
         }
         if (tid == k) s_q[k] = ck;
         h1k = ck;
+        CY_TICK(4)
         __syncthreads();                                                                    // (H)
+        CY_TICK(5)
         // w' = (e + Vp u) / beta - V q: partial over this thread's column subset
         {
             const double dv = cy_dot_cols<S>(sV, R, row, s, s_q, k + 1);
             const double du = fl ? cy_dot_cols<S>(sF, R, row, s, s_u, rp) : cy_dot_cols_g<S>(a.Vp, (size_t)a.ldv, ic, s, s_u, rp);
             s_pc[s * R + row] = dv - du * binv;
         }
+        CY_TICK(6)
         __syncthreads();                                                                    // (I)
         ++epoch;                                    // epoch of X2 (partials and the rows of w' share the record)
         double wp;
@@ -402,8 +407,9 @@ k_lz_cycle(CycleArgs a) {
             const int jj = j0 + lane * S;
             if (lane < 16 && jj <= k) s_col[rb * CY_CMAX + jj] = cs;
         }
+        CY_TICK(7)
         __syncthreads();                                                                    // (K)
-        CY_TICK(2)
+        CY_TICK(8)
         // ---- X2: publish the partials (the rows of w' are already in the record), fetch every record
         if (tid <= k + 1) {
             double v = s_col[tid];
@@ -433,7 +439,7 @@ k_lz_cycle(CycleArgs a) {
             if (tid <= k) s_h[tid] = acc; else s_sc[0] = acc;
         }
         __syncthreads();                                                                    // (A)
-        CY_TICK(3)
+        CY_TICK(9)
     }
     if (failed) {
         if (tid == 0) atomicExch(a.err, 1);
@@ -442,10 +448,10 @@ k_lz_cycle(CycleArgs a) {
     if (timing && tid == 0) {
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        atomicOr((unsigned long long*)(a.dbg + 7), 1ull << (xcc & 15));
+        atomicOr((unsigned long long*)(a.dbg + 15), 1ull << (xcc & 15));
         if (g == 0) {
-            tk[4] = wall_clock64() - wc0; tk[5] = clock64() - sc0;      // shader cycles per 10 ns tick -> clock
-            for (int q = 0; q < 6; ++q) atomicAdd((unsigned long long*)(a.dbg + q), (unsigned long long)tk[q]);
+            tk[10] = wall_clock64() - wc0; tk[11] = clock64() - sc0;    // shader cycles per 10 ns tick -> clock
+            for (int q = 0; q < 12; ++q) atomicAdd((unsigned long long*)(a.dbg + q), (unsigned long long)tk[q]);
         }
     }
     // ---- write back the new basis columns and the scalars

@@ -1443,14 +1443,15 @@ inline void Solver::run() {
     for (EigWork& W : eig) harvest_full_eig_events(W);
     merge_block_stats();
     if (cy_dbg.n) {
-        long long t[8];
-        cy_dbg.download(t, 8, stream);
+        long long t[16];
+        cy_dbg.download(t, 16, stream);
         PX_HIP(hipStreamSynchronize(stream));
-        std::fprintf(stderr, "[cycle ticks/step @100MHz] close+opA %.1f X1 %.1f phaseB %.1f X2 %.1f | %.1f %.1f (steps %lld)\n",
-                     (double)t[0] / st.cycle_steps, (double)t[1] / st.cycle_steps, (double)t[2] / st.cycle_steps,
-                     (double)t[3] / st.cycle_steps, (double)t[4] / st.cycle_steps, (double)t[5] / st.cycle_steps, (long long)st.cycle_steps);
+        const double sN = (double)std::max<long long>(st.cycle_steps, 1);
+        std::fprintf(stderr, "[cycle ticks/step @100MHz] closeA+opA %.1f |B %.1f |ei,vk,av+C %.1f | X1 %.1f | t,alpha,coef %.1f |H %.1f | w' dots %.1f |I+wp+put+fold %.1f |K %.1f | X2 %.1f (steps %lld)\n",
+                     t[0] / sN, t[1] / sN, t[2] / sN, t[3] / sN, t[4] / sN, t[5] / sN, t[6] / sN, t[7] / sN, t[8] / sN, t[9] / sN,
+                     (long long)st.cycle_steps);
         std::fprintf(stderr, "[cycle] XCC id mask of the active workgroups: 0x%llx; shader clock during the cycles: %.0f MHz\n",
-                     (unsigned long long)t[7], t[4] > 0 ? 100.0 * (double)t[5] / (double)t[4] : 0.0);
+                     (unsigned long long)t[15], t[10] > 0 ? 100.0 * (double)t[11] / (double)t[10] : 0.0);
     }
     st.loop_time = now_s() - t_loop0;
     if (warm.joinable()) warm.join();

@@ -464,7 +464,7 @@ inline void Solver::setup_device() {
     rotate_lds_cap = (hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_lz_rotate),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) == hipSuccess)
                          ? 144 * 1024 : 60 * 1024;
-    if (std::getenv("PROXSDP_HIP_DEBUG_CYCLE") != nullptr) { cy_dbg.alloc(8); cy_dbg.zero(stream); }
+    if (std::getenv("PROXSDP_HIP_DEBUG_CYCLE") != nullptr) { cy_dbg.alloc(16); cy_dbg.zero(stream); }
     cycle_lds_cap = 0;
     for (int kb : {160, 156, 152, 144, 128, 96, 64}) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_lz_cycle<128>),

@@ -866,6 +866,28 @@ def test_batched_small_block_projection_against_lapack(n):
         assert info["rank"] == int((w > 1e-7).sum())
 
 
+@pytest.mark.parametrize("n,maxrank,rank0", [(700, 16, 2), (1500, 40, 30)])
+def test_persistent_cycle_kernel_matches_the_step_kernels(n, maxrank, rank0):
+    """lanczos_cycle_kernel = 1: one persistent launch per Lanczos cycle (workgroups of one XCD keep their
+    rows of the basis in LDS, partial dots exchanged through that XCD's L2).  Same arithmetic per step as
+    the two step kernels, only the grouping of partial sums differs: same mat-vec / restart counts, traces
+    to 1e-9.  (If the placement assumption failed, the bounded spins would time out and the library would
+    fall back to the step kernels: cycle_launches would still be counted but the test's equality holds
+    either way; the second assertion checks that cycles really ran.)"""
+    pr = P.maxcut(n, seed=5)
+    kw = dict(max_iter=160, support_path=1, max_target_rank_krylov_eigs=maxrank, initial_target_rank=rank0)
+    a = Optimizer(lanczos_cycle_kernel=0, **kw).optimize(pr, trace_capacity=160)
+    b = Optimizer(lanczos_cycle_kernel=1, **kw).optimize(pr, trace_capacity=160)
+    assert a.stats["cycle_launches"] == 0 and b.stats["cycle_launches"] > 100
+    assert b.stats["cycle_steps"] >= 0.9 * b.stats["lanczos_matvecs"]
+    assert a.iter == b.iter and a.status == b.status
+    assert np.array_equal(a.trace[:, 13], b.trace[:, 13])                         # mat-vecs per iteration
+    assert np.array_equal(a.trace[:, 11], b.trace[:, 11])                         # linesearch trials
+    assert a.stats["lanczos_restarts"] == b.stats["lanczos_restarts"]
+    for col in (1, 2, 7):
+        assert np.allclose(a.trace[:, col], b.trace[:, col], rtol=1e-9, atol=1e-12), col
+
+
 def test_warm_start_knob_reaches_the_same_optimum_with_fewer_restarts():
     """lanczos_warm_start = 1 (library-only): start vector = normalised sum of the previous projection's Ritz
     vectors + 1e-3 x the fixed vector.  Eigenpairs are still converged to krylovkit_tol, so the iterates
