@@ -175,7 +175,8 @@ function chambolle_pock_hip(aff, con, options; ResultType = Main.ProxSDP.Result)
                        length(con.sdpcone), pointer(psd_ptr), pointer(psd_idx),
                        length(con.socone), pointer(soc_ptr), pointer(soc_idx),
                        Int32(1), Int32(0), Ptr{Float64}(C_NULL),         # Julia indices are 1-based
-                       C_NULL, C_NULL, Ptr{Float64}(C_NULL), Int32(0), Int32(0))
+                       C_NULL, C_NULL, Ptr{Float64}(C_NULL), Int32(0), Int32(0),
+                       0, Ptr{Int64}(C_NULL), Ptr{Int32}(C_NULL), C_NULL, Int32(0), Int32(0))   # no coupling rows
         res.primal = pointer(primal); res.dual_cone = pointer(dual_cone)
         res.dual_eq = pointer(dual_eq); res.dual_in = pointer(dual_in)
         res.slack_eq = pointer(slack_eq); res.slack_in = pointer(slack_in)
