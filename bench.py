@@ -258,6 +258,9 @@ def main():
                                          "at the same pinned target rank %d, %.1f s of CPU work, OpenBLAS threads=%d"
                                          % (cpu_it, r0, cpu_loop, ncores),
                                "gpu_it_per_s_same_iterations": min(cpu_it, len(tr)) / max(gpu_same, 1e-9),
+                               "oracle_pin": "the oracle is pinned by the reference's known-answer tests (<= 4x4 PSD, atol 1e-2) and "
+                                             "SDPLIB optima; its KrylovKit layer is a restatement of the published algorithm -- the "
+                                             "reference holds no eigenpair / mat-vec-count vectors (parity unpinned at that layer)",
                                "wall_s": time.time() - tc}
         # BASELINE config 2 (Max-Cut n=1000, the size the CPU path handles comfortably): the same
         # 200 iterations on both sides ("iterations 1-200 at n=1000 fully")

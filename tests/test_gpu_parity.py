@@ -361,6 +361,27 @@ def test_unbounded_lp_certificate_search():
     assert "Primal ray found" in sol.status_string
 
 
+def test_certificate_search_on_a_psd_model_support_and_dense_paths():
+    """Certificate search on an infeasible SDP whose PSD block (side 110) takes the Lanczos path: the
+    snapshot taken when infeasibility is declared rescales the iterate IN PLACE (pdhg.jl:749-755), after
+    which the operator-form factors of the support path no longer describe it -- they are dropped
+    (ADVICE round 1).  Support path (operator-form mat-vec), dense path and the oracle: status
+    INFEASIBLE with a dual ray found, iteration counts within 5 %."""
+    from kat_problems import infeasible_sdp
+    pr = infeasible_sdp()
+    ref = oracle.solve(pr, Options())
+    assert ref.status == 6 and ref.certificate_found
+    for sp in (0, 1):
+        opt = Optimizer(support_path=sp)
+        sol = opt.optimize(pr)
+        print("support_path", sp, sol.status, sol.iter, sol.status_string, "| oracle", ref.iter)
+        assert sol.status == 6 and sol.certificate_found
+        assert "[Dual ray found]" in sol.status_string
+        assert abs(sol.iter - ref.iter) <= 0.05 * ref.iter
+        if sp == 1:
+            assert sol.stats["fop_projections"] > 0
+
+
 def test_infeasible_lp_prefix_matches_oracle():
     """Infeasible LP (the reference needs ~1e6 iterations to declare it): the first 3000
     iterations follow the oracle exactly (no eigen-solver involved)."""
