@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PROXSDP_HIP_ABI_VERSION 4
+#define PROXSDP_HIP_ABI_VERSION 5
 
 /* error codes (negative return values) */
 #define PROXSDP_E_INVALID  (-1)   /* invalid argument / inconsistent problem data */
@@ -209,7 +209,11 @@ typedef struct proxsdp_options {
     int32_t small_block_batch;   /* project the small PSD blocks in ONE batched Jacobi launch instead of one dense
                                   * eigensolver call each: -1 auto (>= 2 blocks of side 2..32), 1 = every block of side
                                   * 2..64, 0 off */
-    int32_t pad7;
+    int32_t full_eig_sign;       /* full_eig! of a dense block without an eigendecomposition: X+ = (X + X sign(X)) / 2
+                                  * with sign(X) from an odd-polynomial iteration of fp64 MFMA products (58 products of
+                                  * n x n symmetric matrices; every |eigenvalue| >= 1e-10 ||X|| is resolved to 1e-15,
+                                  * smaller ones contribute an error <= their own size): -1 auto (48 <= n <= 4096),
+                                  * 1 always, 0 = rocSOLVER dsyevd + reconstruction */
 } proxsdp_options;
 
 #define PROXSDP_TRACE_COLS 14
@@ -253,6 +257,8 @@ typedef struct proxsdp_stats {
     int64_t cycle_steps;         /* Lanczos steps run inside those launches                       */
     double  cycle_ms;            /* their summed kernel time (events; profile_symv_every > 0)     */
     int64_t warm_starts;         /* projections started from the previous Ritz vectors (lanczos_warm_start) */
+    int64_t full_eigs_sign;      /* full_eig! calls served by the sign-function projection (full_eig_sign) */
+    int64_t sign_products;       /* symmetric n x n matrix products (fp64 MFMA) those calls took */
 } proxsdp_stats;
 
 /* Result (structs.jl:60-81).  Arrays are caller-allocated with the stated
@@ -309,6 +315,8 @@ int  proxsdp_hip_device_count(void);          /* <0: PROXSDP_E_HIP */
  * mode 2: full_eig! served by the Lanczos engine (every positive eigenpair), target_rank = estimate
  *         of the number of positive eigenvalues; *out_fell_back = 1 if the dense solver had to run;
  * mode 3: full_eig! by the batched small-block Jacobi kernel (2 <= n <= 64); *out_converged = #{lambda > 0}.
+ * mode 4: full_eig! by the sign-function projection (options.full_eig_sign = 1): fp64 MFMA products, no eigenpairs;
+ *         *out_rank = #{lambda > 0};
  * resid: start vector (n) or NULL.  out_*: rank (current_rank), min_eig,
  * nmatvec, converged eigenpairs, fell_back flag. */
 int proxsdp_hip_psd_project(const double* packed_in, int64_t n, int32_t target_rank,
@@ -337,6 +345,13 @@ int proxsdp_hip_reconstruct(const double* Z, const double* lambda, int64_t n, in
  * SYRK (v_mfma_f64_16x16x4_f64), -1 = the library's choice (options.reconstruct_mfma auto) */
 int proxsdp_hip_reconstruct_kernel(const double* Z, const double* lambda, int64_t n, int32_t r, int32_t mfma,
                                    double* packed_out, int32_t repeat, double* ms);
+
+/* full_eig! (prox_operators.jl:111-126) of one packed block, timed: sign = 0 rocSOLVER dsyevd + reconstruction,
+ * 1 = the sign-function projection (options.full_eig_sign); ms = wall time per call over `repeat` calls on
+ * device-resident data, out_rank = #{lambda > tol_psd} (dsyevd) / #{lambda > 0} (sign), out_products = MFMA
+ * products per call */
+int proxsdp_hip_full_eig_kernel(const double* packed_in, int64_t n, int32_t sign, double* packed_out,
+                                int32_t repeat, double* ms, int32_t* out_rank, int64_t* out_products);
 
 /* Mx = M x (pdhg.jl:634) and Mty = M' y (pdhg.jl:556) for M given as CSC */
 int proxsdp_hip_spmv(const proxsdp_csc* M, int32_t index_base, int32_t transpose,

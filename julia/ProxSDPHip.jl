@@ -96,6 +96,8 @@ struct Stats                     # proxsdp_stats
     cycle_steps::Int64
     cycle_ms::Float64
     warm_starts::Int64
+    full_eigs_sign::Int64
+    sign_products::Int64
 end
 
 mutable struct CResult           # proxsdp_result

@@ -105,7 +105,7 @@ def _opt_fields():
     a("device_id", i32); a("trace_capacity", i32); a("profile_symv_every", i32); a("support_path", i32)
     a("lanczos_operator", i32); a("initial_target_rank", i32)
     a("full_eig_lanczos", i32); a("lanczos_cycle_kernel", i32); a("lanczos_warm_start", i32)
-    a("reconstruct_mfma", i32); a("small_block_batch", i32); a("pad7", i32)
+    a("reconstruct_mfma", i32); a("small_block_batch", i32); a("full_eig_sign", i32)
     return F
 
 
@@ -123,7 +123,8 @@ class Stats(C.Structure):
                 ("host_eig_time", f64), ("host_eigs", i64), ("device_eigs", i64), ("batched_small_eigs", i64),
                 ("mfma_reconstructions", i64), ("orth_profiled", i64), ("orth_profiled_ms", f64),
                 ("full_eig_solver_ms", f64), ("full_eig_recon_ms", f64), ("cycle_launches", i64),
-                ("full_eigs_lanczos", i64), ("cycle_steps", i64), ("cycle_ms", f64), ("warm_starts", i64)]
+                ("full_eigs_lanczos", i64), ("cycle_steps", i64), ("cycle_ms", f64), ("warm_starts", i64),
+                ("full_eigs_sign", i64), ("sign_products", i64)]
 
 
 class Result(C.Structure):
@@ -183,11 +184,12 @@ def lib():
     L.proxsdp_hip_symv_packed.argtypes = [pf64, i64, pf64, pf64, i32, pf64]
     L.proxsdp_hip_reconstruct.argtypes = [pf64, pf64, i64, i32, pf64, i32, pf64]
     L.proxsdp_hip_reconstruct_kernel.argtypes = [pf64, pf64, i64, i32, i32, pf64, i32, pf64]
+    L.proxsdp_hip_full_eig_kernel.argtypes = [pf64, i64, i32, pf64, i32, pf64, C.POINTER(i32), C.POINTER(i64)]
     L.proxsdp_hip_spmv.argtypes = [C.POINTER(CSC), i32, i32, pf64, pf64]
     L.proxsdp_host_symeig.argtypes = [i32, pf64, pf64]
     L.proxsdp_host_start_vector.argtypes = [i64, i64, i32, pf64]
     L.proxsdp_host_preprocess.argtypes = [C.POINTER(Problem), pi64, pi64, pf64, pf64]
-    if L.proxsdp_hip_abi_version() != 4:
+    if L.proxsdp_hip_abi_version() != 5:
         raise ProxSDPHipError(-1, "ABI version mismatch")
     _lib = L
     return L
@@ -452,6 +454,18 @@ def reconstruct(Z, lam, n, repeat=0, mfma=-1):
     ms = f64(0.0)
     _check(L.proxsdp_hip_reconstruct_kernel(Zc.ctypes.data_as(pf64), _p(lam), n, r, mfma, _p(out), repeat, C.byref(ms)))
     return (out, ms.value) if repeat else out
+
+
+def full_eig_kernel(packed, n, sign=1, repeat=1):
+    """full_eig! of one packed block on device-resident data: (X+ packed, ms per call, rank, products per call)"""
+    L = lib()
+    xin = _f(packed)
+    out = np.zeros(n * (n + 1) // 2)
+    ms = f64(0.0)
+    rk = i32(0)
+    npr = i64(0)
+    _check(L.proxsdp_hip_full_eig_kernel(_p(xin), n, int(sign), _p(out), repeat, C.byref(ms), C.byref(rk), C.byref(npr)))
+    return out, ms.value, rk.value, npr.value
 
 
 def spmv(M, x, transpose=False):

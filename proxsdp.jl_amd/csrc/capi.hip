@@ -131,7 +131,9 @@ int proxsdp_hip_psd_project(const double* packed_in, int64_t n, int32_t target_r
         if (!packed_in || !packed_out) throw std::invalid_argument("NULL buffer");
         if (target_rank < 1) throw std::invalid_argument("target_rank < 1");
         proxsdp_options o = Engine::fix(opt);
-        if (mode == 1) { o.full_eig_decomp = 1; o.full_eig_lanczos = 0; }
+        if (mode == 1) { o.full_eig_decomp = 1; o.full_eig_lanczos = 0; o.full_eig_sign = 0; }
+        // mode 4: full_eig! by the sign-function projection (fp64 MFMA products)
+        if (mode == 4) { o.full_eig_decomp = 1; o.full_eig_lanczos = 0; o.full_eig_sign = 1; }
         // the test entry point takes the Krylov branch whenever mode == 0
         if (mode == 0) { o.min_size_krylov_eigs = 0; o.max_target_rank_krylov_eigs = std::max(o.max_target_rank_krylov_eigs, target_rank); }
         // mode 2: full_eig! served by the Lanczos engine, `target_rank` = the estimate of the number of
@@ -177,6 +179,34 @@ int proxsdp_hip_psd_project(const double* packed_in, int64_t n, int32_t target_r
         if (out_nmatvec) *out_nmatvec = S.st.lanczos_matvecs;
         if (out_converged) *out_converged = S.eig[0].converged_eigs;
         if (out_fell_back) *out_fell_back = mode == 2 ? (int32_t)(S.st.full_eigs_lanczos == 0) : (int32_t)S.st.krylov_fallbacks;
+        return 0;
+    });
+}
+
+int proxsdp_hip_full_eig_kernel(const double* packed_in, int64_t n, int32_t sign, double* packed_out,
+                                int32_t repeat, double* ms, int32_t* out_rank, int64_t* out_products) {
+    return guarded([&]() -> int {
+        if (!packed_in || !packed_out) throw std::invalid_argument("NULL buffer");
+        proxsdp_options o = Engine::fix(nullptr);
+        o.full_eig_decomp = 1; o.full_eig_lanczos = 0; o.full_eig_sign = sign ? 1 : 0;
+        Engine E(&o, n, 2);
+        proxsdp::Solver& S = E.S;
+        const int64_t N = n * (n + 1) / 2;
+        proxsdp::DevBuf<double> x(N), y(N);
+        x.upload(packed_in, N, S.stream);
+        S.P.blocks.push_back({(int)n, N, 0});
+        S.test_full_eig(x.p, y.p);             // warm-up (allocations, rocSOLVER workspace)
+        PX_HIP(hipStreamSynchronize(S.stream));
+        const int reps = std::max(1, repeat);
+        const double t0 = proxsdp::now_s();
+        for (int i = 0; i < reps; ++i) S.test_full_eig(x.p, y.p);
+        PX_HIP(hipStreamSynchronize(S.stream));
+        if (ms) *ms = (proxsdp::now_s() - t0) * 1e3 / reps;
+        y.download(packed_out, N, S.stream);
+        PX_HIP(hipStreamSynchronize(S.stream));
+        S.merge_block_stats();
+        if (out_rank) *out_rank = (int32_t)S.test_rank();
+        if (out_products) *out_products = S.st.sign_products / (reps + 1);
         return 0;
     });
 }

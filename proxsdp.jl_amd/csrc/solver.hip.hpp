@@ -31,6 +31,7 @@
 #include "host_util.hpp"
 #include "kernels.hip.hpp"
 #include "lanczos_cycle.hip.hpp"
+#include "sign_project.hip.hpp"
 #include "prep.hpp"
 
 namespace proxsdp {
@@ -188,6 +189,11 @@ struct EigWork {
     EigEvents ev, evo;                             // profiled mat-vec / orthogonalisation launches
     hipEvent_t fe[3] = {nullptr, nullptr, nullptr};   // full_eig!: before solver | after solver | after reconstruction
     bool fe_pending = false;
+    // full_eig! by the matrix sign function (sign_project.hip.hpp): A | X | X' | Y | Q, ld x ld each
+    DevBuf<double> sgA, sgX, sgX2, sgY, sgQ, sg_part, sg_part2, sg_sc;
+    PinnedBuf sg_host;
+    int sg_ld = 0;
+    bool sg_pending = false;                       // fe[] hold a sign projection's events (all of it is "solver")
 };
 
 
@@ -256,6 +262,7 @@ public:
 
     // test hooks (capi.hip)
     void test_project(int idx, double* xp, int tr);
+    void test_full_eig(const double* xin, double* xout) { current_rank.assign(1, 0); min_eig.assign(1, 0.0); full_eig_project(0, xin, xout, false); }
     long long test_rank() const { return current_rank.empty() ? 0 : current_rank[0]; }
     double test_min_eig() const { return min_eig.empty() ? 0.0 : min_eig[0]; }
     void test_spmv(bool transpose, const double* in, double* out);
@@ -376,6 +383,10 @@ private:
                    const double* old, const double* addc, double* normpart, long long cstride);
     void full_eig_project(int idx, const double* xp_in, double* xp_out, bool fuse);
     bool full_eig_by_lanczos(int idx, const double* xp_in, double* xp_out, bool fuse);
+    bool full_eig_by_sign(int idx, const double* xp_in, double* xp_out, bool fuse);
+    template <int EPI, bool FUSE>
+    void sym_gemm(EigWork& W, const double* Pm, const double* Qm, double* T, const double* Y, double ca, double cb,
+                  double cc, const double* dsc, double* part, double* xp_out, const double* xp_old, int blk);
     void spmv(const double* x, double* y);
     void spmv_sparse(const double* x, double* y);
     int  linesearch();
@@ -1033,7 +1044,86 @@ inline void Solver::full_eig_values(EigWork& W, const double* xp, double offscal
 }
 
 // full_eig! (prox_operators.jl:111-126)
+template <int EPI, bool FUSE>
+inline void Solver::sym_gemm(EigWork& W, const double* Pm, const double* Qm, double* T, const double* Y, double ca,
+                             double cb, double cc, const double* dsc, double* part, double* xp_out,
+                             const double* xp_old, int blk) {
+    const int grid = 8 * ceil_div(W.nt * (W.nt + 1) / 2, 8);
+    hipLaunchKernelGGL((dev::k_sym_gemm<EPI, FUSE>), dim3(grid), dim3(dev::TPB), 0, stream, Pm, Qm, W.sg_ld, W.nt, T, Y,
+                       ca, cb, cc, dsc, part, W.n, xp_out, xp_old, FUSE ? (const unsigned*)mask_d.p : nullptr,
+                       FUSE ? (long long)P.blocks[blk].off : 0LL, FUSE ? respart_d.p + tile_base[blk] : nullptr,
+                       FUSE ? rstride : 0);
+    W.lst.sign_products++;
+}
+
+// full_eig! without an eigendecomposition: X+ = (X + X sign(X)) / 2, sign by an odd-polynomial
+// iteration of fp64 MFMA products (sign_project.hip.hpp).  current_rank = #{lambda > 0} =
+// (tr S + tr S^2) / 2 (the reference counts lambda > tol_psd: eigenvalues in (0, tol_psd] are the only
+// difference, and the count only feeds Result.final_rank on this path: min_eig = 0 blocks bump_rank).
+inline bool Solver::full_eig_by_sign(int idx, const double* xp_in, double* xp_out, bool fuse) {
+    EigWork& W = eig[idx];
+    const int n = W.n;
+    if (opt.full_eig_sign == 0) return false;
+    if (opt.full_eig_sign < 0 && (n < 48 || n > 4096)) return false;     // auto: measured window
+    const int ld = W.nt * dev::TILE;
+    const int ntile = W.nt * (W.nt + 1) / 2, grid = 8 * ceil_div(ntile, 8);
+    if (W.sg_ld != ld) {
+        const size_t sz = (size_t)ld * ld;
+        W.sgA.alloc(sz); W.sgX.alloc(sz); W.sgX2.alloc(sz); W.sgY.alloc(sz); W.sgQ.alloc(sz);
+        W.sgA.zero(stream);                                  // the padding stays zero: only entries < n are rewritten
+        W.sg_part.alloc(grid); W.sg_part2.alloc(grid); W.sg_sc.alloc(16); W.sg_host.alloc(16);
+        W.sg_sc.zero(stream);
+        W.sg_ld = ld;
+    }
+    const bool prof = opt.profile_symv_every > 0;
+    if (prof) {
+        if (W.fe[0] == nullptr) for (auto& e : W.fe) PX_HIP(hipEventCreate(&e));
+        harvest_full_eig_events(W);
+        PX_HIP(hipEventRecord(W.fe[0], stream));
+    }
+    const bool fz = fuse && use_support;
+    double* sc = W.sg_sc.p;
+    hipLaunchKernelGGL(dev::k_unpack_sym, dim3(ntile), dim3(dev::TPB), 0, stream, xp_in, n, W.sgA.p, ld,
+                       dev::INV_SQRT2, W.sg_part.p);
+    hipLaunchKernelGGL(dev::k_sign_scalars, dim3(1), dim3(dev::TPB), 0, stream, (const double*)W.sg_part.p, ntile, 0, sc);
+    // Y0 = A A / f^2 and its Frobenius norm g: s = f sqrt(g) >= ||A||_2
+    sym_gemm<dev::SG_PLAIN, false>(W, W.sgA.p, W.sgA.p, W.sgY.p, nullptr, 0, 0, 0, sc + 0, W.sg_part.p, nullptr, nullptr, -1);
+    hipLaunchKernelGGL(dev::k_sign_scalars, dim3(1), dim3(dev::TPB), 0, stream, (const double*)W.sg_part.p, grid, 1, sc);
+    double* X = W.sgX.p;
+    double* Xn = W.sgX2.p;
+    for (int k = 0; k < dev::SIGN_STEPS; ++k) {
+        const dev::SignStep& c = dev::SIGN_TABLE[k];
+        const bool last = k + 1 == dev::SIGN_STEPS;
+        if (k == 0) {
+            sym_gemm<dev::SG_POLY, false>(W, W.sgY.p, W.sgY.p, W.sgQ.p, W.sgY.p, c.a, c.b, c.c, sc + 8, nullptr, nullptr, nullptr, -1);
+            sym_gemm<dev::SG_PLAIN, false>(W, W.sgA.p, W.sgQ.p, X, nullptr, 0, 0, 0, sc + 1, nullptr, nullptr, nullptr, -1);
+        } else {
+            sym_gemm<dev::SG_PLAIN, false>(W, X, X, W.sgY.p, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, -1);
+            sym_gemm<dev::SG_POLY, false>(W, W.sgY.p, W.sgY.p, W.sgQ.p, W.sgY.p, c.a, c.b, c.c, nullptr, nullptr, nullptr, nullptr, -1);
+            sym_gemm<dev::SG_PLAIN, false>(W, X, W.sgQ.p, Xn, nullptr, 0, 0, 0, nullptr, last ? W.sg_part2.p : nullptr,
+                                           nullptr, nullptr, -1);
+            std::swap(X, Xn);
+        }
+    }
+    if (fz) sym_gemm<dev::SG_FINAL, true>(W, W.sgA.p, X, nullptr, nullptr, 0, 0, 0, nullptr, W.sg_part.p, xp_out, xp_in, idx);
+    else sym_gemm<dev::SG_FINAL, false>(W, W.sgA.p, X, nullptr, nullptr, 0, 0, 0, nullptr, W.sg_part.p, xp_out, nullptr, -1);
+    hipLaunchKernelGGL(dev::k_sign_scalars, dim3(1), dim3(dev::TPB), 0, stream, (const double*)W.sg_part.p, grid, 2, sc);
+    hipLaunchKernelGGL(dev::k_sign_scalars, dim3(1), dim3(dev::TPB), 0, stream, (const double*)W.sg_part2.p, grid, 3, sc);
+    if (prof) { PX_HIP(hipEventRecord(W.fe[1], stream)); PX_HIP(hipEventRecord(W.fe[2], stream)); W.fe_pending = true; }
+    PX_HIP(hipMemcpyAsync(W.sg_host.p, sc, 16 * sizeof(double), hipMemcpyDeviceToHost, stream));
+    PX_HIP(hipStreamSynchronize(stream));
+    const double tr = W.sg_host.p[5], fro2 = W.sg_host.p[7];
+    if (!std::isfinite(tr) || !std::isfinite(fro2)) throw HipError("sign-function projection produced non-finite values");
+    const int npos = (int)std::llround(0.5 * (tr + fro2));
+    W.lst.full_eigs++; W.lst.full_eigs_sign++;
+    current_rank[idx] = std::max(0, std::min(npos, n));
+    min_eig[idx] = 0.0;                                      // prox_operators.jl:114
+    W.last_npos = current_rank[idx];
+    return true;
+}
+
 inline void Solver::full_eig_project(int idx, const double* xp_in, double* xp_out, bool fuse) {
+    if (full_eig_by_sign(idx, xp_in, xp_out, fuse)) return;
     EigWork& W = eig[idx];
     std::vector<double> D;
     const bool prof = opt.profile_symv_every > 0;
@@ -1144,7 +1234,7 @@ inline void Solver::merge_block_stats() {
         st.symv_profiled += a.symv_profiled; st.symv_profiled_ms += a.symv_profiled_ms;
         st.orth_profiled += a.orth_profiled; st.orth_profiled_ms += a.orth_profiled_ms;
         st.full_eig_solver_ms += a.full_eig_solver_ms; st.full_eig_recon_ms += a.full_eig_recon_ms;
-        st.full_eigs_lanczos += a.full_eigs_lanczos; st.warm_starts += a.warm_starts; st.device_eigs += a.device_eigs; st.mfma_reconstructions += a.mfma_reconstructions; st.cycle_launches += a.cycle_launches;
+        st.full_eigs_lanczos += a.full_eigs_lanczos; st.full_eigs_sign += a.full_eigs_sign; st.sign_products += a.sign_products; st.warm_starts += a.warm_starts; st.device_eigs += a.device_eigs; st.mfma_reconstructions += a.mfma_reconstructions; st.cycle_launches += a.cycle_launches;
         st.cycle_steps += a.cycle_steps; st.cycle_ms += a.cycle_ms;
         st.symv_bytes += a.symv_bytes; st.host_eig_time += a.host_eig_time; st.host_eigs += a.host_eigs;
         st.fop_projections += a.fop_projections;
