@@ -420,18 +420,18 @@ def bench_randsdp(args, torch, dist, rank, world, dev_id, backend):
 def bench_sdplib(args, torch, dist, rank, world, dev_id, backend):
     """BASELINE config 5: SDPLIB maxG51 / gpp500-1 (test/base_sdplib.jl model) on the FULL-RANK
     fallback eig path, full_eig_decomp = true: every iteration is full_eig! (prox_operators.jl:111-126) =
-    dense eigensolver (rocSOLVER dsyevd) + rank-r+ reconstruction (fp64 MFMA SYRK, r+ ~ n/2 early on).
+    by default the sign-function projection (58 fp64 MFMA products, sign_project.hip.hpp); beside it the
+    dense eigensolver (rocSOLVER dsyevd) + rank-r+ reconstruction (full_eig_sign = 0).
     Single PSD block: replicas for N > 1.  value = iterations/s of maxG51; gpp500-1 beside it."""
     from proxsdp_jl_amd import problems, replicas
     from proxsdp_jl_amd.optimizer import Optimizer
     K, W = args.steps, args.warmup
     gold = os.path.join(ROOT, "tests", "golden", "sdplib")
 
-    def leg(fname):
+    def leg(fname, sign):
         pr = problems.sdplib(os.path.join(gold, fname + ".dat-s"))
         n = pr.psd_sides()[0]
-        N = n * (n + 1) // 2
-        opt = Optimizer(max_iter=W + K, device_id=dev_id, full_eig_decomp=1, profile_symv_every=1)
+        opt = Optimizer(max_iter=W + K, device_id=dev_id, full_eig_decomp=1, profile_symv_every=1, full_eig_sign=sign)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -443,19 +443,45 @@ def bench_sdplib(args, torch, dist, rank, world, dev_id, backend):
         t = float(tr[W + K - 1, 12] - (tr[W - 1, 12] if W > 0 else 0.0))
         its = max(1, int(sol.iter))
         eig_ms, rec_ms = st["full_eig_solver_ms"] / its, st["full_eig_recon_ms"] / its
-        rplus = int(sol.final_rank)
-        flops = (10.0 / 3.0) * n ** 3
-        return {"instance": fname, "n": n, "value": K / t, "unit": "iterations/s", "ms_per_step": 1e3 * t / K,
-                "dense_eigensolver_ms_per_step": eig_ms, "reconstruction_ms_per_step": rec_ms,
-                "dense_eigensolver_share": eig_ms / (1e3 * t / K), "full_eigs": int(st["full_eigs"]),
-                "positive_eigenvalues_last": rplus, "mfma_reconstructions": int(st["mfma_reconstructions"]),
-                "roofline": {"bound": "mfma", "kernel": "rocsolver_dsyevd (library) -- (10/3) n^3 flops (SURVEY 8d F_iter)",
-                             "achieved": flops / (eig_ms * 1e-3) / 1e12 if eig_ms > 0 else None, "peak": 78.6,
-                             "unit": "TFLOP/s", "frac": flops / (eig_ms * 1e-3) / 1e12 / 78.6 if eig_ms > 0 else None,
-                             "traffic": None}}, K, t
+        out = {"instance": fname, "n": n, "value": K / t, "unit": "iterations/s", "ms_per_step": 1e3 * t / K,
+               "full_eigs": int(st["full_eigs"]), "positive_eigenvalues_last": int(sol.final_rank)}
+        if st["full_eigs_sign"] > 0:
+            # executed MFMA flops of one projection: products on 32 x 32 tiles of the block upper triangle
+            # (side <= 3072; 64 x 64 above and for the final product), K = the padded side
+            ld = 64 * ((n + 63) // 64)
+            nprod = st["sign_products"] / st["full_eigs_sign"]
+            t32, t64 = ld // 32, ld // 64
+            f32 = (t32 * (t32 + 1) // 2) * 2.0 * 32 * 32 * ld
+            f64_ = (t64 * (t64 + 1) // 2) * 2.0 * 64 * 64 * ld
+            flops = (nprod - 1) * (f32 if ld <= 3072 else f64_) + f64_
+            ach = flops / (eig_ms * 1e-3) / 1e12 if eig_ms > 0 else None
+            out.update({"projection": "matrix sign function, fp64 MFMA products (full_eig_sign auto)",
+                        "projection_ms_per_step": eig_ms, "products_per_projection": nprod,
+                        "avg_product_launch_ms": eig_ms / nprod if nprod else None,
+                        "projection_share": eig_ms / (1e3 * t / K),
+                        "dsyevd_equivalent_TFLOPs": (10.0 / 3.0) * n ** 3 / (eig_ms * 1e-3) / 1e12 if eig_ms > 0 else None,
+                        "roofline": {"bound": "mfma", "kernel": "k_sym_gemm32 / k_sym_gemm (v_mfma_f64_16x16x4_f64): "
+                                     "executed MFMA flops of the %d products of one projection / event time of the "
+                                     "whole projection (incl. unpack and scalar kernels)" % round(nprod),
+                                     "achieved": ach, "peak": 78.6, "unit": "TFLOP/s",
+                                     "frac": ach / 78.6 if ach else None, "traffic": None,
+                                     "flops_per_projection": flops}})
+        else:
+            flops = (10.0 / 3.0) * n ** 3
+            out.update({"projection": "rocSOLVER dsyevd + fp64 MFMA SYRK reconstruction (full_eig_sign = 0)",
+                        "dense_eigensolver_ms_per_step": eig_ms, "reconstruction_ms_per_step": rec_ms,
+                        "dense_eigensolver_share": eig_ms / (1e3 * t / K),
+                        "mfma_reconstructions": int(st["mfma_reconstructions"]),
+                        "roofline": {"bound": "mfma", "kernel": "rocsolver_dsyevd (library) -- (10/3) n^3 flops (SURVEY 8d F_iter)",
+                                     "achieved": flops / (eig_ms * 1e-3) / 1e12 if eig_ms > 0 else None, "peak": 78.6,
+                                     "unit": "TFLOP/s", "frac": flops / (eig_ms * 1e-3) / 1e12 / 78.6 if eig_ms > 0 else None,
+                                     "traffic": None}})
+        return out, K, t
 
-    a, k1, t1 = leg("maxG51")
-    b, _, _ = leg("gpp500-1")
+    a, k1, t1 = leg("maxG51", -1)
+    b, _, _ = leg("gpp500-1", -1)
+    a0, _, _ = leg("maxG51", 0)
+    b0, _, _ = leg("gpp500-1", 0)
     total_steps, t_steps = replicas.aggregate(dist, k1, t1, device="cuda" if dist is not None else "cpu")
     if rank == 0:
         print(json.dumps({
@@ -465,7 +491,8 @@ def bench_sdplib(args, torch, dist, rank, world, dev_id, backend):
             "dtype": "f64", "data": "SDPLIB files (tests/golden/sdplib)",
             "config": {"workload": "SDPLIB maxG51 / gpp500-1, reference harness model (one merged PSD block), "
                                    "full_eig_decomp=true", "parallelism": "replicas x%d" % world},
-            "roofline": a["roofline"], "maxG51": a, "gpp500-1": b}))
+            "roofline": a["roofline"], "maxG51": a, "gpp500-1": b,
+            "rocsolver_path": {"maxG51": a0, "gpp500-1": b0}}))
     if dist is not None:
         dist.destroy_process_group()
 

@@ -212,7 +212,7 @@ typedef struct proxsdp_options {
     int32_t full_eig_sign;       /* full_eig! of a dense block without an eigendecomposition: X+ = (X + X sign(X)) / 2
                                   * with sign(X) from an odd-polynomial iteration of fp64 MFMA products (58 products of
                                   * n x n symmetric matrices; every |eigenvalue| >= 1e-10 ||X|| is resolved to 1e-15,
-                                  * smaller ones contribute an error <= their own size): -1 auto (48 <= n <= 4096),
+                                  * smaller ones contribute an error <= their own size): -1 auto (33 <= n <= 4096),
                                   * 1 always, 0 = rocSOLVER dsyevd + reconstruction */
 } proxsdp_options;
 

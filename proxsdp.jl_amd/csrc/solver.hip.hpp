@@ -193,6 +193,8 @@ struct EigWork {
     DevBuf<double> sgA, sgX, sgX2, sgY, sgQ, sg_part, sg_part2, sg_sc;
     PinnedBuf sg_host;
     int sg_ld = 0;
+    int sg_npart = 0;
+    bool sg_small = false;                         // products on 32 x 32 tiles (blocks up to side 3072)
     bool sg_pending = false;                       // fe[] hold a sign projection's events (all of it is "solver")
 };
 
@@ -1048,12 +1050,21 @@ template <int EPI, bool FUSE>
 inline void Solver::sym_gemm(EigWork& W, const double* Pm, const double* Qm, double* T, const double* Y, double ca,
                              double cb, double cc, const double* dsc, double* part, double* xp_out,
                              const double* xp_old, int blk) {
+    W.lst.sign_products++;
+    if constexpr (EPI != dev::SG_FINAL) {
+        if (W.sg_small) {                                   // 32 x 32 tiles: small blocks need the workgroups
+            const int nt32 = 2 * W.nt;
+            const int grid32 = 8 * ceil_div(nt32 * (nt32 + 1) / 2, 8);
+            hipLaunchKernelGGL((dev::k_sym_gemm32<EPI>), dim3(grid32), dim3(dev::TPB), 0, stream, Pm, Qm, W.sg_ld, nt32, T, Y,
+                               ca, cb, cc, dsc, part);
+            return;
+        }
+    }
     const int grid = 8 * ceil_div(W.nt * (W.nt + 1) / 2, 8);
     hipLaunchKernelGGL((dev::k_sym_gemm<EPI, FUSE>), dim3(grid), dim3(dev::TPB), 0, stream, Pm, Qm, W.sg_ld, W.nt, T, Y,
                        ca, cb, cc, dsc, part, W.n, xp_out, xp_old, FUSE ? (const unsigned*)mask_d.p : nullptr,
                        FUSE ? (long long)P.blocks[blk].off : 0LL, FUSE ? respart_d.p + tile_base[blk] : nullptr,
                        FUSE ? rstride : 0);
-    W.lst.sign_products++;
 }
 
 // full_eig! without an eigendecomposition: X+ = (X + X sign(X)) / 2, sign by an odd-polynomial
@@ -1064,14 +1075,18 @@ inline bool Solver::full_eig_by_sign(int idx, const double* xp_in, double* xp_ou
     EigWork& W = eig[idx];
     const int n = W.n;
     if (opt.full_eig_sign == 0) return false;
-    if (opt.full_eig_sign < 0 && (n < 48 || n > 4096)) return false;     // auto: measured window
+    if (opt.full_eig_sign < 0 && (n < 33 || n > 4096)) return false;     // auto: measured window
     const int ld = W.nt * dev::TILE;
     const int ntile = W.nt * (W.nt + 1) / 2, grid = 8 * ceil_div(ntile, 8);
     if (W.sg_ld != ld) {
         const size_t sz = (size_t)ld * ld;
         W.sgA.alloc(sz); W.sgX.alloc(sz); W.sgX2.alloc(sz); W.sgY.alloc(sz); W.sgQ.alloc(sz);
         W.sgA.zero(stream);                                  // the padding stays zero: only entries < n are rewritten
-        W.sg_part.alloc(grid); W.sg_part2.alloc(grid); W.sg_sc.alloc(16); W.sg_host.alloc(16);
+        static const int small_max = std::getenv("PROXSDP_HIP_SIGN_SMALL") ? std::atoi(std::getenv("PROXSDP_HIP_SIGN_SMALL")) : 3072;   // measured: 32-tiles win up to n ~ 3500
+        W.sg_small = ld <= small_max;
+        const int nt32 = 2 * W.nt;
+        W.sg_npart = W.sg_small ? 8 * ceil_div(nt32 * (nt32 + 1) / 2, 8) : grid;
+        W.sg_part.alloc(W.sg_npart); W.sg_part2.alloc(W.sg_npart); W.sg_sc.alloc(16); W.sg_host.alloc(16);
         W.sg_sc.zero(stream);
         W.sg_ld = ld;
     }
@@ -1088,7 +1103,7 @@ inline bool Solver::full_eig_by_sign(int idx, const double* xp_in, double* xp_ou
     hipLaunchKernelGGL(dev::k_sign_scalars, dim3(1), dim3(dev::TPB), 0, stream, (const double*)W.sg_part.p, ntile, 0, sc);
     // Y0 = A A / f^2 and its Frobenius norm g: s = f sqrt(g) >= ||A||_2
     sym_gemm<dev::SG_PLAIN, false>(W, W.sgA.p, W.sgA.p, W.sgY.p, nullptr, 0, 0, 0, sc + 0, W.sg_part.p, nullptr, nullptr, -1);
-    hipLaunchKernelGGL(dev::k_sign_scalars, dim3(1), dim3(dev::TPB), 0, stream, (const double*)W.sg_part.p, grid, 1, sc);
+    hipLaunchKernelGGL(dev::k_sign_scalars, dim3(1), dim3(dev::TPB), 0, stream, (const double*)W.sg_part.p, W.sg_npart, 1, sc);
     double* X = W.sgX.p;
     double* Xn = W.sgX2.p;
     for (int k = 0; k < dev::SIGN_STEPS; ++k) {
@@ -1108,7 +1123,7 @@ inline bool Solver::full_eig_by_sign(int idx, const double* xp_in, double* xp_ou
     if (fz) sym_gemm<dev::SG_FINAL, true>(W, W.sgA.p, X, nullptr, nullptr, 0, 0, 0, nullptr, W.sg_part.p, xp_out, xp_in, idx);
     else sym_gemm<dev::SG_FINAL, false>(W, W.sgA.p, X, nullptr, nullptr, 0, 0, 0, nullptr, W.sg_part.p, xp_out, nullptr, -1);
     hipLaunchKernelGGL(dev::k_sign_scalars, dim3(1), dim3(dev::TPB), 0, stream, (const double*)W.sg_part.p, grid, 2, sc);
-    hipLaunchKernelGGL(dev::k_sign_scalars, dim3(1), dim3(dev::TPB), 0, stream, (const double*)W.sg_part2.p, grid, 3, sc);
+    hipLaunchKernelGGL(dev::k_sign_scalars, dim3(1), dim3(dev::TPB), 0, stream, (const double*)W.sg_part2.p, W.sg_npart, 3, sc);
     if (prof) { PX_HIP(hipEventRecord(W.fe[1], stream)); PX_HIP(hipEventRecord(W.fe[2], stream)); W.fe_pending = true; }
     PX_HIP(hipMemcpyAsync(W.sg_host.p, sc, 16 * sizeof(double), hipMemcpyDeviceToHost, stream));
     PX_HIP(hipStreamSynchronize(stream));

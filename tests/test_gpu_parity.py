@@ -1008,11 +1008,13 @@ def test_sdplib_full_eig_fallback_config(fname, iters, golden_dir):
     o.max_iter = iters
     o.full_eig_decomp = True
     ref = oracle.solve(pr, o, trace=True)
-    # an explicit full_eig_decomp = true always takes the dense eigensolver, whatever full_eig_lanczos
+    # an explicit full_eig_decomp = true never goes to the Lanczos engine, whatever full_eig_lanczos
     # says in auto mode (the Lanczos-served full_eig! is for the IMPLICIT regime only, see
-    # test_implicit_full_eig_regime_served_by_lanczos)
-    for fel in (0, -1):
-        opt = Optimizer(max_iter=iters, full_eig_decomp=1, full_eig_lanczos=fel)
+    # test_implicit_full_eig_regime_served_by_lanczos).  full_eig_sign: 0 = rocSOLVER dsyevd + rank-r+
+    # reconstruction, 1 / auto = the sign-function projection (58 fp64 MFMA products, no eigenpairs);
+    # both reproduce the oracle's LAPACK trace.
+    for fel, sign in ((0, 0), (-1, 0), (0, 1), (-1, -1)):
+        opt = Optimizer(max_iter=iters, full_eig_decomp=1, full_eig_lanczos=fel, full_eig_sign=sign)
         sol = opt.optimize(pr, trace_capacity=iters)
         assert sol.status == ref.status == 3 and sol.iter == ref.iter == iters
         G, T = _trace_cols(ref.trace), sol.trace[:, [1, 2, 3, 4, 7, 11]]
@@ -1020,7 +1022,51 @@ def test_sdplib_full_eig_fallback_config(fname, iters, golden_dir):
         assert np.allclose(T, G, rtol=1e-6, atol=1e-8 * np.abs(G).max())
         assert sol.stats["full_eigs"] == iters
         assert sol.stats["lanczos_matvecs"] == 0 and sol.stats["full_eigs_lanczos"] == 0
+        assert sol.stats["full_eigs_sign"] == (iters if sign != 0 else 0)
+        assert sol.stats["sign_products"] == (58 * iters if sign != 0 else 0)
         assert sol.final_rank == ref.final_rank
+
+
+def _spectrum_cases(n, rng):
+    lam = {}
+    lam["gauss"] = rng.standard_normal(n) * 3
+    v = -np.abs(rng.standard_normal(n)); k = max(2, n // 6); v[:k] = np.abs(rng.standard_normal(k)) * 20 + 1
+    lam["lowrank_pos"] = v
+    v = rng.standard_normal(n); v[: n // 4] = 0.0
+    lam["zeros"] = v
+    v = rng.standard_normal(n); v[:5] = 36.83154802; v[5:10] = -2.5; v[10:14] = [1e-12, -1e-12, 3e-9, -3e-9]
+    lam["degenerate_tiny"] = v
+    lam["negdef"] = -np.abs(rng.standard_normal(n)) - 0.1
+    lam["posdef"] = np.abs(rng.standard_normal(n)) + 0.1
+    lam["null"] = np.zeros(n)
+    return lam
+
+
+@pytest.mark.parametrize("n", [33, 64, 100, 257, 501, 1000])
+def test_sign_function_projection_against_lapack(n):
+    """full_eig! by the matrix sign function (sign_project.hip.hpp; psd_project mode 4): X+ = (X + X sign X)/2
+    from 58 fp64 MFMA products, no eigenpairs.  Against LAPACK's projection: every |eigenvalue| >= 1e-10 ||X||
+    is resolved, smaller ones cost at most their own size; the count of positive eigenvalues comes from
+    tr S and tr S^2.  Cases: generic, low-rank positive part, a 25 % null space, repeated eigenvalues with
+    tiny ones next to zero, definite matrices, the zero matrix; sides that are not multiples of 32 / 64."""
+    rng = np.random.default_rng(n)
+    Qm, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    for name, lam in _spectrum_cases(n, rng).items():
+        X = (Qm * lam) @ Qm.T
+        X = (X + X.T) / 2
+        w, V = np.linalg.eigh(X)
+        ref = (V * np.maximum(w, 0.0)) @ V.T
+        out, info = B.psd_project(svec(X), n, 1, mode=4)
+        sc = max(np.abs(w).max(), 1e-300)
+        err = np.abs(out - svec(ref)).max() / sc
+        assert err <= 1e-9, (name, err)
+        assert info["nmatvec"] == 0 and info["min_eig"] == 0.0
+        if name in ("gauss", "lowrank_pos", "negdef", "posdef", "null"):
+            assert info["rank"] == int((lam > 0).sum()), name
+        elif name == "zeros":
+            assert info["rank"] == int((lam > 1e-7).sum()), name       # the exact null space counts as zero
+        dense, _ = B.psd_project(svec(X), n, 1, mode=1)
+        assert np.abs(out - dense).max() / sc <= 1e-9
 
 
 @pytest.mark.parametrize("n,seed", [(420, 1), (1000, 0)])
