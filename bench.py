@@ -76,6 +76,9 @@ def main():
                     help="time limit of the time-to-tol leg with REFERENCE DEFAULT options (0: skip)")
     ap.add_argument("--lanczos-warm-start", dest="lanczos_warm_start", type=int, default=None,
                     help="library-only: Lanczos start vector from the previous projection's Ritz vectors")
+    ap.add_argument("--no-rocsolver-leg", action="store_true",
+                    help="sdplib workload: skip the rocSOLVER dsyevd comparison legs (thousands of tiny kernels per call: "
+                         "not something to run under a kernel trace)")
     ap.add_argument("--full-eig-lanczos", dest="full_eig_lanczos", type=int, default=None,
                     help="library-only: 0 = full_eig! always through the dense eigensolver")
     ap.add_argument("--reconstruct-mfma", dest="reconstruct_mfma", type=int, default=None)
@@ -480,8 +483,10 @@ def bench_sdplib(args, torch, dist, rank, world, dev_id, backend):
 
     a, k1, t1 = leg("maxG51", -1)
     b, _, _ = leg("gpp500-1", -1)
-    a0, _, _ = leg("maxG51", 0)
-    b0, _, _ = leg("gpp500-1", 0)
+    a0 = b0 = None
+    if not args.no_rocsolver_leg:
+        a0, _, _ = leg("maxG51", 0)
+        b0, _, _ = leg("gpp500-1", 0)
     total_steps, t_steps = replicas.aggregate(dist, k1, t1, device="cuda" if dist is not None else "cpu")
     if rank == 0:
         print(json.dumps({

@@ -210,7 +210,7 @@ typedef struct proxsdp_options {
                                   * eigensolver call each: -1 auto (>= 2 blocks of side 2..32), 1 = every block of side
                                   * 2..64, 0 off */
     int32_t full_eig_sign;       /* full_eig! of a dense block without an eigendecomposition: X+ = (X + X sign(X)) / 2
-                                  * with sign(X) from an odd-polynomial iteration of fp64 MFMA products (58 products of
+                                  * with sign(X) from an odd-polynomial iteration of fp64 MFMA products (57 products of
                                   * n x n symmetric matrices; every |eigenvalue| >= 1e-10 ||X|| is resolved to 1e-15,
                                   * smaller ones contribute an error <= their own size): -1 auto (33 <= n <= 4096),
                                   * 1 always, 0 = rocSOLVER dsyevd + reconstruction */

@@ -1112,6 +1112,11 @@ inline bool Solver::full_eig_by_sign(int idx, const double* xp_in, double* xp_ou
         if (k == 0) {
             sym_gemm<dev::SG_POLY, false>(W, W.sgY.p, W.sgY.p, W.sgQ.p, W.sgY.p, c.a, c.b, c.c, sc + 8, nullptr, nullptr, nullptr, -1);
             sym_gemm<dev::SG_PLAIN, false>(W, W.sgA.p, W.sgQ.p, X, nullptr, 0, 0, 0, sc + 1, nullptr, nullptr, nullptr, -1);
+        } else if (last && dev::SIGN_LAST_CUBIC) {
+            // Q = (3 I - X X) / 2 straight from the product's epilogue (the Y term is switched off)
+            sym_gemm<dev::SG_POLY, false>(W, X, X, W.sgQ.p, X, 1.5, 0.0, -0.5, nullptr, nullptr, nullptr, nullptr, -1);
+            sym_gemm<dev::SG_PLAIN, false>(W, X, W.sgQ.p, Xn, nullptr, 0, 0, 0, nullptr, W.sg_part2.p, nullptr, nullptr, -1);
+            std::swap(X, Xn);
         } else {
             sym_gemm<dev::SG_PLAIN, false>(W, X, X, W.sgY.p, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, -1);
             sym_gemm<dev::SG_POLY, false>(W, W.sgY.p, W.sgY.p, W.sgQ.p, W.sgY.p, c.a, c.b, c.c, nullptr, nullptr, nullptr, nullptr, -1);

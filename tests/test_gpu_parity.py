@@ -1011,7 +1011,7 @@ def test_sdplib_full_eig_fallback_config(fname, iters, golden_dir):
     # an explicit full_eig_decomp = true never goes to the Lanczos engine, whatever full_eig_lanczos
     # says in auto mode (the Lanczos-served full_eig! is for the IMPLICIT regime only, see
     # test_implicit_full_eig_regime_served_by_lanczos).  full_eig_sign: 0 = rocSOLVER dsyevd + rank-r+
-    # reconstruction, 1 / auto = the sign-function projection (58 fp64 MFMA products, no eigenpairs);
+    # reconstruction, 1 / auto = the sign-function projection (57 fp64 MFMA products, no eigenpairs);
     # both reproduce the oracle's LAPACK trace.
     for fel, sign in ((0, 0), (-1, 0), (0, 1), (-1, -1)):
         opt = Optimizer(max_iter=iters, full_eig_decomp=1, full_eig_lanczos=fel, full_eig_sign=sign)
@@ -1023,7 +1023,7 @@ def test_sdplib_full_eig_fallback_config(fname, iters, golden_dir):
         assert sol.stats["full_eigs"] == iters
         assert sol.stats["lanczos_matvecs"] == 0 and sol.stats["full_eigs_lanczos"] == 0
         assert sol.stats["full_eigs_sign"] == (iters if sign != 0 else 0)
-        assert sol.stats["sign_products"] == (58 * iters if sign != 0 else 0)
+        assert sol.stats["sign_products"] == (57 * iters if sign != 0 else 0)
         assert sol.final_rank == ref.final_rank
 
 
@@ -1045,7 +1045,7 @@ def _spectrum_cases(n, rng):
 @pytest.mark.parametrize("n", [33, 64, 100, 257, 501, 1000])
 def test_sign_function_projection_against_lapack(n):
     """full_eig! by the matrix sign function (sign_project.hip.hpp; psd_project mode 4): X+ = (X + X sign X)/2
-    from 58 fp64 MFMA products, no eigenpairs.  Against LAPACK's projection: every |eigenvalue| >= 1e-10 ||X||
+    from 57 fp64 MFMA products, no eigenpairs.  Against LAPACK's projection: every |eigenvalue| >= 1e-10 ||X||
     is resolved, smaller ones cost at most their own size; the count of positive eigenvalues comes from
     tr S and tr S^2.  Cases: generic, low-rank positive part, a 25 % null space, repeated eigenvalues with
     tiny ones next to zero, definite matrices, the zero matrix; sides that are not multiples of 32 / 64."""
