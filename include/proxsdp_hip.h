@@ -214,6 +214,12 @@ typedef struct proxsdp_options {
                                   * n x n symmetric matrices; every |eigenvalue| >= 1e-10 ||X|| is resolved to 1e-15,
                                   * smaller ones contribute an error <= their own size): -1 auto (33 <= n <= 4096),
                                   * 1 always, 0 = rocSOLVER dsyevd + reconstruction */
+    int32_t psd_sign_engine;     /* 1: on the Krylov branch, let the sign-function projection stand in for the Lanczos
+                                  * engine when it is measured to be the cheaper way to the SAME matrix (fewer than
+                                  * target_rank positive eigenvalues => the truncated projection is the exact one and
+                                  * min_eig <= 0; verified after every such projection, redone by Lanczos otherwise).
+                                  * -1 auto = 0 = off: the reference's engine choice, mat-vec counts as KrylovKit's */
+    int32_t pad8;
 } proxsdp_options;
 
 #define PROXSDP_TRACE_COLS 14
@@ -259,6 +265,8 @@ typedef struct proxsdp_stats {
     int64_t warm_starts;         /* projections started from the previous Ritz vectors (lanczos_warm_start) */
     int64_t full_eigs_sign;      /* full_eig! calls served by the sign-function projection (full_eig_sign) */
     int64_t sign_products;       /* symmetric n x n matrix products (fp64 MFMA) those calls took */
+    int64_t sign_engine_projections; /* Krylov-branch projections served by the sign function (psd_sign_engine) */
+    int64_t sign_engine_rejected;    /* ... computed but discarded: truncation was active, Lanczos redid them */
 } proxsdp_stats;
 
 /* Result (structs.jl:60-81).  Arrays are caller-allocated with the stated

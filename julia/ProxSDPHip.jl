@@ -98,6 +98,8 @@ struct Stats                     # proxsdp_stats
     warm_starts::Int64
     full_eigs_sign::Int64
     sign_products::Int64
+    sign_engine_projections::Int64
+    sign_engine_rejected::Int64
 end
 
 mutable struct CResult           # proxsdp_result

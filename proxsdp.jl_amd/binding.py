@@ -105,7 +105,7 @@ def _opt_fields():
     a("device_id", i32); a("trace_capacity", i32); a("profile_symv_every", i32); a("support_path", i32)
     a("lanczos_operator", i32); a("initial_target_rank", i32)
     a("full_eig_lanczos", i32); a("lanczos_cycle_kernel", i32); a("lanczos_warm_start", i32)
-    a("reconstruct_mfma", i32); a("small_block_batch", i32); a("full_eig_sign", i32)
+    a("reconstruct_mfma", i32); a("small_block_batch", i32); a("full_eig_sign", i32); a("psd_sign_engine", i32); a("pad8", i32)
     return F
 
 
@@ -124,7 +124,8 @@ class Stats(C.Structure):
                 ("mfma_reconstructions", i64), ("orth_profiled", i64), ("orth_profiled_ms", f64),
                 ("full_eig_solver_ms", f64), ("full_eig_recon_ms", f64), ("cycle_launches", i64),
                 ("full_eigs_lanczos", i64), ("cycle_steps", i64), ("cycle_ms", f64), ("warm_starts", i64),
-                ("full_eigs_sign", i64), ("sign_products", i64)]
+                ("full_eigs_sign", i64), ("sign_products", i64),
+                ("sign_engine_projections", i64), ("sign_engine_rejected", i64)]
 
 
 class Result(C.Structure):

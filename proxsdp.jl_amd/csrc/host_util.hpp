@@ -457,7 +457,7 @@ inline const std::vector<OptEntry>& option_table() {
         PX_OPT(device_id, OT_I32), PX_OPT(trace_capacity, OT_I32), PX_OPT(profile_symv_every, OT_I32),
         PX_OPT(support_path, OT_I32), PX_OPT(lanczos_operator, OT_I32), PX_OPT(initial_target_rank, OT_I32),
         PX_OPT(full_eig_lanczos, OT_I32), PX_OPT(lanczos_cycle_kernel, OT_I32), PX_OPT(lanczos_warm_start, OT_I32),
-        PX_OPT(reconstruct_mfma, OT_I32), PX_OPT(small_block_batch, OT_I32), PX_OPT(full_eig_sign, OT_I32),
+        PX_OPT(reconstruct_mfma, OT_I32), PX_OPT(small_block_batch, OT_I32), PX_OPT(full_eig_sign, OT_I32), PX_OPT(psd_sign_engine, OT_I32),
     };
     return t;
 }
@@ -496,7 +496,7 @@ inline void default_options(proxsdp_options* o) {      // options.jl:1-132
     o->device_id = 0; o->trace_capacity = 0; o->profile_symv_every = 0; o->support_path = -1;
     o->lanczos_operator = -1; o->initial_target_rank = 2;
     o->full_eig_lanczos = -1; o->lanczos_cycle_kernel = -1; o->lanczos_warm_start = 0; o->reconstruct_mfma = -1;
-    o->small_block_batch = -1; o->full_eig_sign = -1;
+    o->small_block_batch = -1; o->full_eig_sign = -1; o->psd_sign_engine = -1;
 }
 
 inline int set_option(proxsdp_options* o, const char* name, double v) {

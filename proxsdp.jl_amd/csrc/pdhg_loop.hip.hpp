@@ -109,7 +109,13 @@ inline void Solver::project_block(int idx, const double* xin, double* xout, bool
     }
     const bool used_fop = W.use_fop;
     const int nev = (int)target_rank[idx];
+    if (exact_projection_by_sign(idx, xp, xo, fuse, nev)) return;
+    const double t_kry = opt.psd_sign_engine == 1 ? now_s() : 0.0;
     lanczos(W, xp, nev);
+    if (opt.psd_sign_engine == 1 && W.converged) {
+        const double ms = (now_s() - t_kry) * 1e3;
+        W.kry_ms = W.kry_ms < 0 ? ms : 0.75 * W.kry_ms + 0.25 * ms;
+    }
     W.use_fop = false;
     if (used_fop) W.lst.fop_projections++;
     if (!W.converged) {                       // prox_operators.jl:55-57
@@ -142,6 +148,58 @@ inline void Solver::project_block(int idx, const double* xin, double* xout, bool
         std::swap(W.lam.n, W.Flam.n);
         W.have_factors = true; W.x_prev_sparse = false;
     }
+}
+
+// psd_sign_engine = 1: the Krylov branch computes the top target_rank eigenpairs and keeps the positive ones
+// (prox_operators.jl:89-109).  Whenever fewer than target_rank eigenvalues are positive that IS the exact
+// projection, min_eig (the smallest returned value) is <= 0, and the two decisions min_eig feeds
+// (pdhg.jl:272 `> tol_psd`, residuals.jl:93 `< tol_psd`) are settled -- so the sign-function projection
+// (sign_project.hip.hpp) may stand in for the Lanczos engine when it is the cheaper way to the same matrix:
+// hub-row / clustered spectra that cost hundreds of mat-vecs per projection (maxG51: 541), many mid-size
+// blocks (MIMO).  It is chosen per block from measured wall-clock averages of both engines, only when the
+// previous projection was not truncated, and VERIFIED afterwards: #{lambda > 0} >= target_rank means the
+// reference would have truncated, and the projection is redone by the Lanczos engine.
+inline double sign_cost_model_ms(int ld) {                   // measured on MI355X (profiles/r02c_sign_projection_summary.md)
+    static const int L[] = {128, 512, 1024, 1536, 2048, 3072, 4096};
+    static const double T[] = {0.30, 0.60, 2.05, 4.8, 11.3, 31.2, 71.2};
+    if (ld <= L[0]) return T[0];
+    for (int i = 1; i < 7; ++i)
+        if (ld <= L[i]) return T[i - 1] + (T[i] - T[i - 1]) * (double)(ld - L[i - 1]) / (L[i] - L[i - 1]);
+    return T[6] * std::pow((double)ld / 4096.0, 3.0);
+}
+inline bool Solver::exact_projection_by_sign(int idx, const double* xp, double* xo, bool fuse, int nev) {
+    if (opt.psd_sign_engine != 1) return false;
+    EigWork& W = eig[idx];
+    if (W.n < 33 || W.n > 4096) return false;
+    if (W.kry_ms < 0.0 || W.last_npos < 0) return false;                  // no Lanczos measurement of this block yet
+    if (W.last_npos >= nev) return false;                                 // truncation was active last time: the reference's engine decides
+    if (W.sign_backoff > 0) { --W.sign_backoff; return false; }           // after a rejected attempt
+    const double est = W.sign_ms >= 0.0 ? W.sign_ms : sign_cost_model_ms(W.nt * dev::TILE);
+    if (W.kry_ms < 1.5 * est) { W.sign_streak = 0; return false; }
+    if (W.sign_streak >= 256) { W.sign_streak = 0; return false; }        // re-measure the Lanczos engine now and then
+    const bool inplace = xp == xo;
+    double* out = xo;
+    if (inplace) {                                                        // keep the input: the check below may reject
+        if (W.sg_out.n < (size_t)W.N) W.sg_out.alloc(W.N);
+        out = W.sg_out.p;
+    }
+    const double t0 = now_s();
+    if (!full_eig_by_sign(idx, xp, out, fuse, true)) return false;
+    const double ms = (now_s() - t0) * 1e3;
+    W.sign_ms = W.sign_ms < 0 ? ms : 0.75 * W.sign_ms + 0.25 * ms;
+    const int npos = (int)current_rank[idx];
+    if (npos >= nev) {                                                    // truncation would be active: not the same projection
+        W.lst.sign_engine_rejected++;
+        current_rank[idx] = 0;
+        W.sign_backoff = 32;
+        return false;
+    }
+    if (inplace) PX_HIP(hipMemcpyAsync(xo, out, (size_t)W.N * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    W.lst.sign_engine_projections++;
+    W.sign_streak++;
+    min_eig[idx] = 0.0;                 // the reference's value is lambda_min of the returned pairs, <= 0: same decisions
+    W.have_factors = false; W.x_prev_sparse = false; W.use_fop = false;
+    return true;
 }
 
 // full_eig! needs X+ = sum over lambda_i > 0 of lambda_i v_i v_i' -- every POSITIVE eigenpair, not

@@ -196,6 +196,11 @@ struct EigWork {
     int sg_npart = 0;
     bool sg_small = false;                         // products on 32 x 32 tiles (blocks up to side 3072)
     bool sg_pending = false;                       // fe[] hold a sign projection's events (all of it is "solver")
+    // cost-based engine choice on the Krylov branch (psd_sign_engine): wall-clock averages of this block's
+    // Lanczos and sign projections, projections since the last Lanczos probe, scratch for in-place calls
+    double kry_ms = -1.0, sign_ms = -1.0;
+    int sign_streak = 0, sign_backoff = 0;
+    DevBuf<double> sg_out;
 };
 
 
@@ -385,7 +390,8 @@ private:
                    const double* old, const double* addc, double* normpart, long long cstride);
     void full_eig_project(int idx, const double* xp_in, double* xp_out, bool fuse);
     bool full_eig_by_lanczos(int idx, const double* xp_in, double* xp_out, bool fuse);
-    bool full_eig_by_sign(int idx, const double* xp_in, double* xp_out, bool fuse);
+    bool full_eig_by_sign(int idx, const double* xp_in, double* xp_out, bool fuse, bool force = false);
+    bool exact_projection_by_sign(int idx, const double* xp, double* xo, bool fuse, int nev);
     template <int EPI, bool FUSE>
     void sym_gemm(EigWork& W, const double* Pm, const double* Qm, double* T, const double* Y, double ca, double cb,
                   double cc, const double* dsc, double* part, double* xp_out, const double* xp_old, int blk);
@@ -1071,11 +1077,13 @@ inline void Solver::sym_gemm(EigWork& W, const double* Pm, const double* Qm, dou
 // iteration of fp64 MFMA products (sign_project.hip.hpp).  current_rank = #{lambda > 0} =
 // (tr S + tr S^2) / 2 (the reference counts lambda > tol_psd: eigenvalues in (0, tol_psd] are the only
 // difference, and the count only feeds Result.final_rank on this path: min_eig = 0 blocks bump_rank).
-inline bool Solver::full_eig_by_sign(int idx, const double* xp_in, double* xp_out, bool fuse) {
+inline bool Solver::full_eig_by_sign(int idx, const double* xp_in, double* xp_out, bool fuse, bool force) {
     EigWork& W = eig[idx];
     const int n = W.n;
-    if (opt.full_eig_sign == 0) return false;
-    if (opt.full_eig_sign < 0 && (n < 33 || n > 4096)) return false;     // auto: measured window
+    if (!force) {
+        if (opt.full_eig_sign == 0) return false;
+        if (opt.full_eig_sign < 0 && (n < 33 || n > 4096)) return false;     // auto: measured window
+    }
     const int ld = W.nt * dev::TILE;
     const int ntile = W.nt * (W.nt + 1) / 2, grid = 8 * ceil_div(ntile, 8);
     if (W.sg_ld != ld) {
@@ -1135,7 +1143,7 @@ inline bool Solver::full_eig_by_sign(int idx, const double* xp_in, double* xp_ou
     const double tr = W.sg_host.p[5], fro2 = W.sg_host.p[7];
     if (!std::isfinite(tr) || !std::isfinite(fro2)) throw HipError("sign-function projection produced non-finite values");
     const int npos = (int)std::llround(0.5 * (tr + fro2));
-    W.lst.full_eigs++; W.lst.full_eigs_sign++;
+    if (!force) { W.lst.full_eigs++; W.lst.full_eigs_sign++; }
     current_rank[idx] = std::max(0, std::min(npos, n));
     min_eig[idx] = 0.0;                                      // prox_operators.jl:114
     W.last_npos = current_rank[idx];
@@ -1254,7 +1262,7 @@ inline void Solver::merge_block_stats() {
         st.symv_profiled += a.symv_profiled; st.symv_profiled_ms += a.symv_profiled_ms;
         st.orth_profiled += a.orth_profiled; st.orth_profiled_ms += a.orth_profiled_ms;
         st.full_eig_solver_ms += a.full_eig_solver_ms; st.full_eig_recon_ms += a.full_eig_recon_ms;
-        st.full_eigs_lanczos += a.full_eigs_lanczos; st.full_eigs_sign += a.full_eigs_sign; st.sign_products += a.sign_products; st.warm_starts += a.warm_starts; st.device_eigs += a.device_eigs; st.mfma_reconstructions += a.mfma_reconstructions; st.cycle_launches += a.cycle_launches;
+        st.full_eigs_lanczos += a.full_eigs_lanczos; st.full_eigs_sign += a.full_eigs_sign; st.sign_products += a.sign_products; st.sign_engine_projections += a.sign_engine_projections; st.sign_engine_rejected += a.sign_engine_rejected; st.warm_starts += a.warm_starts; st.device_eigs += a.device_eigs; st.mfma_reconstructions += a.mfma_reconstructions; st.cycle_launches += a.cycle_launches;
         st.cycle_steps += a.cycle_steps; st.cycle_ms += a.cycle_ms;
         st.symv_bytes += a.symv_bytes; st.host_eig_time += a.host_eig_time; st.host_eigs += a.host_eigs;
         st.fop_projections += a.fop_projections;

@@ -1027,6 +1027,30 @@ def test_sdplib_full_eig_fallback_config(fname, iters, golden_dir):
         assert sol.final_rank == ref.final_rank
 
 
+def test_sign_engine_on_the_krylov_branch_reproduces_the_lanczos_solve(golden_dir):
+    """psd_sign_engine = 1: when fewer than target_rank eigenvalues are positive, the truncated projection of
+    prox_operators.jl:89-109 IS the exact one and min_eig <= 0, so the sign-function projection may replace the
+    Lanczos engine where it is measured to be cheaper (mcp250-1 needs ~100 mat-vecs per projection late in the
+    solve).  Same linesearch decisions, same optimum, iteration count within rounding; every stand-in is verified
+    (#positive < target_rank) or redone by Lanczos.  Opt-in: with REPEATED positive eigenvalues (MIMO's first
+    iterates) single-vector Lanczos returns one copy per distinct eigenvalue, i.e. the reference's projection is
+    not the exact one there, and the knob would change the trajectory (tools/gpurun_engine.py)."""
+    pr = P.sdplib(golden_dir / "sdplib" / "mcp250-1.dat-s")
+    a = Optimizer(tol_gap=1e-4, tol_feasibility=1e-4).optimize(pr, trace_capacity=20000)
+    b = Optimizer(tol_gap=1e-4, tol_feasibility=1e-4, psd_sign_engine=1).optimize(pr, trace_capacity=20000)
+    # the two engines agree to rounding per projection; over ~4000 iterations that moves the stopping test by a
+    # few iterations (measured 4264 vs 4268; mcp500-1: 5645 = 5645, objective to 4e-14)
+    assert a.status == b.status == 1 and abs(a.iter - b.iter) <= 0.01 * a.iter
+    assert a.stats["sign_engine_projections"] == 0 and b.stats["sign_engine_projections"] > 100
+    assert b.stats["lanczos_matvecs"] < a.stats["lanczos_matvecs"]
+    m = min(a.iter, b.iter, 2000)
+    assert np.array_equal(a.trace[:m, 11], b.trace[:m, 11])              # linesearch trials per iteration
+    sc = np.abs(a.trace[:m, 1:5]).max(axis=0)
+    assert np.allclose(a.trace[:m, 1:5], b.trace[:m, 1:5], rtol=0, atol=1e-6 * sc)
+    assert abs(a.objval - b.objval) <= 1e-5 * (1 + abs(a.objval))
+    assert a.final_rank == b.final_rank
+
+
 def _spectrum_cases(n, rng):
     lam = {}
     lam["gauss"] = rng.standard_normal(n) * 3
