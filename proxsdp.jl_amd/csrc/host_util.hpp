@@ -13,6 +13,7 @@
 //                       (/root/reference/src/MOI_wrapper.jl:84-103).
 #pragma once
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdint>
@@ -137,17 +138,23 @@ inline void householder_tridiag(int n, double* a, double* d, double* e) {
 }
 
 // ---- helper threads for the eigenvector accumulation of large Rayleigh quotients -----------------
-// At K = 127 (target rank 63) one QL eigensolve is ~0.9 ms of which the scalar rotation recurrence
-// (sqrt / divide chain on d, e) is ~0.3 ms and applying the ~14 000 rotations to the K x K eigenvector
+// At K = 127 (target rank 63) one QL eigensolve is ~0.41 ms of which the scalar rotation recurrence
+// (sqrt / divide chain on d, e) is ~0.18 ms and applying the ~14 000 rotations to the K x K eigenvector
 // matrix the rest.  The recurrence never reads the eigenvector matrix, so the calling thread runs it
 // ALONE, logging every sweep's rotations, while a few helper threads replay the log on disjoint ROW
-// SLICES of the matrix (rows are independent under column rotations).  Every entry sees exactly the
-// arithmetic of the serial loop: bit-identical results.  Helpers sleep on a condition variable
-// between eigensolves and spin only while one is in flight.  PROXSDP_HIP_EIG_THREADS (default 0 =
-// serial; used from n >= 96).  MEASURED ON THE MI355X BOX (256 hardware threads, rank-63 window):
-// 2 / 4 / 8 helpers make the eigensolve 6-9x SLOWER (3.7-5.1 ms instead of 0.56 ms per iteration:
-// condition-variable wake-ups and cross-core traffic on 127-row columns), so the helpers are OFF
-// by default; the code is kept because it is bit-identical and may pay on hosts with cheap wake-ups.
+// SLICES of the matrix as it is produced (rows are independent under column rotations).  Every entry
+// sees exactly the arithmetic of the serial loop: bit-identical results.
+// Round 2, first version: helpers slept on a condition variable between eigensolves and the caller slept
+// until they were done -- MEASURED ON THE MI355X BOX (256 hardware threads): 6-9x SLOWER than serial
+// (3.7-5.1 ms instead of 0.56 ms per iteration), because idle cores sit in deep C-states and every wake-up
+// costs up to a millisecond.  Second version (this one) never sleeps on the critical path: the pool is ARMED
+// when a projection with a large Krylov dimension starts, armed helpers spin on the job counter and stay
+// hot for 20 ms after the last job, the caller spins on the completion counter.  MEASURED AGAIN on the same
+// box (tools/gpurun_eigthreads.py): still 5x slower (K = 127 standalone 0.97 -> 4.6 / 4.9 / 4.9 / 6.8 ms
+// with 1 / 2 / 4 / 8 helpers; rank-63 window 359 -> 92-162 it/s) -- streaming ~3500 freshly written cache
+// lines of rotation log from the producing core to cores on other CCDs / the other socket costs more than
+// the 0.23 ms of arithmetic it spreads.  PROXSDP_HIP_EIG_THREADS therefore defaults to 0 (serial); the code
+// stays because it is bit-identical and tested, for hosts where the cores share a cache.
 struct QlSweep { int lo, hi, off; };                     // rotations i = hi-1 .. lo, (c, s) at log[off + (hi-1-i)]
 struct QlJob {
     int n = 0;
@@ -156,7 +163,7 @@ struct QlJob {
     const double* cs = nullptr;                          // interleaved c, s
     std::atomic<int> ready{0};                           // sweeps published so far
     std::atomic<int> total{-1};                          // number of sweeps, once known
-    int parts = 1;                                       // row slices: 0 = the caller, 1.. = the helpers
+    int parts = 1;                                       // row slices, one per helper
 };
 inline void ql_replay(const QlJob& J, int r0, int r1) {
     const int n = J.n;
@@ -196,67 +203,98 @@ public:
     void ensure(int t) {
         if (!busy_.try_lock()) return;
         t = std::min(t, 16);
-        while ((int)th_.size() < t) { const int i = (int)th_.size(); th_.emplace_back([this, i]() { loop(i); }); }
+        // (no job can be in flight while busy_ is held: a new helper starts from the current job counter)
+        while ((int)th_.size() < t) {
+            const int i = (int)th_.size();
+            const long long g0 = gen_.load(std::memory_order_acquire);
+            th_.emplace_back([this, i, g0]() { loop(i, g0); });
+        }
         busy_.unlock();
     }
-    // run job J on the helpers (row slices 1..T of T+1; slice 0 is replayed by the caller afterwards)
+    // helpers leave their condition variable and spin for the next 20 ms (called when a projection with a
+    // large Krylov dimension starts, and by start())
+    void arm() {
+        if (th_.empty()) return;
+        armed_until_.store(now_ns() + 20000000LL, std::memory_order_release);
+        if (sleepers_.load(std::memory_order_acquire) > 0) {
+            std::lock_guard<std::mutex> lk(mu_);
+            cv_.notify_all();
+        }
+    }
+    // run job J on the helpers: every row of the matrix belongs to one helper's slice
     bool start(QlJob* J) {
         if (th_.empty() || !busy_.try_lock()) return false;
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            J->parts = (int)th_.size() + 1;
-            job_ = J; ++gen_; pending_ = (int)th_.size();
-        }
-        cv_.notify_all();
+        J->parts = (int)th_.size();
+        done_.store(0, std::memory_order_relaxed);
+        job_.store(J, std::memory_order_release);
+        gen_.fetch_add(1, std::memory_order_acq_rel);
+        arm();
         return true;
     }
     void finish() {
-        std::unique_lock<std::mutex> lk(mu_);
-        done_cv_.wait(lk, [this]() { return pending_ == 0; });
-        job_ = nullptr;
-        lk.unlock();
+        const int t = (int)th_.size();
+        while (done_.load(std::memory_order_acquire) < t) {
+#if defined(__x86_64__)
+            _mm_pause();
+#endif
+        }
+        job_.store(nullptr, std::memory_order_release);
         busy_.unlock();
     }
 private:
+    static long long now_ns() {
+        return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    }
     QlPool() {
         const char* e = std::getenv("PROXSDP_HIP_EIG_THREADS");
-        int t = e ? std::atoi(e) : 0;
         const int hw = (int)std::thread::hardware_concurrency();
+        int t = e ? std::atoi(e) : 0;
         if (hw > 0) t = std::min(t, std::max(0, hw - 2));
         t = std::max(0, std::min(t, 16));
-        for (int i = 0; i < t; ++i) th_.emplace_back([this, i]() { loop(i); });
+        for (int i = 0; i < t; ++i) th_.emplace_back([this, i]() { loop(i, 0); });
     }
     ~QlPool() {
-        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        { std::lock_guard<std::mutex> lk(mu_); stop_.store(true); }
         cv_.notify_all();
         for (auto& t : th_) if (t.joinable()) t.join();
     }
-    void loop(int idx) {
-        long long seen = 0;
+    void loop(int idx, long long seen) {
+        unsigned spins = 0;
         for (;;) {
-            QlJob* J;
-            {
-                std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [&]() { return stop_ || gen_ != seen; });
-                if (stop_) return;
-                seen = gen_; J = job_;
+            const long long g = gen_.load(std::memory_order_acquire);
+            if (g != seen) {
+                seen = g;
+                QlJob* J = job_.load(std::memory_order_acquire);
+                if (J != nullptr && idx < J->parts) {
+                    const int parts = J->parts, n = J->n;
+                    ql_replay(*J, (int)((long long)n * idx / parts), (int)((long long)n * (idx + 1) / parts));
+                }
+                done_.fetch_add(1, std::memory_order_acq_rel);
+                continue;
             }
-            const int parts = J->parts, n = J->n;
-            const int r0 = (int)((long long)n * (idx + 1) / parts), r1 = (int)((long long)n * (idx + 2) / parts);
-            ql_replay(*J, r0, r1);
-            {
-                std::lock_guard<std::mutex> lk(mu_);
-                if (--pending_ == 0) done_cv_.notify_all();
+            if (stop_.load(std::memory_order_relaxed)) return;
+#if defined(__x86_64__)
+            _mm_pause();
+#endif
+            if ((++spins & 1023u) == 0 && now_ns() > armed_until_.load(std::memory_order_acquire)) {
+                std::unique_lock<std::mutex> lk(mu_);
+                sleepers_.fetch_add(1, std::memory_order_acq_rel);
+                cv_.wait(lk, [&]() {
+                    return stop_.load() || gen_.load(std::memory_order_acquire) != seen ||
+                           now_ns() <= armed_until_.load(std::memory_order_acquire);
+                });
+                sleepers_.fetch_sub(1, std::memory_order_acq_rel);
+                if (stop_.load()) return;
             }
         }
     }
     std::vector<std::thread> th_;
     std::mutex mu_, busy_;
-    std::condition_variable cv_, done_cv_;
-    QlJob* job_ = nullptr;
-    long long gen_ = 0;
-    int pending_ = 0;
-    bool stop_ = false;
+    std::condition_variable cv_;
+    std::atomic<QlJob*> job_{nullptr};
+    std::atomic<long long> gen_{0}, armed_until_{0};
+    std::atomic<int> done_{0}, sleepers_{0};
+    std::atomic<bool> stop_{false};
 };
 
 // Phase 2: implicit-shift QL on the tridiagonal (d, e as left by phase 1), accumulating the
@@ -313,7 +351,7 @@ inline int ql_implicit(int n, double* a, double* d, double* e_in, int threads = 
                 const size_t off = cslog.size() / 2;
                 if (logged && cslog.size() + 2 * (size_t)(m - l) > cslog.capacity()) {
                     // (never expected: 4 n^2 rotations reserved; finish serially if it happens)
-                    if (started) { job.total.store(nsweep, std::memory_order_release); ql_replay(job, 0, n / job.parts); QlPool::get().finish(); started = false; }
+                    if (started) { job.total.store(nsweep, std::memory_order_release); QlPool::get().finish(); started = false; }
                     else { job.total.store(nsweep, std::memory_order_release); ql_replay(job, 0, n); }
                     logged = false;
                 }
@@ -359,8 +397,7 @@ inline int ql_implicit(int n, double* a, double* d, double* e_in, int threads = 
     if (logged) {
         job.total.store(nsweep, std::memory_order_release);
         if (started) {
-            ql_replay(job, 0, n / job.parts);                         // the caller's own row slice
-            QlPool::get().finish();
+            QlPool::get().finish();                                    // (spins: the helpers trail the recurrence closely)
         } else {
             ql_replay(job, 0, n);                                      // pool busy (another solver thread): serial replay
         }

@@ -758,6 +758,7 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive
         krylovdim = std::min(W.cap - 1, std::max(krylovdim, nev * mult10 / 10 + 8));
     }
     if (krylovdim + 1 > W.cap) throw std::invalid_argument("Lanczos workspace too small for the requested rank");
+    if (krylovdim >= 96) QlPool::get().arm();            // host eigensolve helpers wake up under the first Lanczos cycle
     const double tol = arpack ? opt.arpack_tol : opt.krylovkit_tol;
     const long long maxiter = arpack ? (long long)opt.arpack_max_iter : (long long)opt.krylovkit_max_iter;
     if (!arpack && opt.krylovkit_eager) throw std::invalid_argument("krylovkit_eager=true is not implemented");
