@@ -242,6 +242,19 @@ def main():
         out["time_to_tol_warm_start"] = tol_leg(time_limit=300.0, max_target_rank_krylov_eigs=args.krylov_rank,
                                                 lanczos_warm_start=1)
 
+    if solo and not args.no_time_to_tol:
+        # full_eig! regime at the metric's size (what the reference falls into with default options once
+        # target_rank > 16): sign-function projection (57 fp64 MFMA products) vs rocSOLVER dsyevd, 12 iterations each
+        def fe_leg(sign):
+            o3 = Optimizer(max_iter=12, device_id=dev_id, full_eig_decomp=1, full_eig_sign=sign, profile_symv_every=1)
+            s3 = o3.optimize(pr, trace_capacity=12)
+            st3 = s3.stats
+            return {"ms_per_step": 1e3 * float(s3.trace[11, 12] - s3.trace[1, 12]) / 10.0,
+                    "projection_ms_per_step": st3["full_eig_solver_ms"] / max(1, int(s3.iter)),
+                    "reconstruction_ms_per_step": st3["full_eig_recon_ms"] / max(1, int(s3.iter)),
+                    "sign_products": int(st3["sign_products"]), "full_eigs": int(st3["full_eigs"])}
+        out["full_eig_regime_n4000"] = {"sign_function": fe_leg(1), "rocsolver_dsyevd": fe_leg(0)}
+
     if solo and not args.no_cpu:
         import oracle                                           # baseline leg only
         ncores = os.cpu_count() or 1

@@ -1027,6 +1027,24 @@ def test_sdplib_full_eig_fallback_config(fname, iters, golden_dir):
         assert sol.final_rank == ref.final_rank
 
 
+def test_sign_function_projection_on_64_tiles_large_block():
+    """Blocks wider than 3072 run the products on the 64 x 64-tile kernel (k_sym_gemm<SG_PLAIN / SG_POLY>; smaller
+    ones only use it for the final product): n = 3100 against LAPACK, forced through psd_project mode 4."""
+    n = 3100
+    rng = np.random.default_rng(7)
+    for name in ("gauss", "lowrank_pos"):
+        if name == "gauss":
+            M = rng.standard_normal((n, n)); X = (M + M.T) / 2
+        else:
+            Z = rng.standard_normal((n, 40)); M = rng.standard_normal((n, n)) * 0.05
+            X = Z @ Z.T - (M @ M.T)                                  # 40 large positive directions over a negative bulk
+        w, V = np.linalg.eigh(X)
+        ref = (V * np.maximum(w, 0.0)) @ V.T
+        out, info = B.psd_project(svec(X), n, 1, mode=4)
+        assert np.abs(out - svec(ref)).max() <= 1e-9 * np.abs(w).max(), name
+        assert info["rank"] == int((w > 0).sum())
+
+
 def test_sign_engine_on_the_krylov_branch_reproduces_the_lanczos_solve(golden_dir):
     """psd_sign_engine = 1: when fewer than target_rank eigenvalues are positive, the truncated projection of
     prox_operators.jl:89-109 IS the exact one and min_eig <= 0, so the sign-function projection may replace the
