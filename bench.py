@@ -436,7 +436,7 @@ def bench_randsdp(args, torch, dist, rank, world, dev_id, backend):
 def bench_sdplib(args, torch, dist, rank, world, dev_id, backend):
     """BASELINE config 5: SDPLIB maxG51 / gpp500-1 (test/base_sdplib.jl model) on the FULL-RANK
     fallback eig path, full_eig_decomp = true: every iteration is full_eig! (prox_operators.jl:111-126) =
-    by default the sign-function projection (58 fp64 MFMA products, sign_project.hip.hpp); beside it the
+    by default the sign-function projection (57 fp64 MFMA products, sign_project.hip.hpp); beside it the
     dense eigensolver (rocSOLVER dsyevd) + rank-r+ reconstruction (full_eig_sign = 0).
     Single PSD block: replicas for N > 1.  value = iterations/s of maxG51; gpp500-1 beside it."""
     from proxsdp_jl_amd import problems, replicas

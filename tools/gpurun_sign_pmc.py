@@ -1,5 +1,5 @@
 """Isolated sign-function projections for the PMC passes: one projection each at n = 501, 1000, 2000, 4000
-(58 products each: k_sym_gemm32 up to side 3072, k_sym_gemm above and for the final product)."""
+(57 products each: k_sym_gemm32 up to side 3072, k_sym_gemm above and for the final product)."""
 import sys
 import numpy as np
 sys.path.insert(0, ".")
