@@ -549,7 +549,7 @@ def bench_mimo(args, torch, dist, rank, world, dev_id, backend):
     sync()
     t0 = time.time()
     if dist is None:
-        opt = Optimizer(max_iter=W + K, device_id=dev_id, support_path=args.support_path)
+        opt = Optimizer(max_iter=W + K, device_id=dev_id, support_path=args.support_path, **extra_opts(args))
         sol = opt.optimize(model, trace_capacity=W + K)
     else:
         cdev = torch.device("cuda", dev_id) if backend == "nccl" else None
