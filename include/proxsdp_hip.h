@@ -217,7 +217,10 @@ typedef struct proxsdp_options {
     int32_t psd_sign_engine;     /* 1: on the Krylov branch, let the sign-function projection stand in for the Lanczos
                                   * engine when it is measured to be the cheaper way to the SAME matrix (fewer than
                                   * target_rank positive eigenvalues => the truncated projection is the exact one and
-                                  * min_eig <= 0; verified after every such projection, redone by Lanczos otherwise).
+                                  * min_eig <= 0; verified after every such projection, redone by Lanczos otherwise;
+                                  * on first use and every 64th projection BOTH engines run on the same input and a
+                                  * disagreement -- repeated eigenvalues, of which single-vector Lanczos returns one
+                                  * copy -- leaves the block to the Lanczos engine for the rest of the solve).
                                   * -1 auto = 0 = off: the reference's engine choice, mat-vec counts as KrylovKit's */
     int32_t pad8;
 } proxsdp_options;
@@ -267,6 +270,8 @@ typedef struct proxsdp_stats {
     int64_t sign_products;       /* symmetric n x n matrix products (fp64 MFMA) those calls took */
     int64_t sign_engine_projections; /* Krylov-branch projections served by the sign function (psd_sign_engine) */
     int64_t sign_engine_rejected;    /* ... computed but discarded: truncation was active, Lanczos redid them */
+    int64_t sign_engine_checks;      /* verification rounds (both engines on the same input; first use, then every 64th) */
+    int64_t sign_engine_mismatches;  /* ... that disagreed (repeated eigenvalues): the block stays with Lanczos */
 } proxsdp_stats;
 
 /* Result (structs.jl:60-81).  Arrays are caller-allocated with the stated

@@ -100,6 +100,8 @@ struct Stats                     # proxsdp_stats
     sign_products::Int64
     sign_engine_projections::Int64
     sign_engine_rejected::Int64
+    sign_engine_checks::Int64
+    sign_engine_mismatches::Int64
 end
 
 mutable struct CResult           # proxsdp_result

@@ -125,7 +125,8 @@ class Stats(C.Structure):
                 ("full_eig_solver_ms", f64), ("full_eig_recon_ms", f64), ("cycle_launches", i64),
                 ("full_eigs_lanczos", i64), ("cycle_steps", i64), ("cycle_ms", f64), ("warm_starts", i64),
                 ("full_eigs_sign", i64), ("sign_products", i64),
-                ("sign_engine_projections", i64), ("sign_engine_rejected", i64)]
+                ("sign_engine_projections", i64), ("sign_engine_rejected", i64),
+                ("sign_engine_checks", i64), ("sign_engine_mismatches", i64)]
 
 
 class Result(C.Structure):

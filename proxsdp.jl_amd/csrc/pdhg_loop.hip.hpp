@@ -148,6 +148,7 @@ inline void Solver::project_block(int idx, const double* xin, double* xout, bool
         std::swap(W.lam.n, W.Flam.n);
         W.have_factors = true; W.x_prev_sparse = false;
     }
+    if (W.sign_check_pending) verify_sign_engine(idx, xo);
 }
 
 // psd_sign_engine = 1: the Krylov branch computes the top target_rank eigenpairs and keeps the positive ones
@@ -170,6 +171,7 @@ inline double sign_cost_model_ms(int ld) {                   // measured on MI35
 inline bool Solver::exact_projection_by_sign(int idx, const double* xp, double* xo, bool fuse, int nev) {
     if (opt.psd_sign_engine != 1) return false;
     EigWork& W = eig[idx];
+    W.sign_check_pending = false;                                         // (a verification whose Lanczos half fell back)
     if (W.n < 33 || W.n > 4096) return false;
     if (W.kry_ms < 0.0 || W.last_npos < 0) return false;                  // no Lanczos measurement of this block yet
     if (W.last_npos >= nev) return false;                                 // truncation was active last time: the reference's engine decides
@@ -177,7 +179,22 @@ inline bool Solver::exact_projection_by_sign(int idx, const double* xp, double* 
     const double est = W.sign_ms >= 0.0 ? W.sign_ms : sign_cost_model_ms(W.nt * dev::TILE);
     if (W.kry_ms < 1.5 * est) { W.sign_streak = 0; return false; }
     if (W.sign_streak >= 256) { W.sign_streak = 0; return false; }        // re-measure the Lanczos engine now and then
+    if (W.sign_disabled) return false;
     const bool inplace = xp == xo;
+    if (W.sign_verified_left <= 0) {
+        // verification round (first use, then every 64th projection): BOTH engines run on this input; the Lanczos
+        // result is the one used, and the engine may serve the next 64 projections only if the two agree.
+        // Single-vector Lanczos returns one eigenvector per DISTINCT eigenvalue: where the iterate has repeated
+        // positive eigenvalues (MIMO's first iterates) the reference's projection is not the exact one, the
+        // comparison fails, and the block stays with the reference's engine for the rest of the solve.
+        if (W.sg_out.n < (size_t)W.N) W.sg_out.alloc(W.N);
+        const long long cr = current_rank[idx];
+        const double me = min_eig[idx];
+        const int lnp = W.last_npos;
+        if (full_eig_by_sign(idx, xp, W.sg_out.p, false, true)) W.sign_check_pending = current_rank[idx] < nev;
+        current_rank[idx] = cr; min_eig[idx] = me; W.last_npos = lnp;
+        return false;
+    }
     double* out = xo;
     if (inplace) {                                                        // keep the input: the check below may reject
         if (W.sg_out.n < (size_t)W.N) W.sg_out.alloc(W.N);
@@ -197,9 +214,30 @@ inline bool Solver::exact_projection_by_sign(int idx, const double* xp, double* 
     if (inplace) PX_HIP(hipMemcpyAsync(xo, out, (size_t)W.N * sizeof(double), hipMemcpyDeviceToDevice, stream));
     W.lst.sign_engine_projections++;
     W.sign_streak++;
+    W.sign_verified_left--;
     min_eig[idx] = 0.0;                 // the reference's value is lambda_min of the returned pairs, <= 0: same decisions
     W.have_factors = false; W.x_prev_sparse = false; W.use_fop = false;
     return true;
+}
+
+// second half of a verification round: xo holds the Lanczos engine's projection, W.sg_out the sign function's
+inline void Solver::verify_sign_engine(int idx, const double* xo) {
+    EigWork& W = eig[idx];
+    W.sign_check_pending = false;
+    if (W.sg_cmp.n < 2) W.sg_cmp.alloc(2);
+    W.sg_cmp.zero(stream);
+    hipLaunchKernelGGL(dev::k_maxdiff, dim3(grid_for(W.N)), dim3(dev::TPB), 0, stream, xo, (const double*)W.sg_out.p,
+                       (long long)W.N, W.sg_cmp.p);
+    double h[2] = {0.0, 0.0};
+    W.sg_cmp.download(h, 2, stream);
+    PX_HIP(hipStreamSynchronize(stream));
+    W.lst.sign_engine_checks++;
+    if (h[0] <= 1e-8 * std::max(h[1], 1e-300)) {
+        W.sign_verified_left = 64;
+    } else {
+        W.sign_disabled = true;
+        W.lst.sign_engine_mismatches++;
+    }
 }
 
 // full_eig! needs X+ = sum over lambda_i > 0 of lambda_i v_i v_i' -- every POSITIVE eigenpair, not

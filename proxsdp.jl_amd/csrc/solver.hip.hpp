@@ -200,6 +200,9 @@ struct EigWork {
     // Lanczos and sign projections, projections since the last Lanczos probe, scratch for in-place calls
     double kry_ms = -1.0, sign_ms = -1.0;
     int sign_streak = 0, sign_backoff = 0;
+    int sign_verified_left = 0;                    // projections the engine may still serve before it is checked again
+    bool sign_disabled = false, sign_check_pending = false;
+    DevBuf<double> sg_cmp;                         // max |difference|, max |value| of a verification
     DevBuf<double> sg_out;
 };
 
@@ -392,6 +395,7 @@ private:
     bool full_eig_by_lanczos(int idx, const double* xp_in, double* xp_out, bool fuse);
     bool full_eig_by_sign(int idx, const double* xp_in, double* xp_out, bool fuse, bool force = false);
     bool exact_projection_by_sign(int idx, const double* xp, double* xo, bool fuse, int nev);
+    void verify_sign_engine(int idx, const double* xo);
     template <int EPI, bool FUSE>
     void sym_gemm(EigWork& W, const double* Pm, const double* Qm, double* T, const double* Y, double ca, double cb,
                   double cc, const double* dsc, double* part, double* xp_out, const double* xp_old, int blk);
@@ -1263,7 +1267,7 @@ inline void Solver::merge_block_stats() {
         st.symv_profiled += a.symv_profiled; st.symv_profiled_ms += a.symv_profiled_ms;
         st.orth_profiled += a.orth_profiled; st.orth_profiled_ms += a.orth_profiled_ms;
         st.full_eig_solver_ms += a.full_eig_solver_ms; st.full_eig_recon_ms += a.full_eig_recon_ms;
-        st.full_eigs_lanczos += a.full_eigs_lanczos; st.full_eigs_sign += a.full_eigs_sign; st.sign_products += a.sign_products; st.sign_engine_projections += a.sign_engine_projections; st.sign_engine_rejected += a.sign_engine_rejected; st.warm_starts += a.warm_starts; st.device_eigs += a.device_eigs; st.mfma_reconstructions += a.mfma_reconstructions; st.cycle_launches += a.cycle_launches;
+        st.full_eigs_lanczos += a.full_eigs_lanczos; st.full_eigs_sign += a.full_eigs_sign; st.sign_products += a.sign_products; st.sign_engine_projections += a.sign_engine_projections; st.sign_engine_rejected += a.sign_engine_rejected; st.sign_engine_checks += a.sign_engine_checks; st.sign_engine_mismatches += a.sign_engine_mismatches; st.warm_starts += a.warm_starts; st.device_eigs += a.device_eigs; st.mfma_reconstructions += a.mfma_reconstructions; st.cycle_launches += a.cycle_launches;
         st.cycle_steps += a.cycle_steps; st.cycle_ms += a.cycle_ms;
         st.symv_bytes += a.symv_bytes; st.host_eig_time += a.host_eig_time; st.host_eigs += a.host_eigs;
         st.fop_projections += a.fop_projections;

@@ -1050,9 +1050,8 @@ def test_sign_engine_on_the_krylov_branch_reproduces_the_lanczos_solve(golden_di
     prox_operators.jl:89-109 IS the exact one and min_eig <= 0, so the sign-function projection may replace the
     Lanczos engine where it is measured to be cheaper (mcp250-1 needs ~100 mat-vecs per projection late in the
     solve).  Same linesearch decisions, same optimum, iteration count within rounding; every stand-in is verified
-    (#positive < target_rank) or redone by Lanczos.  Opt-in: with REPEATED positive eigenvalues (MIMO's first
-    iterates) single-vector Lanczos returns one copy per distinct eigenvalue, i.e. the reference's projection is
-    not the exact one there, and the knob would change the trajectory (tools/gpurun_engine.py)."""
+    (#positive < target_rank) or redone by Lanczos, and the engine itself is checked against the Lanczos engine on
+    first use and every 64th projection (test_sign_engine_steps_aside_where_lanczos_is_not_the_exact_projection)."""
     pr = P.sdplib(golden_dir / "sdplib" / "mcp250-1.dat-s")
     a = Optimizer(tol_gap=1e-4, tol_feasibility=1e-4).optimize(pr, trace_capacity=20000)
     b = Optimizer(tol_gap=1e-4, tol_feasibility=1e-4, psd_sign_engine=1).optimize(pr, trace_capacity=20000)
@@ -1067,6 +1066,21 @@ def test_sign_engine_on_the_krylov_branch_reproduces_the_lanczos_solve(golden_di
     assert np.allclose(a.trace[:m, 1:5], b.trace[:m, 1:5], rtol=0, atol=1e-6 * sc)
     assert abs(a.objval - b.objval) <= 1e-5 * (1 + abs(a.objval))
     assert a.final_rank == b.final_rank
+
+
+def test_sign_engine_steps_aside_where_lanczos_is_not_the_exact_projection():
+    """Single-vector Lanczos returns ONE eigenvector per distinct eigenvalue.  MIMO's first iterates have repeated
+    positive eigenvalues, so the reference's (KrylovKit) projection is not the exact projection there -- and parity
+    means reproducing the reference.  With psd_sign_engine = 1 the first verification round (both engines on the
+    same input) sees the difference and leaves the block to the Lanczos engine: identical solve."""
+    pr = P.mimo(512, seed=0)
+    a = Optimizer(tol_gap=1e-4, tol_feasibility=1e-4).optimize(pr, trace_capacity=2000)
+    b = Optimizer(tol_gap=1e-4, tol_feasibility=1e-4, psd_sign_engine=1).optimize(pr, trace_capacity=2000)
+    assert b.stats["sign_engine_checks"] == 1 and b.stats["sign_engine_mismatches"] == 1
+    assert b.stats["sign_engine_projections"] == 0
+    assert a.status == b.status and a.iter == b.iter
+    assert np.array_equal(a.trace[:, 1:5], b.trace[:, 1:5])
+    assert b.stats["lanczos_matvecs"] == a.stats["lanczos_matvecs"]
 
 
 def _spectrum_cases(n, rng):

@@ -26,7 +26,8 @@ for name, mk, kw in cases:
         out[f"{name}:{eng}"] = dict(status=int(s.status), iterations=int(s.iter), time_s=dt, objective=float(s.objval),
                                     final_rank=int(s.final_rank), matvecs=int(s.stats["lanczos_matvecs"]),
                                     sign_engine=int(s.stats["sign_engine_projections"]),
-                                    rejected=int(s.stats["sign_engine_rejected"]), it_per_s=s.iter / dt)
+                                    rejected=int(s.stats["sign_engine_rejected"]), checks=int(s.stats["sign_engine_checks"]),
+                                    mismatches=int(s.stats["sign_engine_mismatches"]), it_per_s=s.iter / dt)
         print(name, eng, out[f"{name}:{eng}"], flush=True)
     a, b = sols[0], sols[1]
     m = min(len(a.trace), len(b.trace))
