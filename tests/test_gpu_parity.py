@@ -1027,6 +1027,28 @@ def test_sdplib_full_eig_fallback_config(fname, iters, golden_dir):
         assert sol.final_rank == ref.final_rank
 
 
+def test_sign_function_projection_of_several_blocks_side_by_side():
+    """Four PSD blocks of different sides (150, 97, 64, 40) in one model with full_eig_decomp = true: the blocks'
+    sign-function projections run concurrently (one host worker thread and one HIP stream per block, each with its
+    own five work matrices) and must reproduce the oracle's LAPACK trace; with the support-aware vector passes the
+    final product also fills the blocks' residual partials."""
+    model = P.block_diag_problems([P.maxcut(150, seed=1), P.maxcut(97, seed=2), P.maxcut(64, seed=3), P.maxcut(40, seed=4)],
+                                  name="four-blocks")
+    o = Options()
+    o.max_iter = 60
+    o.full_eig_decomp = True
+    ref = oracle.solve(model, o, trace=True)
+    G = _trace_cols(ref.trace)
+    for kw in (dict(), dict(support_path=1)):
+        sol = Optimizer(max_iter=60, full_eig_decomp=1, **kw).optimize(model, trace_capacity=60)
+        assert sol.status == ref.status and sol.iter == ref.iter == 60
+        T = sol.trace[:, [1, 2, 3, 4, 7, 11]]
+        assert np.array_equal(T[:, 5], G[:, 5])
+        assert np.allclose(T, G, rtol=1e-6, atol=1e-8 * np.abs(G).max())
+        assert sol.stats["full_eigs_sign"] == 4 * 60 and sol.stats["sign_products"] == 57 * 4 * 60
+        assert sol.final_rank == ref.final_rank
+
+
 def test_sign_function_projection_on_64_tiles_large_block():
     """Blocks wider than 3072 run the products on the 64 x 64-tile kernel (k_sym_gemm<SG_PLAIN / SG_POLY>; smaller
     ones only use it for the final product): n = 3100 against LAPACK, forced through psd_project mode 4."""
