@@ -76,6 +76,10 @@ def main():
                     help="time limit of the time-to-tol leg with REFERENCE DEFAULT options (0: skip)")
     ap.add_argument("--lanczos-warm-start", dest="lanczos_warm_start", type=int, default=None,
                     help="library-only: Lanczos start vector from the previous projection's Ritz vectors")
+    ap.add_argument("--full-eig-sign", dest="full_eig_sign", type=int, default=None,
+                    help="library-only: full_eig! by the sign-function projection (-1 auto, 0 rocSOLVER, 1 always)")
+    ap.add_argument("--psd-sign-engine", dest="psd_sign_engine", type=int, default=None,
+                    help="library-only: 1 = verified stand-in of the sign-function projection on the Krylov branch")
     ap.add_argument("--no-rocsolver-leg", action="store_true",
                     help="sdplib workload: skip the rocSOLVER dsyevd comparison legs (thousands of tiny kernels per call: "
                          "not something to run under a kernel trace)")
@@ -313,7 +317,8 @@ def main():
 def extra_opts(args):
     """library-only knobs passed through to every GPU leg (empty = the KrylovKit-faithful parity path)"""
     kw = {}
-    for name in ("lanczos_warm_start", "lanczos_cycle_kernel", "full_eig_lanczos", "reconstruct_mfma"):
+    for name in ("lanczos_warm_start", "lanczos_cycle_kernel", "full_eig_lanczos", "reconstruct_mfma", "full_eig_sign",
+                 "psd_sign_engine"):
         v = getattr(args, name, None)
         if v is not None:
             kw[name] = v
