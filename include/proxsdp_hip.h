@@ -13,10 +13,15 @@
  * Python ctypes binding in proxsdp.jl_amd/binding.py is what the tests use.
  *
  * Conventions
- *   - plain C, no C++/torch types; all pointers are HOST pointers, borrowed for
- *     the duration of the call, never freed or written by the library (the
- *     reference mutates `aff` in place -- scaling.jl:24, pdhg.jl:647-663 -- the
- *     library works on private copies).
+ *   - plain C, no C++/torch types; pointers are HOST pointers unless a field says
+ *     otherwise (the two exceptions: `M_dense` with M_dense_on_device = 1 and the
+ *     buffer handed to `reduce_vec_fn` with reduce_vec_on_device = 1 are DEVICE
+ *     pointers on options.device_id), borrowed for the duration of the call, never
+ *     freed or written by the library (the reference mutates `aff` in place --
+ *     scaling.jl:24, pdhg.jl:647-663 -- the library works on private copies).
+ *   - index_base = 1 is the Julia calling convention (1-based Int64 colptr / rowval /
+ *     cone variable lists, structs.jl:32-53); exercised without Julia by
+ *     tests/test_julia_convention.py (ctypes with 1-based arrays + a plain-C caller).
  *   - return value: 0 = the solve ran to a solver status (whatever it is);
  *     < 0 = the call failed (PROXSDP_E_*), text in proxsdp_hip_last_error().
  *     Nothing unwinds across the ABI.  There is NO CPU fallback: without a

@@ -242,13 +242,18 @@ def device_count():
 class _Marshalled:
     """Keeps the numpy arrays behind a proxsdp_problem alive."""
 
-    def __init__(self, prob, eig_resid=None):
+    def __init__(self, prob, eig_resid=None, index_base=0):
+        """index_base = 1 hands the library what Julia's ccall hands it: 1-based Int64 colptr / rowval
+        (SparseMatrixCSC, structs.jl:36-37) and 1-based cone variable lists (SDPSet.vec_i, SOCSet.idx,
+        structs.jl:44-53); the offsets psd_ptr / soc_ptr stay 0-based (julia/ProxSDPHip.jl)."""
+        if index_base not in (0, 1):
+            raise ValueError("index_base must be 0 or 1")
         keep = []
 
         def csc(M, ncols):
             M = sp.csc_matrix(M, dtype=np.float64)
             M.sort_indices()
-            cp, rv, nz = _i(M.indptr), _i(M.indices), _f(M.data)
+            cp, rv, nz = _i(M.indptr) + index_base, _i(M.indices) + index_base, _f(M.data)
             keep.extend([cp, rv, nz])
             return CSC(M.shape[0], ncols, _p(cp, pi64), _p(rv, pi64), _p(nz))
 
@@ -263,13 +268,13 @@ class _Marshalled:
             ptr = np.zeros(len(lst) + 1, dtype=np.int64)
             for k, v in enumerate(lst):
                 ptr[k + 1] = ptr[k] + len(v)
-            idx = _i(np.concatenate(lst)) if lst else np.zeros(1, dtype=np.int64)
+            idx = (_i(np.concatenate(lst)) + index_base) if lst else np.zeros(1, dtype=np.int64)
             keep.extend([ptr, idx])
             return len(lst), _p(ptr, pi64), _p(idx, pi64)
 
         P.n_psd, P.psd_ptr, P.psd_idx = cones(list(prob.psd))
         P.n_soc, P.soc_ptr, P.soc_idx = cones(list(prob.soc))
-        P.index_base = 0
+        P.index_base = index_base
         if eig_resid is not None:
             r = _f(np.concatenate([np.asarray(v, float).ravel() for v in eig_resid]))
             keep.append(r)
@@ -313,7 +318,7 @@ class SolveResult:
         return [dict(zip(TRACE_NAMES, row)) for row in self.trace]
 
 
-def solve(prob, options=None, eig_resid=None, trace_capacity=0, reduce=None, coupling=None):
+def solve(prob, options=None, eig_resid=None, trace_capacity=0, reduce=None, coupling=None, index_base=0):
     """proxsdp_hip_solve: replaces chambolle_pock(aff, con, options) (MOI_wrapper.jl:310).
     Returns the minimisation objective; sign/constant fix-up is the caller's
     (MOI_wrapper.jl:336-337), see optimizer.Optimizer.
@@ -326,7 +331,7 @@ def solve(prob, options=None, eig_resid=None, trace_capacity=0, reduce=None, cou
     o = options if options is not None else default_options()
     if trace_capacity:
         o.trace_capacity = int(trace_capacity)
-    M = _Marshalled(prob, eig_resid)
+    M = _Marshalled(prob, eig_resid, index_base)
     if reduce is not None:
         def _cb(ctx, ps, ns, pm, nm):
             try:
@@ -511,8 +516,8 @@ def host_start_vector(n, seed=1234, init=3):
     return out
 
 
-def host_preprocess(prob):
-    M = _Marshalled(prob)
+def host_preprocess(prob, index_base=0):
+    M = _Marshalled(prob, index_base=index_base)
     n = prob.n
     order, inv = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64)
     cs = np.zeros(n)

@@ -7,7 +7,13 @@ in the build container, results committed as numbers only):
                             tol_gap = tol_feasibility = 1e-4 with reference default options:
                             status, iterations, objective, dual objective, gap, rank schedule
 
-Run from the repo root:  python tests/golden/make_golden_large.py [trace4000] [solve1000]
+  trace_maxcut_n4000_rank63.json  the HEADLINE regime of bench.py: the same instance started at target rank 63
+                            (initial_target_rank = 63, max_target_rank_krylov_eigs = 64: krylovdim 127), first
+                            TRACE4000R63_ITERS (12) iterations: trace columns + Lanczos mat-vecs per iteration
+  solve_maxcut_n2000.json   Max-Cut ER n=2000, seed 0, solved to tol 1e-4 with reference default options
+                            (hours of CPU: past target rank 16 every iteration is a LAPACK full_eig!)
+
+Run from the repo root:  python tests/golden/make_golden_large.py [trace4000] [solve1000] [trace4000r63] [solve2000]
 The inputs are regenerated from the seed by the tests through the same generator
 (proxsdp_jl_amd.problems.maxcut)."""
 import json
@@ -66,9 +72,51 @@ def solve1000():
     print("solve1000", r.status, r.iter, r.objval, r.dual_objval, r.gap, time.time() - t0)
 
 
+def trace4000r63():
+    pr = P.maxcut(4000, seed=0)
+    o = Options()
+    o.max_iter = int(os.environ.get("TRACE4000R63_ITERS", "12"))
+    o.initial_target_rank = 63
+    o.max_target_rank_krylov_eigs = 64
+    mv, rs = [], []
+
+    def cb(it, xin, xout, p, arc):
+        mv.append(int(arc[0].matvecs))
+        rs.append(int(getattr(arc[0], "restarts", 0)))
+    t0 = time.time()
+    r = oracle.solve(pr, o, trace=True, proj_callback=cb)
+    per_iter = [mv[0]] + [mv[i] - mv[i - 1] for i in range(1, len(mv))]
+    (OUT / "trace_maxcut_n4000_rank63.json").write_text(json.dumps(dict(
+        n=4000, seed=0, initial_target_rank=63, max_target_rank_krylov_eigs=64, status=r.status, iter=r.iter,
+        objval=r.objval, rows=rows_of(r), current_rank=[t["current_rank"][0] for t in r.trace], matvecs=per_iter,
+        wall_s=time.time() - t0)))
+    print("trace4000r63", r.status, r.iter, r.objval, per_iter, time.time() - t0)
+
+
+def solve2000():
+    pr = P.maxcut(2000, seed=0)
+    o = Options()
+    o.time_limit = 12 * 3600.0
+    t0 = time.time()
+    r = oracle.solve(pr, o, trace=True)
+    sched = []
+    for t in r.trace:
+        if not sched or sched[-1][1] != t["target_rank"][0]:
+            sched.append([t["iter"], t["target_rank"][0]])
+    (OUT / "solve_maxcut_n2000.json").write_text(json.dumps(dict(
+        n=2000, seed=0, tol=1e-4, status=r.status, iter=r.iter, objval=r.objval, dual_objval=r.dual_objval,
+        gap=r.gap, final_rank=int(r.final_rank), full_eigs=int(r.stats["full_eigs"]),
+        rank_schedule=sched, wall_s=time.time() - t0)))
+    print("solve2000", r.status, r.iter, r.objval, r.dual_objval, r.gap, time.time() - t0)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["trace4000", "solve1000"]
     if "trace4000" in which:
         trace4000()
     if "solve1000" in which:
         solve1000()
+    if "trace4000r63" in which:
+        trace4000r63()
+    if "solve2000" in which:
+        solve2000()
