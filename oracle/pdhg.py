@@ -411,11 +411,18 @@ def linesearch(st, a, aff, Mt, opt, p):
         box_projection(a.y_half, aff, bt)
         a.y_temp -= bt * a.y_half
         a.Mty = Mt @ a.y_temp
-        y_norm = float(np.linalg.norm(a.y_temp - st.y_old))
-        Mty_norm = float(np.linalg.norm(a.Mty - a.Mty_old))
+        # "In-place norm" (pdhg.jl:559-564): the differences overwrite Mty and y_temp ...
+        a.Mty -= a.Mty_old
+        a.y_temp -= st.y_old
+        y_norm = float(np.linalg.norm(a.y_temp))
+        Mty_norm = float(np.linalg.norm(a.Mty))
         if math.sqrt(p.beta) * p.primal_step * Mty_norm <= opt.delta * y_norm:
             break
         p.primal_step *= opt.linsearch_decay
+    # ... and are "reverted" after the loop (pdhg.jl:573-575): the accepted Mty and y carry
+    # fl(fl(v - v_old) + v_old), not v -- restated because it is what the reference iterates on
+    a.Mty += a.Mty_old
+    a.y_temp += st.y_old
     st.y = a.y_temp.copy()
     p.primal_step_old = p.primal_step
     p.dual_step = p.beta * p.primal_step

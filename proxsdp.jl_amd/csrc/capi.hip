@@ -366,7 +366,7 @@ int proxsdp_hip_dual_trial(const double* y, const double* Mx, const double* Mx_o
         part.zero(st);
         hipLaunchKernelGGL(proxsdp::dev::k_dual_trial, dim3(g), dim3(proxsdp::dev::TPB), 0, st,
                            (const double*)dy.p, (const double*)d1.p, (const double*)d0.p, (const double*)dbh.p,
-                           (int)p, (int)Q, bt, theta, dout.p, part.p);
+                           (int)p, (int)Q, bt, theta, dout.p, part.p, 1);
         hipLaunchKernelGGL(proxsdp::dev::k_combine, dim3(1), dim3(proxsdp::dev::TPB), 0, st,
                            (const double*)part.p, proxsdp::PSTRIDE, g, 1, 0u, sc.p);
         dout.download(y_out, Q, st);

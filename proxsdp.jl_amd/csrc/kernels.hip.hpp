@@ -1383,7 +1383,7 @@ k_spmv_csr_wave(const int* __restrict__ rowptr, const int* __restrict__ col, con
 __global__ void __launch_bounds__(TPB)
 k_dual_trial(const double* __restrict__ y, const double* __restrict__ Mx, const double* __restrict__ Mx_old,
              const double* __restrict__ bh, int p, int Q, double bt, double theta,
-             double* __restrict__ yout, double* __restrict__ part) {
+             double* __restrict__ yout, double* __restrict__ part, int addback) {
     __shared__ double sm[NWAVE];
     double ss = 0.0;
     for (int i = blockIdx.x * TPB + threadIdx.x; i < Q; i += gridDim.x * TPB) {
@@ -1391,8 +1391,10 @@ k_dual_trial(const double* __restrict__ y, const double* __restrict__ Mx, const 
         const double ybar = yi + bt * ((1.0 + theta) * Mx[i] - theta * Mx_old[i]);
         const double proj = (i < p) ? bh[i] : fmin(ybar / bt, bh[i]);
         const double yn = ybar - bt * proj;
-        yout[i] = yn;
         const double d = yn - yi;
+        // linesearch! takes its norms "in place" (y_temp .-= y_old ... y_temp .+= y_old, pdhg.jl:560-575):
+        // the y it keeps is fl(fl(y+ - y_old) + y_old); dual_step! (addback = 0) keeps y+ itself
+        yout[i] = addback ? d + yi : yn;
         ss += d * d;
     }
     double tot = block_sum(ss, sm);
@@ -1406,7 +1408,7 @@ k_dual_trial(const double* __restrict__ y, const double* __restrict__ Mx, const 
 __global__ void __launch_bounds__(TPB)
 k_spmv_csc_norm(const int* __restrict__ colptr, const int* __restrict__ row, const double* __restrict__ val,
                 const double* __restrict__ y, double* __restrict__ Mty, const double* __restrict__ Mty_old,
-                long long ncols, double* __restrict__ part) {
+                long long ncols, double* __restrict__ part, int addback) {
     __shared__ double sm[NWAVE];
     double ss = 0.0;
     long long j = (long long)blockIdx.x * TPB + threadIdx.x;
@@ -1415,8 +1417,9 @@ k_spmv_csc_norm(const int* __restrict__ colptr, const int* __restrict__ row, con
         double acc = 0.0;
         const int k0 = colptr[j], k1 = colptr[j + 1];
         for (int k = k0; k < k1; ++k) acc += val[k] * y[row[k]];
-        Mty[j] = acc;
-        const double d = acc - Mty_old[j];
+        const double o = Mty_old[j];
+        const double d = acc - o;
+        Mty[j] = addback ? d + o : acc;       // pdhg.jl:560,574 (a.Mty .-= a.Mty_old ... a.Mty .+= a.Mty_old)
         ss += d * d;
     }
     double tot = block_sum(ss, sm);
@@ -1537,8 +1540,8 @@ k_dual_trial_batch(const double* __restrict__ y, const double* __restrict__ Mx, 
         const double ybar = yi + bt * ((1.0 + theta) * Mx[i] - theta * Mx_old[i]);
         const double proj = (i < p) ? bh[i] : fmin(ybar / bt, bh[i]);
         const double yn = ybar - bt * proj;
-        yout[i] = yn;
         const double d = yn - yi;
+        yout[i] = d + yi;                      // in-place norm + revert (pdhg.jl:561,575): fl(fl(y+ - y_old) + y_old)
         // roww: 0 for a coupling row another shard accounts for (block-sharded solve), else 1
         ss += (roww != nullptr ? roww[i] : 1.0) * (d * d);
     }
@@ -1561,8 +1564,9 @@ k_spmvT_S_batch(const int* __restrict__ colptr, const int* __restrict__ row, con
         const int col = supp[s];
         double acc = 0.0;
         for (int k = colptr[col]; k < colptr[col + 1]; ++k) acc += val[k] * y[row[k]];
-        out[s] = acc;
-        const double d = acc - MtyS_old[s];
+        const double o = MtyS_old[s];
+        const double d = acc - o;
+        out[s] = d + o;                        // pdhg.jl:560,574
         ss += d * d;
     }
     const double tot = block_sum(ss, sm);
@@ -1766,7 +1770,8 @@ k_dense_mtv(const double* __restrict__ M, long long ld, int Q, long long n, cons
             long long ystride, const unsigned char* __restrict__ offdiag, double scale,
             double* __restrict__ OUT, long long ostride, const double* __restrict__ old,
             const double* __restrict__ addc, double* __restrict__ part, long long cstride,
-            const int* __restrict__ sp_colptr, const int* __restrict__ sp_row, const double* __restrict__ sp_val) {
+            const int* __restrict__ sp_colptr, const int* __restrict__ sp_row, const double* __restrict__ sp_val,
+            int addback) {
     __shared__ double sm[NWAVE];
     double ss[NC];
 #pragma unroll
@@ -1832,8 +1837,8 @@ k_dense_mtv(const double* __restrict__ M, long long ld, int Q, long long n, cons
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const double v = acc[c][t] * sc + spv[c] + ad;
-                OUT[c * ostride + j] = v;
                 const double d = v - o;
+                OUT[c * ostride + j] = addback ? d + o : v;      // linesearch!: pdhg.jl:560,574
                 ss[c] += d * d;
             }
         }

@@ -378,10 +378,10 @@ inline int Solver::linesearch() {
         const double bt = beta * primal_step;
         hipLaunchKernelGGL(dev::k_dual_trial, dim3(gq), dim3(dev::TPB), 0, stream,
                            ybuf[yc].p, Mxbuf[1 - mxc].p, Mxbuf[mxc].p, bh_d.p, (int)P.p, (int)P.Q, bt, theta,
-                           ybuf[1 - yc].p, part.p);
+                           ybuf[1 - yc].p, part.p, 1);
         hipLaunchKernelGGL(dev::k_spmv_csc_norm, dim3(gx), dim3(dev::TPB), 0, stream,
                            csc_ptr.p, csc_row.p, csc_val.p, ybuf[1 - yc].p, Mtybuf[1 - mtyc].p, Mtybuf[mtyc].p,
-                           (long long)P.n, part.p + PSTRIDE);
+                           (long long)P.n, part.p + PSTRIDE, 1);
         hipLaunchKernelGGL(dev::k_combine, dim3(1), dim3(dev::TPB), 0, stream,
                            part.p, PSTRIDE, PSTRIDE, 2, 0u, scal.p);
         scal.download(hscal.data(), 2, stream);
@@ -405,13 +405,13 @@ inline void Solver::dual_step_plain() {
     const int gx = std::min(PSTRIDE, grid_for(P.n));
     hipLaunchKernelGGL(dev::k_dual_trial, dim3(gq), dim3(dev::TPB), 0, stream,
                        ybuf[yc].p, Mxbuf[1 - mxc].p, Mxbuf[mxc].p, bh_d.p, (int)P.p, (int)P.Q, dual_step, 1.0,
-                       ybuf[1 - yc].p, part.p);
+                       ybuf[1 - yc].p, part.p, 0);
     if (P.dense())
-        dense_mtv(1, ybuf[1 - yc].p, 0, true, Mtybuf[1 - mtyc].p, 0, Mtybuf[mtyc].p, nullptr, part.p + PSTRIDE, 0);
+        dense_mtv(1, ybuf[1 - yc].p, 0, true, Mtybuf[1 - mtyc].p, 0, Mtybuf[mtyc].p, nullptr, part.p + PSTRIDE, 0, false);
     else
     hipLaunchKernelGGL(dev::k_spmv_csc_norm, dim3(gx), dim3(dev::TPB), 0, stream,
                        csc_ptr.p, csc_row.p, csc_val.p, ybuf[1 - yc].p, Mtybuf[1 - mtyc].p, Mtybuf[mtyc].p,
-                       (long long)P.n, part.p + PSTRIDE);
+                       (long long)P.n, part.p + PSTRIDE, 0);
     primal_step_old = primal_step;
     st.linesearch_trials += 1;
 }
@@ -511,7 +511,7 @@ inline double Solver::dual_feas_host(const std::vector<double>& y, const std::ve
     if (P.dense()) {                                          // c + M'y with the caller's (unscaled) M
         DevBuf<double> yd(std::max<int64_t>(P.Q, 1)), cd(P.n), od(P.n);
         yd.upload(y.data(), P.Q, stream); cd.upload(cvec.data(), P.n, stream);
-        dense_mtv(1, yd.p, 0, false, od.p, 0, nullptr, cd.p, nullptr, 0);
+        dense_mtv(1, yd.p, 0, false, od.p, 0, nullptr, cd.p, nullptr, 0, false);
         od.download(dc.data(), P.n, stream);
         PX_HIP(hipStreamSynchronize(stream));
     }
@@ -749,7 +749,7 @@ inline void Solver::dense_mv(const double* x, double* y, bool scaled) {
 
 // OUT_c = s o (M' Y_c) [+ addc], c < nc <= 3, one pass over M
 inline void Solver::dense_mtv(int nc, const double* Y, long long ystride, bool scaled, double* OUT, long long ostride,
-                              const double* old, const double* addc, double* normpart, long long cstride) {
+                              const double* old, const double* addc, double* normpart, long long cstride, bool addback) {
     int gx = std::min(PSTRIDE, grid_for(P.n));
     if (gx >= 8) gx &= ~7;                               // multiple of 8: XCD-aware chunk order in the kernel
     const unsigned char* od = scaled ? offdiag_d.p : nullptr;
@@ -757,7 +757,7 @@ inline void Solver::dense_mtv(int nc, const double* Y, long long ystride, bool s
     auto launch = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(gx), dim3(dev::TPB), 0, stream, Md, (long long)P.n, (int)P.p, (long long)P.n,
                            Y, ystride, od, sc, OUT, ostride, old, addc, normpart, cstride,
-                           scaled && P.nnz > 0 ? csc_ptr.p : nullptr, csc_row.p, csc_val.p);
+                           scaled && P.nnz > 0 ? csc_ptr.p : nullptr, csc_row.p, csc_val.p, addback ? 1 : 0);
     };
     dense_ev_begin();
     if (nc == 1) launch(dev::k_dense_mtv<1, 1, 8>);
@@ -795,7 +795,7 @@ inline int Solver::linesearch_dense() {
                            ybuf[yc].p, Mxbuf[1 - mxc].p, Mxbuf[mxc].p, bh_d.p, (int)P.p, (int)P.Q, tb,
                            ycand_d.p, ystride, bpart.p, cstride);
         dense_mtv(nc, ycand_d.p, ystride, true, Mtycand_d.p, (long long)P.n, Mtybuf[mtyc].p, nullptr,
-                  bpart.p + PSTRIDE, cstride);
+                  bpart.p + PSTRIDE, cstride, true);
         hipLaunchKernelGGL(dev::k_combine_multi, dim3(nc * 2), dim3(dev::TPB), 0, stream,
                            (const double*)bpart.p, PSTRIDE, std::max(gq, gx), 0ull, bscal.p, nc * 2,
                            (const double*)nullptr, 0, 0, (double*)nullptr);

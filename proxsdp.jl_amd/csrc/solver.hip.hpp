@@ -390,7 +390,7 @@ private:
     int  linesearch_dense();
     void dense_mv(const double* x, double* y, bool scaled);
     void dense_mtv(int nc, const double* Y, long long ystride, bool scaled, double* OUT, long long ostride,
-                   const double* old, const double* addc, double* normpart, long long cstride);
+                   const double* old, const double* addc, double* normpart, long long cstride, bool addback);
     void full_eig_project(int idx, const double* xp_in, double* xp_out, bool fuse);
     bool full_eig_by_lanczos(int idx, const double* xp_in, double* xp_out, bool fuse);
     bool full_eig_by_sign(int idx, const double* xp_in, double* xp_out, bool fuse, bool force = false);
