@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PROXSDP_HIP_ABI_VERSION 5
+#define PROXSDP_HIP_ABI_VERSION 6
 
 /* error codes (negative return values) */
 #define PROXSDP_E_INVALID  (-1)   /* invalid argument / inconsistent problem data */
@@ -132,6 +132,14 @@ typedef struct proxsdp_problem {
     int (*reduce_vec_fn)(void* ctx, double* buf, int64_t len, int32_t on_device);
     int32_t reduce_vec_on_device;
     int32_t reserved2;
+    /* optional, block-sharded solves only: an RCCL communicator (ncclComm_t, one rank per shard, created by the
+     * caller -- e.g. ncclCommInitRank in the process that owns the GPU).  When non-NULL the library issues BOTH
+     * collectives itself on its own stream -- ncclAllReduce(sum) / ncclAllReduce(max) of the packed scalar record
+     * and ncclAllReduce(sum) of the coupling buffer -- with no host callback and no host copy of the vectors;
+     * reduce_fn / reduce_vec_fn may then be NULL (they are ignored).  librccl.so is loaded at run time
+     * (dlopen): the library does not link it, and a process that never passes a communicator never loads it. */
+    void* nccl_comm;
+    int64_t reserved3;
 } proxsdp_problem;
 
 /* Options (options.jl:1-132): same names, same defaults (proxsdp_hip_default_options).
@@ -227,7 +235,33 @@ typedef struct proxsdp_options {
                                   * disagreement -- repeated eigenvalues, of which single-vector Lanczos returns one
                                   * copy -- leaves the block to the Lanczos engine for the rest of the solve).
                                   * -1 auto = 0 = off: the reference's engine choice, mat-vec counts as KrylovKit's */
-    int32_t pad8;
+    int32_t full_eig_lanczos_verify; /* full_eig! served by the Lanczos engine (full_eig_lanczos) is the library's own
+                                  * algorithm; single-vector Lanczos returns ONE eigenvector per distinct eigenvalue, so a
+                                  * repeated positive eigenvalue would silently lose copies.  k > 0: the first such call of a
+                                  * block and every k-th after it are ALSO computed by the reference's engine (sign-function /
+                                  * dense eigensolver) on the same input and compared (max |difference| <= 1e-8 max |X+|); a
+                                  * mismatch hands the block back to the dense engine for the rest of the solve
+                                  * (stats.full_eigs_lanczos_checks / _mismatches).  -1 auto = 128, 0 = never */
+    double  full_eig_lanczos_posres; /* acceptance of that engine: the first strictly negative Ritz pair must be resolved to
+                                  * posres x spectral scale (default 1e-7 = tol_psd's magnitude) */
+    int32_t full_eig_lanczos_kdim10; /* its Krylov dimension = max(2 g + 1, g x kdim10 / 10 + 8), default 30 */
+    int32_t sign_small_tile_max; /* sign-function projection: 32 x 32 product tiles up to this padded side, 64 x 64
+                                  * above (default 3072, measured cross-over ~ 3500) */
+    int32_t host_eig_threads;    /* helper threads of the host K x K eigensolver's rotation replay (default 0:
+                                  * measured slower on the MI355X host; results are bit-identical) */
+    int32_t block_threads;       /* host worker threads driving concurrent per-block projections (one HIP stream
+                                  * per block): -1 auto = min(8, blocks), 0 = blocks in sequence */
+    int32_t device_restart;      /* thick restart of the Lanczos engine on the DEVICE (K x K Rayleigh-quotient
+                                  * eigensolve, basis rotation and convergence test chained on the stream; the host
+                                  * reads back once per projection): -1 auto, 0 = host eigensolve per restart, 1 = on */
+    int32_t block_batch;         /* PSD blocks of equal side projected by ONE launch per Lanczos step (grid.z = block)
+                                  * instead of one stream + host thread per block: -1 auto, 0 off, 1 on */
+    int32_t block_eigensolver;   /* 0 (default) = KrylovKit's single-vector thick-restart Lanczos (the reference's
+                                  * algorithm, mat-vec counts as the oracle's); b > 1 = warm-started BLOCK eigensolver of
+                                  * width b (library-only: same wanted pairs to krylovkit_tol, different Krylov space) */
+    int32_t rocsolver_warmup;    /* 1 = load rocSOLVER's code objects from a background thread at start-up (default 0) */
+    int32_t reserved_i[6];       /* zero */
+    double  reserved_d[2];       /* zero */
 } proxsdp_options;
 
 #define PROXSDP_TRACE_COLS 14
@@ -277,6 +311,13 @@ typedef struct proxsdp_stats {
     int64_t sign_engine_rejected;    /* ... computed but discarded: truncation was active, Lanczos redid them */
     int64_t sign_engine_checks;      /* verification rounds (both engines on the same input; first use, then every 64th) */
     int64_t sign_engine_mismatches;  /* ... that disagreed (repeated eigenvalues): the block stays with Lanczos */
+    int64_t full_eigs_lanczos_checks;     /* Lanczos-served full_eig! calls verified against the dense engine */
+    int64_t full_eigs_lanczos_mismatches; /* ... that disagreed: the block went back to the dense engine */
+    int64_t batched_block_steps;     /* Lanczos steps launched for several blocks at once (block_batch) */
+    int64_t rccl_reductions;         /* collectives issued by the library itself on its own stream (nccl_comm) */
+    int64_t device_restarts;         /* thick restarts done entirely on the device (device_restart) */
+    int64_t block_eig_steps;         /* block steps of the block eigensolver (block_eigensolver) */
+    int64_t reserved[6];
 } proxsdp_stats;
 
 /* Result (structs.jl:60-81).  Arrays are caller-allocated with the stated

@@ -57,6 +57,8 @@ struct Problem                   # proxsdp_problem
     reduce_vec_fn::Ptr{Cvoid}
     reduce_vec_on_device::Int32
     reserved2::Int32
+    nccl_comm::Ptr{Cvoid}        # RCCL communicator of a block-sharded solve (C_NULL otherwise)
+    reserved3::Int64
 end
 
 struct Stats                     # proxsdp_stats
@@ -102,6 +104,13 @@ struct Stats                     # proxsdp_stats
     sign_engine_rejected::Int64
     sign_engine_checks::Int64
     sign_engine_mismatches::Int64
+    full_eigs_lanczos_checks::Int64
+    full_eigs_lanczos_mismatches::Int64
+    batched_block_steps::Int64
+    rccl_reductions::Int64
+    device_restarts::Int64
+    block_eig_steps::Int64
+    reserved::NTuple{6,Int64}
 end
 
 mutable struct CResult           # proxsdp_result
@@ -182,7 +191,8 @@ function chambolle_pock_hip(aff, con, options; ResultType = Main.ProxSDP.Result)
                        length(con.socone), pointer(soc_ptr), pointer(soc_idx),
                        Int32(1), Int32(0), Ptr{Float64}(C_NULL),         # Julia indices are 1-based
                        C_NULL, C_NULL, Ptr{Float64}(C_NULL), Int32(0), Int32(0),
-                       0, Ptr{Int64}(C_NULL), Ptr{Int32}(C_NULL), C_NULL, Int32(0), Int32(0))   # no coupling rows
+                       0, Ptr{Int64}(C_NULL), Ptr{Int32}(C_NULL), C_NULL, Int32(0), Int32(0),   # no coupling rows
+                       C_NULL, 0)                                                                # no RCCL communicator
         res.primal = pointer(primal); res.dual_cone = pointer(dual_cone)
         res.dual_eq = pointer(dual_eq); res.dual_in = pointer(dual_in)
         res.slack_eq = pointer(slack_eq); res.slack_in = pointer(slack_in)

@@ -55,7 +55,8 @@ class Problem(C.Structure):
                 ("reduce_ctx", C.c_void_p), ("reduce_fn", C.c_void_p),
                 ("M_dense", C.c_void_p), ("M_dense_on_device", i32), ("reserved1", i32),
                 ("n_coupling", i64), ("coupling_rows", pi64), ("coupling_owned", C.POINTER(i32)),
-                ("reduce_vec_fn", C.c_void_p), ("reduce_vec_on_device", i32), ("reserved2", i32)]
+                ("reduce_vec_fn", C.c_void_p), ("reduce_vec_on_device", i32), ("reserved2", i32),
+                ("nccl_comm", C.c_void_p), ("reserved3", i64)]
 
 
 REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, pf64, i32, pf64, i32)
@@ -105,7 +106,11 @@ def _opt_fields():
     a("device_id", i32); a("trace_capacity", i32); a("profile_symv_every", i32); a("support_path", i32)
     a("lanczos_operator", i32); a("initial_target_rank", i32)
     a("full_eig_lanczos", i32); a("lanczos_cycle_kernel", i32); a("lanczos_warm_start", i32)
-    a("reconstruct_mfma", i32); a("small_block_batch", i32); a("full_eig_sign", i32); a("psd_sign_engine", i32); a("pad8", i32)
+    a("reconstruct_mfma", i32); a("small_block_batch", i32); a("full_eig_sign", i32); a("psd_sign_engine", i32)
+    a("full_eig_lanczos_verify", i32); a("full_eig_lanczos_posres", f64); a("full_eig_lanczos_kdim10", i32)
+    a("sign_small_tile_max", i32); a("host_eig_threads", i32); a("block_threads", i32)
+    a("device_restart", i32); a("block_batch", i32); a("block_eigensolver", i32); a("rocsolver_warmup", i32)
+    a("reserved_i", i32 * 6); a("reserved_d", f64 * 2)
     return F
 
 
@@ -126,7 +131,10 @@ class Stats(C.Structure):
                 ("full_eigs_lanczos", i64), ("cycle_steps", i64), ("cycle_ms", f64), ("warm_starts", i64),
                 ("full_eigs_sign", i64), ("sign_products", i64),
                 ("sign_engine_projections", i64), ("sign_engine_rejected", i64),
-                ("sign_engine_checks", i64), ("sign_engine_mismatches", i64)]
+                ("sign_engine_checks", i64), ("sign_engine_mismatches", i64),
+                ("full_eigs_lanczos_checks", i64), ("full_eigs_lanczos_mismatches", i64),
+                ("batched_block_steps", i64), ("rccl_reductions", i64), ("device_restarts", i64),
+                ("block_eig_steps", i64), ("reserved", i64 * 6)]
 
 
 class Result(C.Structure):
@@ -191,7 +199,7 @@ def lib():
     L.proxsdp_host_symeig.argtypes = [i32, pf64, pf64]
     L.proxsdp_host_start_vector.argtypes = [i64, i64, i32, pf64]
     L.proxsdp_host_preprocess.argtypes = [C.POINTER(Problem), pi64, pi64, pf64, pf64]
-    if L.proxsdp_hip_abi_version() != 5:
+    if L.proxsdp_hip_abi_version() != 6:
         raise ProxSDPHipError(-1, "ABI version mismatch")
     _lib = L
     return L

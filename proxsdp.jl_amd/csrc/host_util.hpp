@@ -198,23 +198,25 @@ inline void ql_replay(const QlJob& J, int r0, int r1) {
 class QlPool {
 public:
     static QlPool& get() { static QlPool p; return p; }
-    int helpers() const { return (int)th_.size(); }
+    int helpers() const { return nth_.load(std::memory_order_acquire); }
     // at least t helper threads (explicit request of a caller, e.g. the bit-identity test)
     void ensure(int t) {
         if (!busy_.try_lock()) return;
         t = std::min(t, 16);
         // (no job can be in flight while busy_ is held: a new helper starts from the current job counter)
+        // th_ has capacity 16 from construction (never reallocates); readers only look at nth_
         while ((int)th_.size() < t) {
             const int i = (int)th_.size();
             const long long g0 = gen_.load(std::memory_order_acquire);
             th_.emplace_back([this, i, g0]() { loop(i, g0); });
+            nth_.store((int)th_.size(), std::memory_order_release);
         }
         busy_.unlock();
     }
     // helpers leave their condition variable and spin for the next 20 ms (called when a projection with a
     // large Krylov dimension starts, and by start())
     void arm() {
-        if (th_.empty()) return;
+        if (helpers() == 0) return;
         armed_until_.store(now_ns() + 20000000LL, std::memory_order_release);
         if (sleepers_.load(std::memory_order_acquire) > 0) {
             std::lock_guard<std::mutex> lk(mu_);
@@ -223,8 +225,8 @@ public:
     }
     // run job J on the helpers: every row of the matrix belongs to one helper's slice
     bool start(QlJob* J) {
-        if (th_.empty() || !busy_.try_lock()) return false;
-        J->parts = (int)th_.size();
+        if (helpers() == 0 || !busy_.try_lock()) return false;
+        J->parts = helpers();                    // (stable while busy_ is held: ensure() takes the same lock)
         done_.store(0, std::memory_order_relaxed);
         job_.store(J, std::memory_order_release);
         gen_.fetch_add(1, std::memory_order_acq_rel);
@@ -232,7 +234,7 @@ public:
         return true;
     }
     void finish() {
-        const int t = (int)th_.size();
+        const int t = helpers();
         while (done_.load(std::memory_order_acquire) < t) {
 #if defined(__x86_64__)
             _mm_pause();
@@ -245,14 +247,7 @@ private:
     static long long now_ns() {
         return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
     }
-    QlPool() {
-        const char* e = std::getenv("PROXSDP_HIP_EIG_THREADS");
-        const int hw = (int)std::thread::hardware_concurrency();
-        int t = e ? std::atoi(e) : 0;
-        if (hw > 0) t = std::min(t, std::max(0, hw - 2));
-        t = std::max(0, std::min(t, 16));
-        for (int i = 0; i < t; ++i) th_.emplace_back([this, i]() { loop(i, 0); });
-    }
+    QlPool() { th_.reserve(16); }          // helpers are created by ensure() (options.host_eig_threads), at most 16
     ~QlPool() {
         { std::lock_guard<std::mutex> lk(mu_); stop_.store(true); }
         cv_.notify_all();
@@ -293,7 +288,7 @@ private:
     std::condition_variable cv_;
     std::atomic<QlJob*> job_{nullptr};
     std::atomic<long long> gen_{0}, armed_until_{0};
-    std::atomic<int> done_{0}, sleepers_{0};
+    std::atomic<int> done_{0}, sleepers_{0}, nth_{0};
     std::atomic<bool> stop_{false};
 };
 
@@ -495,6 +490,10 @@ inline const std::vector<OptEntry>& option_table() {
         PX_OPT(support_path, OT_I32), PX_OPT(lanczos_operator, OT_I32), PX_OPT(initial_target_rank, OT_I32),
         PX_OPT(full_eig_lanczos, OT_I32), PX_OPT(lanczos_cycle_kernel, OT_I32), PX_OPT(lanczos_warm_start, OT_I32),
         PX_OPT(reconstruct_mfma, OT_I32), PX_OPT(small_block_batch, OT_I32), PX_OPT(full_eig_sign, OT_I32), PX_OPT(psd_sign_engine, OT_I32),
+        PX_OPT(full_eig_lanczos_verify, OT_I32), PX_OPT(full_eig_lanczos_posres, OT_F64), PX_OPT(full_eig_lanczos_kdim10, OT_I32),
+        PX_OPT(sign_small_tile_max, OT_I32), PX_OPT(host_eig_threads, OT_I32), PX_OPT(block_threads, OT_I32),
+        PX_OPT(device_restart, OT_I32), PX_OPT(block_batch, OT_I32), PX_OPT(block_eigensolver, OT_I32),
+        PX_OPT(rocsolver_warmup, OT_I32),
     };
     return t;
 }
@@ -534,6 +533,9 @@ inline void default_options(proxsdp_options* o) {      // options.jl:1-132
     o->lanczos_operator = -1; o->initial_target_rank = 2;
     o->full_eig_lanczos = -1; o->lanczos_cycle_kernel = -1; o->lanczos_warm_start = 0; o->reconstruct_mfma = -1;
     o->small_block_batch = -1; o->full_eig_sign = -1; o->psd_sign_engine = -1;
+    o->full_eig_lanczos_verify = -1; o->full_eig_lanczos_posres = 1e-7; o->full_eig_lanczos_kdim10 = 30;
+    o->sign_small_tile_max = 3072; o->host_eig_threads = 0; o->block_threads = -1;
+    o->device_restart = -1; o->block_batch = -1; o->block_eigensolver = 0; o->rocsolver_warmup = 0;
 }
 
 inline int set_option(proxsdp_options* o, const char* name, double v) {

@@ -252,10 +252,46 @@ inline bool Solver::full_eig_by_lanczos(int idx, const double* xp, double* xo, b
     EigWork& W = eig[idx];
     if (opt.full_eig_lanczos == 0 || opt.eigsolver == 1 || W.n <= opt.min_size_krylov_eigs) return false;
     if (W.last_npos < 0) return false;                       // no estimate yet: dense eigensolver first
+    if (W.fel_disabled) return false;                        // a verification failed earlier in this solve
     const int maxnev = std::min((W.cap - 2) / 2, W.n - 1);   // krylovdim = 2 nev + 1 <= cap - 1
     int g = W.last_npos + std::max(3, W.last_npos / 8);
     if (8 * W.last_npos > W.n) return false;                 // many positive pairs: the dense solver is the cheaper tool
     const bool used_fop = W.use_fop;
+    // Verification (options.full_eig_lanczos_verify): this engine is the library's own algorithm, and single-vector
+    // Lanczos returns ONE eigenvector per distinct eigenvalue -- a repeated positive eigenvalue, or a start vector
+    // deficient in an eigendirection, would silently drop a copy from X+.  On the first call of a block and every
+    // k-th after it the reference's engine (full_eig_project: sign function / dsyevd) ALSO projects the same input
+    // (into a scratch buffer, BEFORE the reconstruction overwrites an in-place input); the results are compared
+    // below and a mismatch hands the block back to the dense engine for the rest of the solve.
+    const int vk = opt.full_eig_lanczos_verify < 0 ? 128 : opt.full_eig_lanczos_verify;
+    bool verify = vk > 0 && (W.fel_served % vk) == 0;
+    long long ref_rank = 0;
+    int ref_npos = 0;
+    bool ref_sign = false;
+    if (verify) {
+        if (W.sg_out.n < (size_t)W.N) W.sg_out.alloc(W.N);
+        const long long cr = current_rank[idx];
+        const double me = min_eig[idx];
+        const int lnp = W.last_npos;
+        const bool hf = W.have_factors, xs = W.x_prev_sparse, uf = W.use_fop;
+        const long long fe0 = W.lst.full_eigs, fs0 = W.lst.full_eigs_sign;
+        full_eig_project(idx, xp, W.sg_out.p, false);
+        ref_rank = current_rank[idx]; ref_npos = W.last_npos; ref_sign = W.lst.full_eigs_sign > fs0;
+        current_rank[idx] = cr; min_eig[idx] = me; W.last_npos = lnp;
+        W.have_factors = hf; W.x_prev_sparse = xs; W.use_fop = uf;
+        W.lst.full_eigs = fe0; W.lst.full_eigs_sign = fs0;   // (the check is not a full_eig! call of the solve)
+    }
+    auto use_reference_result = [&]() {
+        W.fel_disabled = true;
+        W.lst.full_eigs_lanczos_mismatches++;
+        W.have_factors = false; W.x_prev_sparse = false; W.use_fop = false;
+        if (xp != xo) { full_eig_project(idx, xp, xo, fuse); return; }   // input intact: the ordinary dense call
+        // in-place call: the input is gone, the scratch buffer holds the dense engine's projection of it
+        PX_HIP(hipMemcpyAsync(xo, W.sg_out.p, (size_t)W.N * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        W.lst.full_eigs++;
+        if (ref_sign) W.lst.full_eigs_sign++;
+        current_rank[idx] = ref_rank; min_eig[idx] = 0.0; W.last_npos = ref_npos;
+    };
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (g > maxnev || g < 1) break;
         lanczos(W, xp, g, true);
@@ -264,6 +300,7 @@ inline bool Solver::full_eig_by_lanczos(int idx, const double* xp, double* xo, b
             break;
         }
         const int npos = W.count;
+        W.fel_served++;
         // guard: between consecutive projections of this regime the number of positive eigenvalues
         // moves by a few; a collapse means the Krylov space was fooled (e.g. decoupled coordinates
         // resolved long before the small positive pairs): let the dense solver decide
@@ -286,6 +323,20 @@ inline bool Solver::full_eig_by_lanczos(int idx, const double* xp, double* xo, b
             std::swap(W.lam.p, W.Flam.p);
             std::swap(W.lam.n, W.Flam.n);
             W.have_factors = true; W.x_prev_sparse = false;
+        }
+        if (verify) {
+            if (W.sg_cmp.n < 2) W.sg_cmp.alloc(2);
+            W.sg_cmp.zero(stream);
+            hipLaunchKernelGGL(dev::k_maxdiff, dim3(grid_for(W.N)), dim3(dev::TPB), 0, stream, (const double*)xo,
+                               (const double*)W.sg_out.p, (long long)W.N, W.sg_cmp.p);
+            double h[2] = {0.0, 0.0};
+            W.sg_cmp.download(h, 2, stream);
+            PX_HIP(hipStreamSynchronize(stream));
+            W.lst.full_eigs_lanczos_checks++;
+            if (!(h[0] <= 1e-8 * std::max(h[1], 1e-300))) {
+                W.lst.full_eigs--; W.lst.full_eigs_lanczos--;
+                use_reference_result();
+            }
         }
         return true;
     }
@@ -1169,7 +1220,8 @@ inline void Solver::run() {
     // opt-in only: measured on MI355X/ROCm 7.2, loading rocSOLVER's code objects from a second
     // thread stalls this thread's kernel launches (a 0.3 s solve took 8 s), so by default the
     // exit path pays the one-off ~3 s initialisation itself in a cold process
-    if (big_block && std::getenv("PROXSDP_HIP_WARMUP") != nullptr) start_rocsolver_warmup();
+    if (big_block && opt.rocsolver_warmup == 1) start_rocsolver_warmup();
+    if (opt.host_eig_threads > 0) QlPool::get().ensure(opt.host_eig_threads);
     for (int k = 0; k < 2; ++k) {
         xbuf[k].alloc(P.n); Mtybuf[k].alloc(P.n);
         ybuf[k].alloc(std::max<int64_t>(P.Q, 1)); Mxbuf[k].alloc(std::max<int64_t>(P.Q, 1));
@@ -1247,10 +1299,9 @@ inline void Solver::run() {
         }
         // several eigensolver-sized blocks: project them concurrently, one worker thread and one
         // stream per block (the per-block Lanczos chains are launch-latency-bound, so they overlap
-        // almost perfectly: MIMO n=512 x 8 on one GPU).  PROXSDP_HIP_BLOCK_THREADS=0 disables.
+        // almost perfectly: MIMO n=512 x 8 on one GPU).  options.block_threads = 0 disables.
         {
-            const char* e = std::getenv("PROXSDP_HIP_BLOCK_THREADS");
-            int nthreads = e ? atoi(e) : 8;
+            int nthreads = opt.block_threads < 0 ? 8 : std::min(opt.block_threads, 64);
             // (blocks handled by the batched small-block kernel need no worker / stream of their own)
             const std::vector<int>& pool_blocks = small_blocks.empty() ? big_blocks : large_blocks;
             nthreads = std::min<int>(nthreads, (int)pool_blocks.size());

@@ -171,6 +171,8 @@ struct EigWork {
     bool x_prev_sparse = true;                     // x_prev is zero off the support (initial iterate)
     bool use_fop = false;                          // the projection in progress uses the operator form
     int last_npos = -1;                            // positive eigenvalues found by the last full_eig! of this block
+    long long fel_served = 0;                      // full_eig! calls of this block served by the Lanczos engine
+    bool fel_disabled = false;                     // ... switched off after a failed verification (full_eig_lanczos_verify)
     // persistent Lanczos cycle kernel (lanczos_cycle.hip.hpp): granule buffers, epoch counter, error word
     DevBuf<double> xg1, xg2, warm_part;
     DevBuf<unsigned> xf1, xf2;
@@ -756,9 +758,9 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive
     const bool arpack = (opt.eigsolver == 1);
     int krylovdim = std::max(2 * nev + 1, (int)opt.eigsolver_min_lanczos);
     // positive-part mode is the library's own algorithm (not KrylovKit's call): a larger Krylov space
-    // resolves the bulk-edge pairs that decide it with fewer restarts (PROXSDP_HIP_POSKD = multiplier x 10)
+    // resolves the bulk-edge pairs that decide it with fewer restarts (options.full_eig_lanczos_kdim10)
     if (positive_part) {
-        static const int mult10 = std::getenv("PROXSDP_HIP_POSKD") ? std::atoi(std::getenv("PROXSDP_HIP_POSKD")) : 30;
+        const int mult10 = opt.full_eig_lanczos_kdim10 > 0 ? opt.full_eig_lanczos_kdim10 : 30;
         krylovdim = std::min(W.cap - 1, std::max(krylovdim, nev * mult10 / 10 + 8));
     }
     if (krylovdim + 1 > W.cap) throw std::invalid_argument("Lanczos workspace too small for the requested rank");
@@ -978,7 +980,7 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive
             // once and says nothing about the pairs around it)
             int jn = j;
             while (jn < K && D[jn] >= -1e-12 * scale) ++jn;
-            static const double posres = std::getenv("PROXSDP_HIP_POSRES") ? std::atof(std::getenv("PROXSDP_HIP_POSRES")) : 1e-7;
+            const double posres = opt.full_eig_lanczos_posres > 0.0 ? opt.full_eig_lanczos_posres : 1e-7;
             if (converged >= j && (jn == K || std::fabs(f[jn]) <= std::max(tol, posres * scale))) { pos_count = j; break; }
             if (K < krylovdim || numiter == maxiter) { pos_fail = true; break; }
         } else {
@@ -1095,7 +1097,7 @@ inline bool Solver::full_eig_by_sign(int idx, const double* xp_in, double* xp_ou
         const size_t sz = (size_t)ld * ld;
         W.sgA.alloc(sz); W.sgX.alloc(sz); W.sgX2.alloc(sz); W.sgY.alloc(sz); W.sgQ.alloc(sz);
         W.sgA.zero(stream);                                  // the padding stays zero: only entries < n are rewritten
-        static const int small_max = std::getenv("PROXSDP_HIP_SIGN_SMALL") ? std::atoi(std::getenv("PROXSDP_HIP_SIGN_SMALL")) : 3072;   // measured: 32-tiles win up to n ~ 3500
+        const int small_max = opt.sign_small_tile_max > 0 ? opt.sign_small_tile_max : 3072;   // measured: 32-tiles win up to n ~ 3500
         W.sg_small = ld <= small_max;
         const int nt32 = 2 * W.nt;
         W.sg_npart = W.sg_small ? 8 * ceil_div(nt32 * (nt32 + 1) / 2, 8) : grid;
@@ -1267,7 +1269,7 @@ inline void Solver::merge_block_stats() {
         st.symv_profiled += a.symv_profiled; st.symv_profiled_ms += a.symv_profiled_ms;
         st.orth_profiled += a.orth_profiled; st.orth_profiled_ms += a.orth_profiled_ms;
         st.full_eig_solver_ms += a.full_eig_solver_ms; st.full_eig_recon_ms += a.full_eig_recon_ms;
-        st.full_eigs_lanczos += a.full_eigs_lanczos; st.full_eigs_sign += a.full_eigs_sign; st.sign_products += a.sign_products; st.sign_engine_projections += a.sign_engine_projections; st.sign_engine_rejected += a.sign_engine_rejected; st.sign_engine_checks += a.sign_engine_checks; st.sign_engine_mismatches += a.sign_engine_mismatches; st.warm_starts += a.warm_starts; st.device_eigs += a.device_eigs; st.mfma_reconstructions += a.mfma_reconstructions; st.cycle_launches += a.cycle_launches;
+        st.full_eigs_lanczos += a.full_eigs_lanczos; st.full_eigs_sign += a.full_eigs_sign; st.sign_products += a.sign_products; st.sign_engine_projections += a.sign_engine_projections; st.sign_engine_rejected += a.sign_engine_rejected; st.sign_engine_checks += a.sign_engine_checks; st.sign_engine_mismatches += a.sign_engine_mismatches; st.full_eigs_lanczos_checks += a.full_eigs_lanczos_checks; st.full_eigs_lanczos_mismatches += a.full_eigs_lanczos_mismatches; st.batched_block_steps += a.batched_block_steps; st.device_restarts += a.device_restarts; st.block_eig_steps += a.block_eig_steps; st.warm_starts += a.warm_starts; st.device_eigs += a.device_eigs; st.mfma_reconstructions += a.mfma_reconstructions; st.cycle_launches += a.cycle_launches;
         st.cycle_steps += a.cycle_steps; st.cycle_ms += a.cycle_ms;
         st.symv_bytes += a.symv_bytes; st.host_eig_time += a.host_eig_time; st.host_eigs += a.host_eigs;
         st.fop_projections += a.fop_projections;
