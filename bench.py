@@ -50,6 +50,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--settle", type=int, default=200,
+                    help="untimed iterations BEFORE the warm-up, inside the same solve: a rank-63 solve started cold needs "
+                         "~150 iterations until its projections cost what they cost for the rest of the solve (188 -> 140 "
+                         "Lanczos steps per iteration); with them the --steps window measures the steady regime whatever "
+                         "--steps/--warmup are.  Stated in config.settle_iterations; 0 = the cold-start window.")
     ap.add_argument("--n", type=int, default=4000, help="PSD side (metric: 4000)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline sample budget")
@@ -88,6 +93,11 @@ def main():
     ap.add_argument("--reconstruct-mfma", dest="reconstruct_mfma", type=int, default=None)
     ap.add_argument("--lanczos-cycle-kernel", dest="lanczos_cycle_kernel", type=int, default=None,
                     help="library-only: -1 auto, 0 off, 1 on: persistent LDS-resident Lanczos cycle kernel")
+    ap.add_argument("--block-batch", dest="block_batch", type=int, default=None,
+                    help="library-only: equal-side PSD blocks in one launch per Lanczos step (-1 auto, 0 off = stream per block)")
+    ap.add_argument("--block-threads", dest="block_threads", type=int, default=None)
+    ap.add_argument("--device-restart", dest="device_restart", type=int, default=None)
+    ap.add_argument("--block-eigensolver", dest="block_eigensolver", type=int, default=None)
     ap.add_argument("--rand-n", type=int, default=2000)
     ap.add_argument("--rand-m", type=int, default=4000)
     ap.add_argument("--blocks", type=int, default=8)
@@ -117,7 +127,8 @@ def main():
     if args.workload == "sdplib":
         return bench_sdplib(args, torch, dist, rank, world, dev_id, backend)
     n = args.n
-    K, W = args.steps, args.warmup
+    K, W0 = args.steps, args.warmup
+    W = W0 + max(0, args.settle)                    # settle + warm-up iterations, all untimed
     pr = problems.maxcut(n, seed=replicas.replica_seed(args.seed, rank))
     N = n * (n + 1) // 2
     r0 = max(2, int(round(n ** 0.5))) if args.target_rank < 0 else args.target_rank
@@ -156,12 +167,13 @@ def main():
 
     out = {
         "metric": "PDHG iterations/sec at target rank ~ sqrt(n), Max-Cut SDP n=%d (tol 1e-4 options)" % n,
-        "value": value, "unit": "iterations/s", "n_gpus": world, "steps": K, "warmup": W,
+        "value": value, "unit": "iterations/s", "n_gpus": world, "steps": K, "warmup": W0,
         "ms_per_step": 1e3 * t_steps / K, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "Max-Cut SDP, Erdos-Renyi G(n,12/(n-1)) unit weights, n=%d, one PSD cone, Nx=%d, "
                                "p=%d equality rows; window pinned at target rank %d ~ sqrt(n)" % (n, N, n, r0),
                    "parallelism": "replicas x%d (single PSD block does not shard)" % world,
+                   "settle_iterations": W - W0, "warmup_iterations": W0,
                    "timed_iterations": [W + 1, W + K], "target_rank": rank_end, "krylovdim": krylovdim,
                    "lanczos_matvecs_per_step": mv_step, "linesearch_trials_per_step": trials_step,
                    "lanczos_restarts_per_step": st["lanczos_restarts"] / max(1, int(sol.iter)),
@@ -173,26 +185,32 @@ def main():
         "solve_wall_s": wall, "init_s": st["init_time"], "exit_s": st["exit_time"],
     }
 
+    if W > W0 and len(sol.trace) >= W0 + K:
+        # the same solve's cold-start window (what --settle 0 would have timed): first projections of a
+        # rank-63 solve need more Lanczos steps each
+        tc_, mvc_, _, _ = window(sol, W0, K)
+        out["cold_start_window"] = {"value": K / tc_, "unit": "iterations/s", "ms_per_step": 1e3 * tc_ / K,
+                                    "timed_iterations": [W0 + 1, W0 + K], "lanczos_matvecs_per_step": mvc_}
     solo = rank == 0 and world == 1
     if solo and not args.no_early_leg:
         # the first iterations of a solve with reference default options (target rank 2..5): the
         # cheapest regime, 25-46 mat-vecs per iteration -- side figure only
-        o4 = Optimizer(max_iter=W + K, device_id=dev_id, profile_symv_every=args.profile_every,
+        o4 = Optimizer(max_iter=W0 + K, device_id=dev_id, profile_symv_every=args.profile_every,
                        support_path=args.support_path, lanczos_operator=args.lanczos_operator, **extra_opts(args))
-        s4 = o4.optimize(pr, trace_capacity=W + K)
-        t4, mv4, tr4, rk4 = window(s4, W, K)
+        s4 = o4.optimize(pr, trace_capacity=W0 + K)
+        t4, mv4, tr4, rk4 = window(s4, W0, K)
         out["early_iterations"] = {"value": K / t4, "unit": "iterations/s", "ms_per_step": 1e3 * t4 / K,
-                                   "timed_iterations": [W + 1, W + K], "target_rank": rk4,
+                                   "timed_iterations": [W0 + 1, W0 + K], "target_rank": rk4,
                                    "lanczos_matvecs_per_step": mv4,
                                    "roofline": step_roofline(s4.stats, n, N, rk4, 25, mv4, 1e3 * t4 / K)}
 
     if solo and not args.no_packed_leg:
         # HBM evidence: the same early window with the reference's operator -- every mat-vec streams
         # the packed triangle through the tile kernel (8N + 16n bytes per launch, what dsymv('U') reads)
-        o1 = Optimizer(max_iter=W + K, device_id=dev_id, profile_symv_every=args.profile_every,
+        o1 = Optimizer(max_iter=W0 + K, device_id=dev_id, profile_symv_every=args.profile_every,
                        support_path=args.support_path, lanczos_operator=0)
-        s1 = o1.optimize(pr, trace_capacity=W + K)
-        t1 = window(s1, W, K)[0]
+        s1 = o1.optimize(pr, trace_capacity=W0 + K)
+        t1 = window(s1, W0, K)[0]
         ms = s1.stats["symv_profiled_ms"] / max(1, s1.stats["symv_profiled"])
         symv_bytes = 8.0 * N + 16.0 * n
         traffic, src = pmc_traffic("symv_packed", n)
@@ -226,25 +244,46 @@ def main():
         # (a) Lanczos path kept up to rank 64 ("rank ~ sqrt(n)"); (b) the reference's DEFAULT options:
         # max_target_rank_krylov_eigs = 16 (options.jl:76), so once target_rank reaches 17 every
         # iteration is a full eigendecomposition (prox_operators.jl:46-59), bounded by --default-time-limit
+        # Every leg carries its distance to the instance's PINNED optimum (tests/golden/maxcut_n4000_tight.json:
+        # tol-1e-6 solves with host-side LAPACK certificates, tools/gpurun_pin_metric.py) -- north_star's
+        # "same objective within 1e-4" is judged against that, not against another tol-1e-4 solve.
+        tight = None
+        tp = os.path.join(ROOT, "tests", "golden", "maxcut_n%d_tight.json" % n)
+        if os.path.exists(tp) and args.seed == 0:
+            tj = json.load(open(tp))
+            tight = {"objective": tj["objective"], "dual_bound": tj.get("dual_bound"), "source": "tests/golden/maxcut_n%d_tight.json "
+                     "(tol 1e-6, LAPACK certificate)" % n}
+        out["pinned_optimum"] = tight
+
         def tol_leg(**kw):
             o2 = Optimizer(device_id=dev_id, profile_symv_every=args.profile_every, **kw, **extra_opts(args))
             s2 = o2.optimize(pr)
             s = s2.stats
+            obj = o2.objective_value()
             return {"status": o2.termination_status(), "time_s": s2.time, "iterations": int(s2.iter),
-                    "objective": o2.objective_value(), "gap": s2.gap,
+                    "objective": obj, "gap": s2.gap,
+                    "objective_rel_diff_vs_tight": (abs(obj - tight["objective"]) / (1 + abs(tight["objective"]))) if tight else None,
                     "whole_solve_it_per_s": s2.iter / max(s["loop_time"], 1e-9), "loop_s": s["loop_time"],
                     "final_rank": int(s2.final_rank), "lanczos_matvecs": int(s["lanczos_matvecs"]),
                     "lanczos_restarts": int(s["lanczos_restarts"]), "full_eigs": int(s["full_eigs"]),
+                    "full_eigs_lanczos": int(s["full_eigs_lanczos"]),
+                    "full_eigs_lanczos_checks": int(s["full_eigs_lanczos_checks"]),
+                    "full_eigs_lanczos_mismatches": int(s["full_eigs_lanczos_mismatches"]),
                     "host_eigensolve_s": s["host_eig_time"], "device_eigensolves": int(s["device_eigs"]),
+                    "device_restarts": int(s["device_restarts"]),
                     "full_eig_solver_s": 1e-3 * s["full_eig_solver_ms"], "full_eig_recon_s": 1e-3 * s["full_eig_recon_ms"],
                     "options": kw}
-        out["time_to_tol"] = tol_leg(time_limit=300.0, max_target_rank_krylov_eigs=args.krylov_rank)
+        # THE metric's second half: the reference's own options (options.jl defaults: Krylov path up to target
+        # rank 16, full_eig! beyond -- served here by the Lanczos engine, verified against the dense engine)
         if args.default_time_limit > 0:
-            out["time_to_tol_default_options"] = tol_leg(time_limit=args.default_time_limit)
+            out["time_to_tol"] = tol_leg(time_limit=args.default_time_limit)
+            out["time_to_tol"]["label"] = "reference default options (max_target_rank_krylov_eigs = 16)"
+        # non-default knob, named in the key: Lanczos path kept up to rank 64 ("rank ~ sqrt(n)")
+        out["time_to_tol_krylov_rank%d" % args.krylov_rank] = tol_leg(time_limit=300.0, max_target_rank_krylov_eigs=args.krylov_rank)
         # library-only knob: every projection's Lanczos starts from the previous projection's Ritz vectors
         # instead of the reference's fixed start vector (same krylovkit_tol, fewer restarts)
-        out["time_to_tol_warm_start"] = tol_leg(time_limit=300.0, max_target_rank_krylov_eigs=args.krylov_rank,
-                                                lanczos_warm_start=1)
+        out["time_to_tol_krylov_rank%d_warm_start" % args.krylov_rank] = tol_leg(
+            time_limit=300.0, max_target_rank_krylov_eigs=args.krylov_rank, lanczos_warm_start=1)
 
     if solo and not args.no_time_to_tol:
         # full_eig! regime at the metric's size (what the reference falls into with default options once
@@ -267,17 +306,29 @@ def main():
         o.initial_target_rank = r0                              # the headline's regime on the CPU side too
         o.max_target_rank_krylov_eigs = kry
         tc = time.time()
-        ref = oracle.solve(pr, o)
+        omv = []
+        ref = oracle.solve(pr, o, trace=True, proj_callback=lambda it, xin, xout, p_, arc: omv.append(int(arc[0].matvecs)))
         cpu_it = max(int(ref.iter), 1)
         cpu_loop = ref.stats["loop_time"]
         tr = sol.trace
         gpu_same = float(tr[min(cpu_it, len(tr)) - 1, 12])
+        # the oracle's iterations ARE the headline solve's first iterations (same instance, same options):
+        # compare them instead of throwing them away -- objectives and Lanczos mat-vec counts per iteration
+        kk = min(cpu_it, len(tr), len(ref.trace))
+        o_mv = [omv[0]] + [omv[i] - omv[i - 1] for i in range(1, len(omv))]
+        o_po = np.array([t["prim_obj"] for t in ref.trace[:kk]]); o_do = np.array([t["dual_obj"] for t in ref.trace[:kk]])
+        sc_ = max(1.0, float(np.abs(o_po).max()), float(np.abs(o_do).max()))
+        parity = {"iterations_compared": kk,
+                  "max_abs_diff_objectives_over_scale": float(max(np.abs(tr[:kk, 1] - o_po).max(), np.abs(tr[:kk, 2] - o_do).max()) / sc_),
+                  "matvecs_per_iteration_oracle": o_mv[:kk], "matvecs_per_iteration_gpu": [int(v) for v in tr[:kk, 13]],
+                  "same_matvec_counts": bool([int(v) for v in tr[:kk, 13]] == o_mv[:kk])}
         out["cpu_baseline"] = {"value": cpu_it / cpu_loop, "unit": "iterations/s", "cores": ncores,
                                "kind": "port",
                                "sample": "NumPy/SciPy oracle restatement (not Julia), iterations 1-%d of the same instance "
                                          "at the same pinned target rank %d, %.1f s of CPU work, OpenBLAS threads=%d"
                                          % (cpu_it, r0, cpu_loop, ncores),
                                "gpu_it_per_s_same_iterations": min(cpu_it, len(tr)) / max(gpu_same, 1e-9),
+                               "parity_on_the_sample": parity,
                                "oracle_pin": "the oracle is pinned by the reference's known-answer tests (<= 4x4 PSD, atol 1e-2) and "
                                              "SDPLIB optima; its KrylovKit layer is a restatement of the published algorithm -- the "
                                              "reference holds no eigenpair / mat-vec-count vectors (parity unpinned at that layer)",
@@ -318,7 +369,7 @@ def extra_opts(args):
     """library-only knobs passed through to every GPU leg (empty = the KrylovKit-faithful parity path)"""
     kw = {}
     for name in ("lanczos_warm_start", "lanczos_cycle_kernel", "full_eig_lanczos", "reconstruct_mfma", "full_eig_sign",
-                 "psd_sign_engine"):
+                 "psd_sign_engine", "block_batch", "block_threads", "device_restart", "block_eigensolver"):
         v = getattr(args, name, None)
         if v is not None:
             kw[name] = v
@@ -433,6 +484,10 @@ def bench_randsdp(args, torch, dist, rank, world, dev_id, backend):
                                          "kernels traffic/algorithmic = 1.005 (A'y) and 1.018 (A x): profiles/r01_pmc_dense.md",
                          "bytes_per_launch": bytes_pass, "avg_launch_ms": pass_ms,
                          "launches": int(st["dense_passes"])},
+            "cpu_baseline": None,
+            "cpu_baseline_note": "none at this size: the 64 GB coefficient matrix exists only in HBM (the oracle would need it "
+                                 "in host memory and ~2 min per pass); the n=500, m=1000 instance is compared with the oracle "
+                                 "in tests/test_gpu_parity.py::test_randsdp_config_against_oracle",
             "generate_s": t_gen, "solve_wall_s": wall, "init_s": st["init_time"], "exit_s": st["exit_time"]}))
     if dist is not None:
         dist.destroy_process_group()
@@ -554,7 +609,8 @@ def bench_mimo(args, torch, dist, rank, world, dev_id, backend):
     sync()
     t0 = time.time()
     if dist is None:
-        opt = Optimizer(max_iter=W + K, device_id=dev_id, support_path=args.support_path, **extra_opts(args))
+        opt = Optimizer(max_iter=W + K, device_id=dev_id, support_path=args.support_path,
+                        profile_symv_every=args.profile_every, **extra_opts(args))
         sol = opt.optimize(model, trace_capacity=W + K)
     else:
         cdev = torch.device("cuda", dev_id) if backend == "nccl" else None
@@ -570,14 +626,45 @@ def bench_mimo(args, torch, dist, rank, world, dev_id, backend):
     _, t_steps = replicas.aggregate(dist, K, t_steps, device="cuda" if (dist is not None and backend == "nccl") else "cpu")
     if rank == 0:
         side = args.mimo_n + 1
+        st = sol.stats
+        Nb = side * (side + 1) // 2
+        roof = None
+        if st["symv_profiled"] > 0:
+            # dominant kernel: the (batched) packed-triangle mat-vec launch, 8N + 16n algorithmic bytes per block
+            ms = st["symv_profiled_ms"] / st["symv_profiled"]
+            blocks_per_launch = (st["batched_profiled_blocks"] / st["symv_profiled"]) if st["batched_profiled_blocks"] > 0 else 1.0
+            byts = blocks_per_launch * (8.0 * Nb + 16.0 * side)
+            roof = {"bound": "hbm", "kernel": "k_lzb_mv (batched: grid.z = block) -- step-closing workgroups + packed-triangle "
+                                              "mat-vec tiles of every live block" if st["batched_block_steps"] > 0 else "k_symv_finish (one launch per block)",
+                    "achieved": byts / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                    "bytes_per_launch": byts, "blocks_per_launch": blocks_per_launch, "avg_launch_ms": ms,
+                    "launches_profiled": int(st["symv_profiled"]),
+                    "note": "%d triangles of %.2f MB: L2/Infinity-Cache resident and far too small to fill the chip -- a "
+                            "latency-bound launch; the batch exists to advance all blocks' dependent chains per launch" % (args.blocks, 8.0 * Nb / 1e6)}
+        cpu = None
+        if world == 1 and not args.no_cpu:
+            import oracle                                           # baseline leg only
+            o = oracle.Options()
+            o.time_limit = min(args.cpu_seconds, 15.0)
+            tc = time.time()
+            ref = oracle.solve(model, o)
+            cpu = {"value": max(int(ref.iter), 1) / ref.stats["loop_time"], "unit": "iterations/s", "cores": os.cpu_count() or 1,
+                   "kind": "port", "sample": "NumPy/SciPy oracle restatement (not Julia), iterations 1-%d of the same %d-block model, "
+                                             "%.1f s of CPU work" % (int(ref.iter), args.blocks, ref.stats["loop_time"]),
+                   "wall_s": time.time() - tc}
         print(json.dumps({
+            "roofline": roof, "cpu_baseline": cpu,
+            "cpu_baseline_note": None if cpu is not None else "N > 1 or --no-cpu",
+            "lanczos_matvecs_per_step": st["lanczos_matvecs"] / max(1, int(sol.iter)),
+            "batched_block_steps": int(st["batched_block_steps"]),
             "metric": "PDHG iterations/sec, MIMO detection SDP n=%d x %d blocks (one block-diagonal model)" % (args.mimo_n, args.blocks),
             "value": K / t_steps, "unit": "iterations/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": 1e3 * t_steps / K, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "MIMO x%d: PSD side %d per block, Nx=%d, Q=%d; blocks sharded over %d rank(s)"
                                    % (args.blocks, side, model.n, model.A.shape[0] + model.G.shape[0], world),
-                       "parallelism": "block-sharded, scalar all-reduce x2 per iteration" if world > 1 else "single GPU, blocks in sequence",
+                       "parallelism": "block-sharded, scalar all-reduce per iteration" if world > 1 else "single GPU, equal-side blocks batched per launch (grid.z = block)",
                        "status_after_window": int(sol.status), "objective": float(sol.objval)},
             "solve_wall_s": wall}))
     if dist is not None:

@@ -317,7 +317,9 @@ typedef struct proxsdp_stats {
     int64_t rccl_reductions;         /* collectives issued by the library itself on its own stream (nccl_comm) */
     int64_t device_restarts;         /* thick restarts done entirely on the device (device_restart) */
     int64_t block_eig_steps;         /* block steps of the block eigensolver (block_eigensolver) */
-    int64_t reserved[6];
+    int64_t batched_profiled_blocks; /* block mat-vecs inside the event-bracketed batched launches (symv_profiled
+                                      * counts launches; bytes of those launches = this x (8 N + 16 n)) */
+    int64_t reserved[5];
 } proxsdp_stats;
 
 /* Result (structs.jl:60-81).  Arrays are caller-allocated with the stated

@@ -110,7 +110,8 @@ struct Stats                     # proxsdp_stats
     rccl_reductions::Int64
     device_restarts::Int64
     block_eig_steps::Int64
-    reserved::NTuple{6,Int64}
+    batched_profiled_blocks::Int64
+    reserved::NTuple{5,Int64}
 end
 
 mutable struct CResult           # proxsdp_result

@@ -134,7 +134,7 @@ class Stats(C.Structure):
                 ("sign_engine_checks", i64), ("sign_engine_mismatches", i64),
                 ("full_eigs_lanczos_checks", i64), ("full_eigs_lanczos_mismatches", i64),
                 ("batched_block_steps", i64), ("rccl_reductions", i64), ("device_restarts", i64),
-                ("block_eig_steps", i64), ("reserved", i64 * 6)]
+                ("block_eig_steps", i64), ("batched_profiled_blocks", i64), ("reserved", i64 * 5)]
 
 
 class Result(C.Structure):

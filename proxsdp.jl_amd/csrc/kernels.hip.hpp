@@ -421,13 +421,13 @@ struct FopArgs {
 // NCHP = 0: the mat-vec came from the packed tiles (Ppart / Apart).  NCHP > 0: it is rebuilt from
 // the operator-form pieces (16*NCHP*4 >= rp): A v = Vp (lam o (Vp' v)) + E v.
 template <int NCH, int NCHP>
-__global__ void __launch_bounds__(TPB)
-k_lz_orth(const double* __restrict__ Ppart, int nt, int npad, const double* __restrict__ V, int ldv, int k,
-          double* __restrict__ wbuf, const double* __restrict__ hred, double* __restrict__ hpart_out, int pld,
-          double* __restrict__ hsum_out, const LanczosCtl* __restrict__ ctl,
-          const double* __restrict__ alphas, const double* __restrict__ betas,
-          const double* __restrict__ Apart, int napart, int first, const double* __restrict__ arrow, int keep,
-          FopArgs fo) {
+__device__ __forceinline__ void
+lz_orth_body(const double* __restrict__ Ppart, int nt, int npad, const double* __restrict__ V, int ldv, int k,
+             double* __restrict__ wbuf, const double* __restrict__ hred, double* __restrict__ hpart_out, int pld,
+             double* __restrict__ hsum_out, const LanczosCtl* __restrict__ ctl,
+             const double* __restrict__ alphas, const double* __restrict__ betas,
+             const double* __restrict__ Apart, int napart, int first, const double* __restrict__ arrow, int keep,
+             const FopArgs& fo) {
     const int stop = ctl->stop;                      // tested after the loads below are in flight
     constexpr int NC = 16 * NCH;
     constexpr int NCP = 16 * (NCHP > 0 ? NCHP : 1);
@@ -597,6 +597,17 @@ k_lz_orth(const double* __restrict__ Ppart, int nt, int npad, const double* __re
         if (lane < 16 && jc <= k) hpart_out[(long long)jc * pld + blockIdx.x] = hs;
     }
 }
+template <int NCH, int NCHP>
+__global__ void __launch_bounds__(TPB)
+k_lz_orth(const double* __restrict__ Ppart, int nt, int npad, const double* __restrict__ V, int ldv, int k,
+          double* __restrict__ wbuf, const double* __restrict__ hred, double* __restrict__ hpart_out, int pld,
+          double* __restrict__ hsum_out, const LanczosCtl* __restrict__ ctl,
+          const double* __restrict__ alphas, const double* __restrict__ betas,
+          const double* __restrict__ Apart, int napart, int first, const double* __restrict__ arrow, int keep,
+          FopArgs fo) {
+    lz_orth_body<NCH, NCHP>(Ppart, nt, npad, V, ldv, k, wbuf, hred, hpart_out, pld, hsum_out, ctl, alphas, betas, Apart,
+                            napart, first, arrow, keep, fo);
+}
 
 // second pass applied and the step closed:
 //   h2 = sum of partial dots;  beta^2 = |w'|^2 - |h2|^2  (= |w' - V h2|^2 exactly, V being
@@ -726,6 +737,74 @@ k_symv_finish(const double* __restrict__ xp, int n, int nt, int npad, double* __
     else if (ctl->stop) return;
     else
         symv_tiles(xp, n, npad, nt * (nt + 1) / 2, wbuf, Ppart, (int)blockIdx.x - nt, (int)gridDim.x - nt, s_a, s_b, Apart);
+}
+
+// ---------------------------------------------------------------------------
+// BATCHED Lanczos step over several PSD blocks of EQUAL side (the reference projects the blocks of a model one
+// after the other, prox_operators.jl:40-61; north_star: "a batched symmetric mat-vec for the Lanczos
+// recurrence").  grid.z = block: the workgroups of block z run exactly the single-block bodies above on that
+// block's buffers, so results, mat-vec counts and restart counts per block are those of the one-block-at-a-time
+// path; what changes is that ONE launch advances every block's (latency-bound) recurrence, instead of one
+// stream + host thread per block contending for the hardware queues.  Blocks restart at different basis sizes
+// (keep depends on the converged count), so the step index is PER BLOCK and a block that has finished its
+// cycle idles (mode 0) until the others have.  Packed-triangle operator, krylovdim <= 63 (NCH = 1).
+// ---------------------------------------------------------------------------
+constexpr int LZB_MAX = 8;
+struct LzBlk {
+    const double* xp;            // packed block of the iterate
+    double* Ppart; double* wbuf; double* V;
+    double* hpart1; double* hpart2; double* hsum; double* alphas; double* betas;
+    LanczosCtl* ctl;
+    double* Apart; double* hred;
+    const double* arrow; const double* resid;
+    int k;                       // Lanczos step whose mat-vec this launch runs (basis column k)
+    int keep;                    // first step of the block's current cycle (0, or the restart's keep)
+    int mode;                    // k_lzb_mv: 0 idle | 1 first mat-vec of a cycle (on v_k) | 2 close step k-1 + mat-vec of
+                                 // step k on w' | 3 close step k-1 only (end of the cycle).  k_lzb_orth: != 0 = active
+    int pad;
+};
+struct LzBatch {
+    LzBlk b[LZB_MAX];
+    int n, nt, npad, pld, napart, nb;
+    double tol;
+};
+__global__ void __launch_bounds__(TPB)
+k_lzb_begin(LzBatch B) {
+    const LzBlk& b = B.b[blockIdx.z];
+    if (b.mode == 0) return;
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i < B.npad) b.V[i] = b.resid[i];
+    if (i == 0) { b.ctl->stop = 0; b.ctl->kstop = 0; b.ctl->carry = 0.0; }
+}
+// workgroups [0, nt): closing work; [nt, nt + ntile): mat-vec tiles (as k_symv_finish / k_symv_packed)
+__global__ void __launch_bounds__(TPB)
+k_lzb_mv(LzBatch B) {
+    __shared__ double s_a[2 * NWAVE * TILE];
+    __shared__ double s_b[NWAVE * LZ_ROWS];
+    __shared__ double s_beta;
+    const LzBlk& b = B.b[blockIdx.z];
+    const int mode = b.mode;
+    if (mode == 0) return;
+    const int nt = B.nt;
+    if ((int)blockIdx.x < nt) {
+        if (mode == 1) return;
+        const int kc = b.k - 1;
+        lz_finish_body<1>(b.wbuf, b.V, B.npad, kc, (kc & 1) ? b.hpart2 : b.hpart1, B.pld, b.hsum, b.alphas, b.betas, b.ctl,
+                          B.tol, kc > b.keep ? 1 : 0, blockIdx.x, s_a, s_b, &s_beta, b.hred);
+    } else {
+        if (mode == 3 || b.ctl->stop) return;
+        const double* v = (mode == 1) ? b.V + (long long)b.k * B.npad : b.wbuf;
+        symv_tiles(b.xp, B.n, B.npad, nt * (nt + 1) / 2, v, b.Ppart, (int)blockIdx.x - nt, (int)gridDim.x - nt, s_a, s_b,
+                   b.Apart);
+    }
+}
+__global__ void __launch_bounds__(TPB)
+k_lzb_orth(LzBatch B) {
+    const LzBlk& b = B.b[blockIdx.z];
+    if (b.mode == 0) return;
+    FopArgs fo{};
+    lz_orth_body<1, 0>(b.Ppart, B.nt, B.npad, b.V, B.npad, b.k, b.wbuf, b.hred, (b.k & 1) ? b.hpart2 : b.hpart1, B.pld,
+                       b.hsum, b.ctl, b.alphas, b.betas, b.Apart, B.napart, b.k == b.keep ? 1 : 0, b.arrow, b.keep, fo);
 }
 
 // ---------------------------------------------------------------------------

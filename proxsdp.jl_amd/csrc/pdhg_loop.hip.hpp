@@ -68,16 +68,62 @@ inline void Solver::reduce_coupling(double* Mx_dev) {
 
 // psd_projection! (prox_operators.jl:33-66), one block: reads the packed block of xin,
 // writes the projected block into xout (xin == xout on the dense path)
-inline void Solver::project_block(int idx, const double* xin, double* xout, bool fuse) {
+// the branch condition of psd_projection! (prox_operators.jl:46-49)
+inline bool Solver::krylov_branch(int idx) const {
+    return !opt.full_eig_decomp && target_rank[idx] <= opt.max_target_rank_krylov_eigs &&
+           eig[idx].n > opt.min_size_krylov_eigs && (iter % opt.full_eig_freq) > opt.full_eig_len;
+}
+// may this block's Lanczos run ride in a batched launch (solver.hip.hpp lanczos_batch)?
+inline bool Solver::batch_eligible(int idx, bool fuse) const {
+    const EigWork& W = eig[idx];
+    if (opt.block_batch == 0 || !krylov_branch(idx)) return false;
+    if (opt.eigsolver == 1 || opt.psd_sign_engine == 1 || opt.lanczos_warm_start != 0 || opt.lanczos_cycle_kernel == 1)
+        return false;
+    // operator-form blocks keep their own path (their step kernels take per-block factor ranks)
+    if (fuse && use_support && opt.lanczos_operator != 0 && W.fop_ok && (W.have_factors || W.x_prev_sparse)) return false;
+    return std::max(2 * (int)target_rank[idx] + 1, (int)opt.eigsolver_min_lanczos) <= 63;
+}
+// psd_projection!'s loop over the blocks (prox_operators.jl:40-61): blocks of equal side whose Lanczos runs can
+// be batched go through ONE launch per step (groups of up to LZB_MAX), the rest through run_blocks
+// (one stream + host thread per block, or in sequence)
+inline void Solver::project_blocks(const std::vector<int>& blocks, const double* xin, double* xout, bool fuse) {
+    std::vector<int> rest;
+    std::vector<std::vector<int>> groups;
+    if (opt.block_batch != 0 && blocks.size() >= 2) {
+        std::vector<int> cand;
+        for (int idx : blocks) (batch_eligible(idx, fuse) ? cand : rest).push_back(idx);
+        std::stable_sort(cand.begin(), cand.end(), [this](int a, int b) { return eig[a].n < eig[b].n; });
+        size_t i0 = 0;
+        while (i0 < cand.size()) {
+            size_t i1 = i0;
+            while (i1 < cand.size() && eig[cand[i1]].n == eig[cand[i0]].n && i1 - i0 < (size_t)dev::LZB_MAX) ++i1;
+            if (i1 - i0 >= 2) groups.emplace_back(cand.begin() + i0, cand.begin() + i1);
+            else rest.push_back(cand[i0]);
+            i0 = i1;
+        }
+        std::sort(rest.begin(), rest.end());
+    } else {
+        rest = blocks;
+    }
+    for (const std::vector<int>& g : groups) {
+        std::vector<int> nevs;
+        for (int idx : g) { current_rank[idx] = 0; nevs.push_back((int)target_rank[idx]); }
+        lanczos_batch(g, xin, nevs);
+        for (int idx : g) project_block(idx, xin, xout, fuse, true);
+    }
+    if (!groups.empty()) merge_block_stats();
+    if (!rest.empty()) run_blocks(rest, [this, xin, xout, fuse](int idx) { project_block(idx, xin, xout, fuse); });
+}
+
+inline void Solver::project_block(int idx, const double* xin, double* xout, bool fuse, bool lanczos_done) {
     EigWork& W = eig[idx];
     const double* xp = xin + P.blocks[idx].off;
     double* xo = xout + P.blocks[idx].off;
     current_rank[idx] = 0;
-    const bool krylov = !opt.full_eig_decomp && target_rank[idx] <= opt.max_target_rank_krylov_eigs &&
-                        W.n > opt.min_size_krylov_eigs && (iter % opt.full_eig_freq) > opt.full_eig_len;
+    const bool krylov = lanczos_done || krylov_branch(idx);
     // operator-form mat-vec: legal when this block's x_prev is known in factored form (or is
     // zero off the support) and the update is the sparse support update of this iteration
-    W.use_fop = fuse && use_support && opt.lanczos_operator != 0 && W.fop_ok && krylov &&
+    W.use_fop = !lanczos_done && fuse && use_support && opt.lanczos_operator != 0 && W.fop_ok && krylov &&
                 (W.have_factors || W.x_prev_sparse);
     if (W.use_fop) {
         if (!W.have_factors) { W.F_r = 0; W.F_first = 0; }
@@ -109,12 +155,14 @@ inline void Solver::project_block(int idx, const double* xin, double* xout, bool
     }
     const bool used_fop = W.use_fop;
     const int nev = (int)target_rank[idx];
-    if (exact_projection_by_sign(idx, xp, xo, fuse, nev)) return;
-    const double t_kry = opt.psd_sign_engine == 1 ? now_s() : 0.0;
-    lanczos(W, xp, nev);
-    if (opt.psd_sign_engine == 1 && W.converged) {
-        const double ms = (now_s() - t_kry) * 1e3;
-        W.kry_ms = W.kry_ms < 0 ? ms : 0.75 * W.kry_ms + 0.25 * ms;
+    if (!lanczos_done) {                      // (a batched run has already filled W.vals / W.Z)
+        if (exact_projection_by_sign(idx, xp, xo, fuse, nev)) return;
+        const double t_kry = opt.psd_sign_engine == 1 ? now_s() : 0.0;
+        lanczos(W, xp, nev);
+        if (opt.psd_sign_engine == 1 && W.converged) {
+            const double ms = (now_s() - t_kry) * 1e3;
+            W.kry_ms = W.kry_ms < 0 ? ms : 0.75 * W.kry_ms + 0.25 * ms;
+        }
     }
     W.use_fop = false;
     if (used_fop) W.lst.fop_projections++;
@@ -353,9 +401,9 @@ inline void Solver::psd_projection(double* x) {
     }
     if (!small_blocks.empty()) {
         project_small_blocks(x);
-        run_blocks(large_blocks, [this, x](int idx) { project_block(idx, x, x, false); });
+        project_blocks(large_blocks, x, x, false);
     } else {
-        run_blocks(big_blocks, [this, x](int idx) { project_block(idx, x, x, false); });
+        project_blocks(big_blocks, x, x, false);
     }
 }
 
@@ -392,7 +440,7 @@ inline void Solver::primal_step_dev() {
                            xcur, supp_d.p, MtyS_cur.p, cS_d.p, primal_step, xsave_d.p, ns, esv_d.p);
         std::fill(min_eig.begin(), min_eig.end(), 0.0);
         double t0 = now_s();
-        run_blocks(big_blocks, [this, xcur, xnew](int idx) { project_block(idx, xcur, xnew, true); });
+        project_blocks(big_blocks, xcur, xnew, true);
         st.t_psd += now_s() - t0;
         if (P.sdplen < P.n)
             hipLaunchKernelGGL(dev::k_tail_copy_res, dim3(n_res_wg - tile_base.back()), dim3(dev::TPB), 0, stream,

@@ -259,6 +259,11 @@ public:
     void setup_device();
     void alloc_eigwork(EigWork& W, int n, int max_nev);
     void lanczos(EigWork& W, const double* xp, int nev, bool positive_part = false);
+    void lanczos_batch(const std::vector<int>& blocks, const double* xbase, const std::vector<int>& nevs);
+    bool lz_init(EigWork& W, struct LzRun& R, int nev, bool positive_part);
+    void lz_prepare_arrow(struct LzRun& R);
+    bool lz_after_cycle(EigWork& W, struct LzRun& R, bool speculated);
+    void lz_finish_run(EigWork& W, struct LzRun& R);
     void full_eig_values(EigWork& W, const double* xp, double offscale, bool vectors, std::vector<double>& Dhost);
     void harvest_full_eig_events(EigWork& W);
     bool cycle_plan(const EigWork& W, int krylovdim, int& R, int& G, bool& f_in_lds) const;
@@ -385,7 +390,10 @@ private:
 
     void primal_step_dev();
     void psd_projection(double* x);
-    void project_block(int idx, const double* xin, double* xout, bool fuse);
+    void project_block(int idx, const double* xin, double* xout, bool fuse, bool lanczos_done = false);
+    void project_blocks(const std::vector<int>& blocks, const double* xin, double* xout, bool fuse);
+    bool krylov_branch(int idx) const;
+    bool batch_eligible(int idx, bool fuse) const;
     void setup_support();
     int  linesearch_residual_support();
     void setup_dense();
@@ -754,8 +762,24 @@ inline void Solver::rotate(EigWork& W, int K, const std::vector<double>& U, int 
 // below zero while small positive eigenvalues are still unresolved -- measured on gpp500-1.)
 // Returns the j positive pairs (count = j, possibly 0, converged = true), or converged = false when
 // more than nev Ritz values are positive / maxiter is hit.
-inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive_part) {
-    const bool arpack = (opt.eigsolver == 1);
+// Host state of ONE thick-restart Lanczos run (one PSD block): what KrylovKit keeps between the restarts of an
+// eigsolve call.  Split out of Solver::lanczos so that the single-block driver and the batched multi-block driver
+// (lanczos_batch: one launch per step for several blocks) share the restart logic line by line.
+struct LzRun {
+    int nev = 0, krylovdim = 0, ld = 0;
+    bool arpack = false, positive_part = false;
+    double tol = 0.0, step_tol = 0.0;
+    long long maxiter = 0;
+    std::vector<double> T, Tw, D, U, f, al, be, Qa, da, ea;
+    int howmany = 0, numiter = 1, converged = 0, K = 0, kfirst = 0, pos_count = -1, m_arrow = 0;
+    bool pos_fail = false, presymv = false;
+    double betaK = 0.0;
+};
+
+// parameters of the run and the per-call reset of W; false = the call ends at once (dsaupd argument errors)
+inline bool Solver::lz_init(EigWork& W, LzRun& R, int nev, bool positive_part) {
+    R.nev = nev; R.positive_part = positive_part;
+    R.arpack = (opt.eigsolver == 1);
     int krylovdim = std::max(2 * nev + 1, (int)opt.eigsolver_min_lanczos);
     // positive-part mode is the library's own algorithm (not KrylovKit's call): a larger Krylov space
     // resolves the bulk-edge pairs that decide it with fewer restarts (options.full_eig_lanczos_kdim10)
@@ -764,16 +788,181 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive
         krylovdim = std::min(W.cap - 1, std::max(krylovdim, nev * mult10 / 10 + 8));
     }
     if (krylovdim + 1 > W.cap) throw std::invalid_argument("Lanczos workspace too small for the requested rank");
-    if (krylovdim >= 96) QlPool::get().arm();            // host eigensolve helpers wake up under the first Lanczos cycle
-    const double tol = arpack ? opt.arpack_tol : opt.krylovkit_tol;
-    const long long maxiter = arpack ? (long long)opt.arpack_max_iter : (long long)opt.krylovkit_max_iter;
-    if (!arpack && opt.krylovkit_eager) throw std::invalid_argument("krylovkit_eager=true is not implemented");
+    R.krylovdim = krylovdim;
+    R.tol = R.arpack ? opt.arpack_tol : opt.krylovkit_tol;
+    R.maxiter = R.arpack ? (long long)opt.arpack_max_iter : (long long)opt.krylovkit_max_iter;
+    if (!R.arpack && opt.krylovkit_eager) throw std::invalid_argument("krylovkit_eager=true is not implemented");
     W.prev_numiter = std::max(W.numiter, 1);
     W.converged = false; W.count = 0; W.converged_eigs = 0; W.numiter = 0; W.vals.clear();
     W.lst.lanczos_calls++;
-    if (arpack && (!(0 < nev && nev < W.n) || krylovdim > W.n)) return;   // dsaupd info=-1/-3 -> error -> fallback
+    if (R.arpack && (!(0 < nev && nev < W.n) || krylovdim > W.n)) return false;   // dsaupd info=-1/-3 -> error -> fallback
+    R.step_tol = R.arpack ? 0.0 : R.tol;          // invariant-subspace test inside the recurrence
+    R.ld = krylovdim + 1;
+    R.T.assign((size_t)R.ld * R.ld, 0.0); R.D.assign(R.ld, 0.0); R.f.assign(R.ld, 0.0);
+    R.al.assign(R.ld, 0.0); R.be.assign(R.ld, 0.0);
+    R.howmany = nev; R.numiter = 1; R.converged = 0; R.K = 0; R.kfirst = 0; R.pos_count = -1;
+    R.pos_fail = false; R.presymv = false; R.betaK = 0.0;
+    return true;
+}
 
-    const double step_tol = arpack ? 0.0 : tol;       // invariant-subspace test inside the recurrence
+// while the GPU works through the enqueued steps: reduce the arrow part [diag(D) f; f' .] of this cycle's
+// Rayleigh quotient (known since the restart) to tridiagonal form, so that only the QL sweep is left on
+// the critical path once alpha/beta arrive (host_util.hpp symeig_tridiag_from; K = 53: 108 -> 54 us,
+// K = 127: 1330 -> 544 us)
+inline void Solver::lz_prepare_arrow(LzRun& R) {
+    R.m_arrow = R.kfirst;
+    if (R.m_arrow <= 0) return;
+    const int n1 = R.m_arrow + 1, ld = R.ld;
+    R.Qa.assign((size_t)n1 * n1, 0.0); R.da.assign(n1, 0.0); R.ea.assign(n1, 0.0);
+    for (int j = 0; j < R.m_arrow; ++j) {
+        R.Qa[(size_t)j * n1 + j] = R.T[(size_t)j * ld + j];
+        R.Qa[(size_t)j * n1 + R.m_arrow] = R.Qa[(size_t)R.m_arrow * n1 + j] = R.T[(size_t)j * ld + R.m_arrow];
+    }
+    householder_tridiag(n1, R.Qa.data(), R.da.data(), R.ea.data());
+}
+
+// After a cycle's read-back (W.rec_host valid): Rayleigh quotient, K x K eigensolve, convergence.  Returns true
+// when the run goes on: the restart rotation has been enqueued and R.kfirst / R.T describe the next cycle;
+// false when the run is over (lz_finish_run produces the results).  `speculated`: the first mat-vec of the
+// next cycle was already enqueued before the read-back.
+inline bool Solver::lz_after_cycle(EigWork& W, LzRun& R, bool speculated) {
+    const int krylovdim = R.krylovdim, ld = R.ld, kfirst = R.kfirst, nev = R.nev;
+    const double tol = R.tol;
+    std::vector<double>& T = R.T; std::vector<double>& D = R.D; std::vector<double>& U = R.U;
+    std::vector<double>& f = R.f; std::vector<double>& al = R.al; std::vector<double>& be = R.be;
+    dev::LanczosCtl hctl{};
+    std::copy(W.rec_host, W.rec_host + krylovdim, al.begin());
+    std::copy(W.rec_host + dev::MAXK, W.rec_host + dev::MAXK + krylovdim, be.begin());
+    std::memcpy(&hctl, W.rec_host + 2 * dev::MAXK, sizeof(hctl));
+    const int Kend = hctl.stop ? hctl.kstop : krylovdim;
+    // launches after the stop flag are no-ops; count the mat-vecs that did work
+    {
+        long long skipped = (long long)(krylovdim - Kend);
+        W.lst.lanczos_matvecs += (Kend - kfirst);
+        W.lst.symv_launches -= skipped;
+        W.lst.symv_bytes -= skipped * (8.0 * (double)W.N + 16.0 * (double)W.n);
+        W.mv_iter += (Kend - kfirst);
+    }
+    for (int k = kfirst; k < Kend; ++k) {
+        T[(size_t)k * ld + k] = al[k];
+        if (k + 1 < Kend) { T[(size_t)k * ld + k + 1] = be[k]; T[(size_t)(k + 1) * ld + k] = be[k]; }
+    }
+    const int K = R.K = Kend;
+    const double betaK = R.betaK = be[K - 1];
+    if (!(betaK == betaK)) {                         // NaN guard: treat as not converged
+        R.converged = 0; R.pos_fail = true; R.howmany = 0;
+        return false;
+    }
+    if (betaK <= tol && K < R.howmany && !R.arpack) R.howmany = K;
+    if (K == 1) {
+        D[0] = T[0]; U.assign(1, 1.0); f[0] = betaK;
+    } else {
+        R.Tw.assign((size_t)K * K, 0.0);
+        for (int c = 0; c < K; ++c)
+            for (int r = 0; r < K; ++r) R.Tw[(size_t)c * K + r] = T[(size_t)c * ld + r];
+        std::vector<double> Dasc(K);
+        const double te0 = now_s();
+        if (R.m_arrow > 0 && K > R.m_arrow)
+            symeig_tridiag_from(K, R.m_arrow, R.Qa.data(), R.da.data(), R.ea.data(), al.data(), be.data(), R.Tw.data(), Dasc.data());
+        else
+            symeig_dense(K, R.Tw.data(), Dasc.data(), kfirst == 0);
+        W.lst.host_eig_time += now_s() - te0; W.lst.host_eigs++;
+        U.assign((size_t)K * K, 0.0);
+        for (int c = 0; c < K; ++c) {                // :LR -> descending
+            D[c] = Dasc[K - 1 - c];
+            for (int r = 0; r < K; ++r) U[(size_t)c * K + r] = R.Tw[(size_t)(K - 1 - c) * K + r];
+            f[c] = betaK * U[(size_t)c * K + (K - 1)];
+        }
+    }
+    int converged = 0;
+    if (!R.arpack) {
+        while (converged < K && std::fabs(f[converged]) <= tol) ++converged;
+    } else {
+        const double eps23 = std::pow(2.220446049250313e-16 / 2.0, 2.0 / 3.0);
+        int want = std::min(nev, K);
+        for (int i = 0; i < want; ++i)
+            if (std::fabs(f[i]) <= tol * std::max(eps23, std::fabs(D[i]))) ++converged;
+    }
+    R.converged = converged;
+    if (R.positive_part) {
+        int j = 0;
+        while (j < K && D[j] > 0.0) ++j;
+        if (j > nev) { R.pos_fail = true; return false; }      // more positive pairs than the workspace was sized for
+        const double scale = std::max(std::fabs(D[0]), std::fabs(D[K - 1]));
+        // the deciding pair: the first STRICTLY negative Ritz value (an exactly-zero pair with zero
+        // residual is what a decoupled, unused coordinate of the block looks like: it is found at
+        // once and says nothing about the pairs around it)
+        int jn = j;
+        while (jn < K && D[jn] >= -1e-12 * scale) ++jn;
+        const double posres = opt.full_eig_lanczos_posres > 0.0 ? opt.full_eig_lanczos_posres : 1e-7;
+        if (converged >= j && (jn == K || std::fabs(f[jn]) <= std::max(tol, posres * scale))) { R.pos_count = j; return false; }
+        if (K < krylovdim || R.numiter == R.maxiter) { R.pos_fail = true; return false; }
+    } else {
+        if (converged >= R.howmany) return false;
+        if (K < krylovdim) return false;                 // invariant subspace without convergence (arpack rule)
+    }
+    if (R.numiter == R.maxiter) return false;
+    const int keep = R.arpack ? std::min(krylovdim - 1, nev + std::max(1, (krylovdim - nev) / 2))
+                              : (3 * krylovdim + 2 * converged) / 5;
+    // arrow part of the restarted T for k_lz_orth: f (couplings of v_K with the kept Ritz
+    // vectors) and D (their Ritz values)
+    for (int j = 0; j < keep; ++j) { W.arrow_host.p[j] = f[j]; W.arrow_host.p[dev::MAXK + j] = D[j]; }
+    rotate(W, K, U, K, keep, W.Z.p, K, keep, W.arrow_host.p, 2 * dev::MAXK);   // Z[:, :keep] = V U[:, :keep]; Z[:, keep] = V[:, K]
+    std::swap(W.V.p, W.Z.p);
+    std::fill(T.begin(), T.end(), 0.0);
+    for (int j = 0; j < keep; ++j) {
+        T[(size_t)j * ld + j] = D[j];
+        T[(size_t)j * ld + keep] = f[j];
+        T[(size_t)keep * ld + j] = f[j];
+    }
+    R.kfirst = keep;
+    R.presymv = speculated;
+    ++R.numiter;
+    W.lst.lanczos_restarts++;
+    return true;
+}
+
+// results of the run (KrylovKit's return values / dseupd's), Ritz vectors into W.Z
+inline void Solver::lz_finish_run(EigWork& W, LzRun& R) {
+    const int K = R.K, nev = R.nev;
+    W.numiter = R.numiter;
+    if (R.positive_part) {
+        if (R.pos_fail || R.pos_count < 0) { W.converged = false; return; }
+        W.count = R.pos_count; W.converged_eigs = R.pos_count; W.converged = true;
+        W.vals.assign(R.D.begin(), R.D.begin() + R.pos_count);
+        if (R.pos_count > 0) rotate(W, K, R.U, K, R.pos_count, W.Z.p, -1, 0, nullptr, 0);
+        return;
+    }
+    if (R.pos_fail) { W.converged = false; return; }     // NaN guard
+    if (R.arpack) {
+        // _saupd!/_seupd! (eigsolver.jl:668-746): converged only when all nev pairs are
+        W.converged_eigs = R.converged;
+        if (R.converged < nev) { W.converged = false; return; }
+        W.count = nev;
+        W.vals.assign(R.D.begin(), R.D.begin() + nev);
+        std::reverse(W.vals.begin(), W.vals.end());      // arc.d is ascending
+        std::vector<double> Ur((size_t)K * nev);
+        for (int c = 0; c < nev; ++c)
+            for (int r = 0; r < K; ++r) Ur[(size_t)c * K + r] = R.U[(size_t)(nev - 1 - c) * K + r];
+        rotate(W, K, Ur, K, nev, W.Z.p, -1, 0, nullptr, 0);
+        W.converged = true;
+        return;
+    }
+    int howmany = R.howmany;
+    if (R.converged > howmany) howmany = R.converged;
+    W.count = howmany;
+    W.vals.assign(R.D.begin(), R.D.begin() + howmany);
+    W.converged_eigs = R.converged;
+    W.converged = (R.converged != 0);                    // eigsolver.jl:816-818
+    rotate(W, K, R.U, K, howmany, W.Z.p, -1, 0, nullptr, 0);          // Ritz vectors B*v
+}
+
+inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive_part) {
+    LzRun R;
+    if (!lz_init(W, R, nev, positive_part)) return;
+    const int krylovdim = R.krylovdim;
+    const double step_tol = R.step_tol;
+    if (krylovdim >= 96) QlPool::get().arm();            // host eigensolve helpers wake up under the first Lanczos cycle
     if (opt.lanczos_warm_start != 0 && !positive_part && W.fop_ok && W.have_factors && W.F_r > 0 && W.tpart.n > 0) {
         // start from the previous projection's Ritz vectors (library-only knob; the reference starts
         // every projection from the same fixed vector, krylovkit_reset_resid = false)
@@ -788,28 +977,22 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive
     hipLaunchKernelGGL(dev::k_lz_begin, dim3(ceil_div(W.npad, dev::TPB)), dim3(dev::TPB), 0, stream,
                        W.V.p, (const double*)W.resid.p, W.npad, W.ctl_p);
 
-    const int ld = krylovdim + 1;
-    std::vector<double> T((size_t)ld * ld, 0.0), Tw, D(ld), U, f(ld), al(ld), be(ld), Qa, da, ea;
-    int howmany = nev, numiter = 1, converged = 0, K = 0, kfirst = 0, pos_count = -1;
-    bool pos_fail = false;
-    bool presymv = false;
-    double betaK = 0.0;
-    dev::LanczosCtl hctl{};
     int cyR = 0, cyG = 0;
     bool cyF = false;
     const bool cyc = cycle_plan(W, krylovdim, cyR, cyG, cyF);
     int cy_err_host = 0;
     if (cyc && W.cy_err_host.p == nullptr) { W.cy_err_host.alloc(1); W.cy_err_host.p[0] = 0.0; }
     while (true) {
+        const int kfirst = R.kfirst;
         if (cyc) {
             launch_cycle(W, kfirst, krylovdim, step_tol, cyR, cyG, cyF);
             PX_HIP(hipMemcpyAsync(W.cy_err_host.p, W.cy_err.p, sizeof(int), hipMemcpyDeviceToHost, stream));
         } else {
         for (int k = kfirst; k < krylovdim; ++k) {
             if (k == kfirst) {
-                if (!presymv) launch_symv(W, xp, W.V.p + (size_t)k * W.npad, true);   // v_k is ready (start)
+                if (!R.presymv) launch_symv(W, xp, W.V.p + (size_t)k * W.npad, true);   // v_k is ready (start)
                 else { W.lst.symv_launches++; W.lst.symv_bytes += 8.0 * (double)W.N + 16.0 * (double)W.n; }
-                presymv = false;               // after a restart the mat-vec of v_keep is already in Ppart
+                R.presymv = false;             // after a restart the mat-vec of v_keep is already in Ppart
             } else {
                 // close step k-1 and run the mat-vec of step k in one launch
                 launch_symv_finish(W, xp, k - 1, step_tol, k - 1 > kfirst);
@@ -862,31 +1045,18 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive
         hipLaunchKernelGGL(klf, dim3(W.nt), dim3(dev::TPB), 0, stream,
                            W.w.p, W.n, W.V.p, W.npad, krylovdim - 1, lz_hpart(W, krylovdim - 1), W.pld, W.hsum1.p,
                            W.alphas_p, W.betas_p, W.ctl_p, step_tol, (krylovdim - 1 > kfirst) ? 1 : 0, W.hred.p);
+        }
         // the first mat-vec of a possible next cycle only needs v_K = V[:,krylovdim], which is
         // final now: enqueue it before the host round trip so the GPU works during the K x K
         // eigensolve (wasted only when this cycle turns out to be the last one)
         // -- speculated only when this block's previous projection needed a restart too
-        }
-        const bool speculate = !cyc && (W.prev_numiter > 1 || numiter > 1);
+        const bool speculate = !cyc && (W.prev_numiter > 1 || R.numiter > 1);
         if (speculate) {
             launch_symv(W, xp, W.V.p + (size_t)krylovdim * W.npad, true);
             W.lst.symv_launches--; W.lst.symv_bytes -= 8.0 * (double)W.N + 16.0 * (double)W.n;   // counted when used
         }
         PX_HIP(hipMemcpyAsync(W.rec_host, W.rec.p, EigWork::REC_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, stream));
-        // while the GPU works through the enqueued steps: reduce the arrow part [diag(D) f; f' .]
-        // of this cycle's Rayleigh quotient (known since the restart) to tridiagonal form, so that
-        // only the QL sweep is left on the critical path once alpha/beta arrive
-        // (host_util.hpp symeig_tridiag_from; K = 53: 108 -> 54 us, K = 127: 1330 -> 544 us)
-        const int m_arrow = kfirst;
-        if (m_arrow > 0) {
-            const int n1 = m_arrow + 1;
-            Qa.assign((size_t)n1 * n1, 0.0); da.assign(n1, 0.0); ea.assign(n1, 0.0);
-            for (int j = 0; j < m_arrow; ++j) {
-                Qa[(size_t)j * n1 + j] = T[(size_t)j * ld + j];
-                Qa[(size_t)j * n1 + m_arrow] = Qa[(size_t)m_arrow * n1 + j] = T[(size_t)j * ld + m_arrow];
-            }
-            householder_tridiag(n1, Qa.data(), da.data(), ea.data());
-        }
+        lz_prepare_arrow(R);                             // (host work under the GPU's cycle)
         PX_HIP(hipStreamSynchronize(stream));
         if (W.cye_pending) {
             W.cye_pending = false;
@@ -903,9 +1073,6 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive
             lanczos(W, xp, nev, positive_part);
             return;
         }
-        std::copy(W.rec_host, W.rec_host + krylovdim, al.begin());
-        std::copy(W.rec_host + dev::MAXK, W.rec_host + dev::MAXK + krylovdim, be.begin());
-        std::memcpy(&hctl, W.rec_host + 2 * dev::MAXK, sizeof(hctl));
         if (W.ev.used) {                                   // harvest profiled symv launches
             for (size_t s = 0; s < W.ev.used; ++s) {
                 float ms = 0.f;
@@ -922,118 +1089,105 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive
             }
         }
         W.evo.used = 0;
-        const int Kend = hctl.stop ? hctl.kstop : krylovdim;
-        // launches after the stop flag are no-ops; count the mat-vecs that did work
-        {
-            long long skipped = (long long)(krylovdim - Kend);
-            W.lst.lanczos_matvecs += (Kend - kfirst);
-            W.lst.symv_launches -= skipped;
-            W.lst.symv_bytes -= skipped * (8.0 * (double)W.N + 16.0 * (double)W.n);
-            W.mv_iter += (Kend - kfirst);
+        if (!lz_after_cycle(W, R, speculate)) break;
+    }
+    lz_finish_run(W, R);
+}
+
+// KrylovKit eigsolve of SEVERAL blocks of equal side at once (kernels.hip.hpp "BATCHED Lanczos step"): one
+// launch per step for all of them (grid.z = block) on the solver's stream, per-block host restart logic
+// (lz_after_cycle) between the cycles.  Per block the arithmetic, the mat-vec count and the restart count are
+// those of lanczos(); blocks that have converged drop out of the launches.  Preconditions (checked by
+// batch_eligible): plain KrylovKit mode, packed-triangle operator, krylovdim <= 63.
+inline void Solver::lanczos_batch(const std::vector<int>& blocks, const double* xbase, const std::vector<int>& nevs) {
+    const int nb = (int)blocks.size();
+    if (nb < 1 || nb > dev::LZB_MAX) throw std::invalid_argument("lanczos_batch: 1..LZB_MAX blocks");
+    std::vector<LzRun> R(nb);
+    std::vector<char> live(nb, 0), ran(nb, 0);
+    EigWork& W0 = eig[blocks[0]];
+    dev::LzBatch B{};
+    B.n = W0.n; B.nt = W0.nt; B.npad = W0.npad; B.pld = W0.pld; B.napart = W0.napart; B.nb = nb;
+    for (int q = 0; q < nb; ++q) {
+        EigWork& W = eig[blocks[q]];
+        W.use_fop = false;
+        live[q] = ran[q] = lz_init(W, R[q], nevs[q], false) ? 1 : 0;
+        if (R[q].krylovdim > 63) throw std::invalid_argument("lanczos_batch: krylovdim > 63");
+        B.tol = R[q].step_tol;
+    }
+    auto fill = [&](int q) -> dev::LzBlk& {
+        EigWork& W = eig[blocks[q]];
+        dev::LzBlk& b = B.b[q];
+        b.xp = xbase + P.blocks[blocks[q]].off;
+        b.Ppart = W.Ppart.p; b.wbuf = W.w.p; b.V = W.V.p; b.hpart1 = W.hpart1.p; b.hpart2 = W.hpart2.p;
+        b.hsum = W.hsum1.p; b.alphas = W.alphas_p; b.betas = W.betas_p; b.ctl = W.ctl_p; b.Apart = W.Apart.p;
+        b.hred = W.hred.p; b.arrow = W.arrow_p; b.resid = W.resid.p;
+        return b;
+    };
+    const int ntile = 8 * ceil_div(W0.nt * (W0.nt + 1) / 2, 8);
+    for (int q = 0; q < nb; ++q) fill(q).mode = live[q] ? 1 : 0;
+    hipLaunchKernelGGL(dev::k_lzb_begin, dim3(ceil_div(W0.npad, dev::TPB), 1, nb), dim3(dev::TPB), 0, stream, B);
+    const double mv_bytes = 8.0 * (double)W0.N + 16.0 * (double)W0.n;
+    long long nlaunch = 0, prof_blocks = 0;
+    while (true) {
+        int tmax = 0, nlive = 0;
+        for (int q = 0; q < nb; ++q)
+            if (live[q]) { tmax = std::max(tmax, R[q].krylovdim - R[q].kfirst); ++nlive; }
+        if (nlive == 0) break;
+        for (int t = 0; t <= tmax; ++t) {
+            bool any_orth = false;
+            for (int q = 0; q < nb; ++q) {
+                dev::LzBlk& b = fill(q);               // (V / arrow pointers change at a restart)
+                b.mode = 0;
+                if (!live[q]) continue;
+                const int k = R[q].kfirst + t, kd = R[q].krylovdim;
+                b.k = k; b.keep = R[q].kfirst;
+                b.mode = (t == 0) ? 1 : (k < kd) ? 2 : (k == kd) ? 3 : 0;
+                if (k < kd) {
+                    any_orth = true;
+                    eig[blocks[q]].lst.symv_launches++; eig[blocks[q]].lst.symv_bytes += mv_bytes;
+                }
+            }
+            // every profile_symv_every-th batched mat-vec launch carries its own start/stop events
+            const bool prof = opt.profile_symv_every > 0 && t > 0 && t < tmax && (nlaunch++ % opt.profile_symv_every) == 0;
+            if (prof) {
+                if (W0.ev.used == W0.ev.e0.size()) {
+                    hipEvent_t a, b2;
+                    PX_HIP(hipEventCreate(&a)); PX_HIP(hipEventCreate(&b2));
+                    W0.ev.e0.push_back(a); W0.ev.e1.push_back(b2);
+                }
+                const size_t slot = W0.ev.used++;
+                hipExtLaunchKernelGGL(dev::k_lzb_mv, dim3(W0.nt + ntile, 1, nb), dim3(dev::TPB), 0, stream,
+                                      W0.ev.e0[slot], W0.ev.e1[slot], 0, B);
+                int act = 0;
+                for (int q = 0; q < nb; ++q) act += (B.b[q].mode == 2) ? 1 : 0;
+                prof_blocks += act;
+            } else
+            hipLaunchKernelGGL(dev::k_lzb_mv, dim3(W0.nt + ntile, 1, nb), dim3(dev::TPB), 0, stream, B);
+            if (!any_orth) continue;
+            for (int q = 0; q < nb; ++q)
+                if (B.b[q].mode == 3 || (live[q] && B.b[q].k >= R[q].krylovdim)) B.b[q].mode = 0;
+            hipLaunchKernelGGL(dev::k_lzb_orth, dim3(W0.nt, 1, nb), dim3(dev::TPB), 0, stream, B);
+            st.batched_block_steps += nlive;
         }
-        for (int k = kfirst; k < Kend; ++k) {
-            T[(size_t)k * ld + k] = al[k];
-            if (k + 1 < Kend) { T[(size_t)k * ld + k + 1] = be[k]; T[(size_t)(k + 1) * ld + k] = be[k]; }
+        for (int q = 0; q < nb; ++q) {
+            if (!live[q]) continue;
+            EigWork& W = eig[blocks[q]];
+            PX_HIP(hipMemcpyAsync(W.rec_host, W.rec.p, EigWork::REC_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, stream));
         }
-        K = Kend;
-        betaK = be[K - 1];
-        if (!(betaK == betaK)) {                         // NaN guard: treat as not converged
-            W.converged = false; W.numiter = numiter; return;
-        }
-        if (betaK <= tol && K < howmany && !arpack) howmany = K;
-        if (K == 1) {
-            D[0] = T[0]; U.assign(1, 1.0); f[0] = betaK;
-        } else {
-            Tw.assign((size_t)K * K, 0.0);
-            for (int c = 0; c < K; ++c)
-                for (int r = 0; r < K; ++r) Tw[(size_t)c * K + r] = T[(size_t)c * ld + r];
-            std::vector<double> Dasc(K);
-            const double te0 = now_s();
-            if (m_arrow > 0 && K > m_arrow)
-                symeig_tridiag_from(K, m_arrow, Qa.data(), da.data(), ea.data(), al.data(), be.data(), Tw.data(), Dasc.data());
-            else
-            symeig_dense(K, Tw.data(), Dasc.data(), kfirst == 0);
-            W.lst.host_eig_time += now_s() - te0; W.lst.host_eigs++;
-            U.assign((size_t)K * K, 0.0);
-            for (int c = 0; c < K; ++c) {                // :LR -> descending
-                D[c] = Dasc[K - 1 - c];
-                for (int r = 0; r < K; ++r) U[(size_t)c * K + r] = Tw[(size_t)(K - 1 - c) * K + r];
-                f[c] = betaK * U[(size_t)c * K + (K - 1)];
+        for (int q = 0; q < nb; ++q) if (live[q]) lz_prepare_arrow(R[q]);
+        PX_HIP(hipStreamSynchronize(stream));
+        for (size_t sl = 0; sl < W0.ev.used; ++sl) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, W0.ev.e0[sl], W0.ev.e1[sl]) == hipSuccess) {
+                W0.lst.symv_profiled_ms += ms; W0.lst.symv_profiled++;
             }
         }
-        converged = 0;
-        if (!arpack) {
-            while (converged < K && std::fabs(f[converged]) <= tol) ++converged;
-        } else {
-            const double eps23 = std::pow(2.220446049250313e-16 / 2.0, 2.0 / 3.0);
-            int want = std::min(nev, K);
-            for (int i = 0; i < want; ++i)
-                if (std::fabs(f[i]) <= tol * std::max(eps23, std::fabs(D[i]))) ++converged;
-        }
-        if (positive_part) {
-            int j = 0;
-            while (j < K && D[j] > 0.0) ++j;
-            if (j > nev) { pos_fail = true; break; }      // more positive pairs than the workspace was sized for
-            const double scale = std::max(std::fabs(D[0]), std::fabs(D[K - 1]));
-            // the deciding pair: the first STRICTLY negative Ritz value (an exactly-zero pair with zero
-            // residual is what a decoupled, unused coordinate of the block looks like: it is found at
-            // once and says nothing about the pairs around it)
-            int jn = j;
-            while (jn < K && D[jn] >= -1e-12 * scale) ++jn;
-            const double posres = opt.full_eig_lanczos_posres > 0.0 ? opt.full_eig_lanczos_posres : 1e-7;
-            if (converged >= j && (jn == K || std::fabs(f[jn]) <= std::max(tol, posres * scale))) { pos_count = j; break; }
-            if (K < krylovdim || numiter == maxiter) { pos_fail = true; break; }
-        } else {
-        if (converged >= howmany) break;
-        if (K < krylovdim) break;                        // invariant subspace without convergence (arpack rule)
-        }
-        if (numiter == maxiter) break;
-        const int keep = arpack ? std::min(krylovdim - 1, nev + std::max(1, (krylovdim - nev) / 2))
-                                : (3 * krylovdim + 2 * converged) / 5;
-        // arrow part of the restarted T for k_lz_orth: f (couplings of v_K with the kept Ritz
-        // vectors) and D (their Ritz values)
-        for (int j = 0; j < keep; ++j) { W.arrow_host.p[j] = f[j]; W.arrow_host.p[dev::MAXK + j] = D[j]; }
-        rotate(W, K, U, K, keep, W.Z.p, K, keep, W.arrow_host.p, 2 * dev::MAXK);   // Z[:, :keep] = V U[:, :keep]; Z[:, keep] = V[:, K]
-        std::swap(W.V.p, W.Z.p);
-        std::fill(T.begin(), T.end(), 0.0);
-        for (int j = 0; j < keep; ++j) {
-            T[(size_t)j * ld + j] = D[j];
-            T[(size_t)j * ld + keep] = f[j];
-            T[(size_t)keep * ld + j] = f[j];
-        }
-        kfirst = keep;
-        presymv = speculate;
-        ++numiter;
-        W.lst.lanczos_restarts++;
+        W0.ev.used = 0;
+        for (int q = 0; q < nb; ++q)
+            if (live[q]) live[q] = lz_after_cycle(eig[blocks[q]], R[q], false) ? 1 : 0;
     }
-    W.numiter = numiter;
-    if (positive_part) {
-        if (pos_fail || pos_count < 0) { W.converged = false; return; }
-        W.count = pos_count; W.converged_eigs = pos_count; W.converged = true;
-        W.vals.assign(D.begin(), D.begin() + pos_count);
-        if (pos_count > 0) rotate(W, K, U, K, pos_count, W.Z.p, -1, 0, nullptr, 0);
-        return;
-    }
-    if (arpack) {
-        // _saupd!/_seupd! (eigsolver.jl:668-746): converged only when all nev pairs are
-        W.converged_eigs = converged;
-        if (converged < nev) { W.converged = false; return; }
-        W.count = nev;
-        W.vals.assign(D.begin(), D.begin() + nev);
-        std::reverse(W.vals.begin(), W.vals.end());      // arc.d is ascending
-        std::vector<double> Ur((size_t)K * nev);
-        for (int c = 0; c < nev; ++c)
-            for (int r = 0; r < K; ++r) Ur[(size_t)c * K + r] = U[(size_t)(nev - 1 - c) * K + r];
-        rotate(W, K, Ur, K, nev, W.Z.p, -1, 0, nullptr, 0);
-        W.converged = true;
-        return;
-    }
-    if (converged > howmany) howmany = converged;
-    W.count = howmany;
-    W.vals.assign(D.begin(), D.begin() + howmany);
-    W.converged_eigs = converged;
-    W.converged = (converged != 0);                      // eigsolver.jl:816-818
-    rotate(W, K, U, K, howmany, W.Z.p, -1, 0, nullptr, 0);            // Ritz vectors B*v
+    for (int q = 0; q < nb; ++q) if (ran[q]) lz_finish_run(eig[blocks[q]], R[q]);
+    st.batched_profiled_blocks += prof_blocks;       // blocks served by the event-bracketed launches (bytes = this x (8N + 16n))
 }
 
 // eigen!(Symmetric(smat(xp))) through rocSOLVER dsyevd (ascending), the dense

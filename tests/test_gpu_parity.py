@@ -640,6 +640,46 @@ def test_block_diagonal_model_two_blocks(support_path):
     assert np.allclose(sol.primal, ref.primal, atol=1e-7)
 
 
+@pytest.mark.parametrize("kind", ["mimo_dense_passes", "maxcut_support_packed"])
+def test_batched_multi_block_lanczos_equals_the_per_block_path_and_the_oracle(kind):
+    """Row "batched symmetric mat-vec across blocks" (north_star; reference loop prox_operators.jl:40-61): PSD
+    blocks of EQUAL side advance their Lanczos recurrences in ONE launch per step (grid.z = block,
+    options.block_batch) instead of one stream + host thread per block.  Per block the kernels' bodies are the
+    same, so the whole trace must be BIT-identical to the per-block path (block_batch = 0), the Lanczos mat-vec
+    totals per iteration must be the oracle's (blocks restart at different basis sizes and drop out of the
+    launches at different cycles), and the trace must follow the oracle's as the single-block tests do."""
+    if kind == "mimo_dense_passes":
+        # three MIMO instances of side 121 (> 100: Lanczos path; box rows on every entry: dense vector passes)
+        pr = P.block_diag_problems([P.mimo(120, seed=s_) for s_ in (1, 2, 3)])
+        kw, iters = dict(), 90
+    else:
+        # four Max-Cut blocks of side 150 on the support path with the packed-triangle operator
+        pr = P.block_diag_problems([P.maxcut(150, seed=s_) for s_ in (0, 1, 2, 3)])
+        kw, iters = dict(support_path=1, lanczos_operator=0), 120
+    o = Options()
+    o.max_iter = iters
+    omv = []
+    ref = oracle.solve(pr, o, trace=True, proj_callback=lambda it, xi, xo, p_, arc: omv.append(sum(int(a.matvecs) for a in arc)))
+    per_it = np.diff(np.array([0] + omv))
+    sb = Optimizer(max_iter=iters, block_batch=1, **kw).optimize(pr, trace_capacity=iters)
+    ss = Optimizer(max_iter=iters, block_batch=0, **kw).optimize(pr, trace_capacity=iters)
+    assert sb.stats["batched_block_steps"] > 0 and ss.stats["batched_block_steps"] == 0
+    cols = [c for c in range(14) if c != 12]                               # (column 12 is the wall clock)
+    assert np.array_equal(sb.trace[:, cols], ss.trace[:, cols]), "batched launch changed the arithmetic of a block"
+    assert sb.stats["lanczos_matvecs"] == ss.stats["lanczos_matvecs"]
+    assert sb.stats["lanczos_restarts"] == ss.stats["lanczos_restarts"]
+    assert sb.status == ref.status and sb.iter == ref.iter
+    G, T = _trace_cols(ref.trace), sb.trace[:, [1, 2, 3, 4, 7, 11]]
+    assert np.array_equal(T[:, 5], G[:, 5])                                # linesearch trials
+    mv = sb.trace[:, 13]
+    same = mv == per_it[:len(mv)]
+    tight = int(np.argmin(same)) if not same.all() else len(mv)            # degenerate truncation may part the runs later
+    assert tight >= 10, (mv[:12], per_it[:12])
+    assert np.allclose(T[:tight], G[:tight], rtol=1e-8, atol=1e-10 * np.abs(G).max())
+    print(kind, "iterations with the oracle's mat-vec totals:", tight, "of", len(mv),
+          "| batched block-steps", sb.stats["batched_block_steps"], "| restarts", sb.stats["lanczos_restarts"])
+
+
 def test_support_and_dense_paths_agree_on_maxcut():
     """Max-Cut n=300, 150 iterations: the support-aware passes and the dense passes are the
     same arithmetic on the support and exact zeros elsewhere."""
