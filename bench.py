@@ -595,7 +595,7 @@ def bench_mimo(args, torch, dist, rank, world, dev_id, backend):
     PSD side 513, 263 682 box rows each) as ONE block-diagonal model; its PSD blocks are sharded
     over the ranks (one block per GPU at N = blocks), scalars all-reduced twice per iteration
     (RCCL).  A step is one PDHG iteration of the coupled model; strong scaling in N."""
-    from proxsdp_jl_amd import problems, replicas, sharded
+    from proxsdp_jl_amd import binding, problems, replicas, sharded
     from proxsdp_jl_amd.optimizer import Optimizer
     K, W = args.steps, args.warmup
     model = problems.block_diag_problems([problems.mimo(args.mimo_n, seed=s) for s in range(args.blocks)],
@@ -614,8 +614,13 @@ def bench_mimo(args, torch, dist, rank, world, dev_id, backend):
         sol = opt.optimize(model, trace_capacity=W + K)
     else:
         cdev = torch.device("cuda", dev_id) if backend == "nccl" else None
+        # native RCCL: the library reduces the scalar record and the coupling rows itself on its own stream
+        # (proxsdp_problem.nccl_comm); PROXSDP_BENCH_NATIVE_RCCL=0 keeps the torch.distributed callbacks
+        comm = None
+        if os.environ.get("PROXSDP_BENCH_NATIVE_RCCL", "1") != "0" and binding.rccl_available():
+            comm = sharded.make_native_comm(dist, rank, world, device_id=dev_id)
         opt, sol, _ = sharded.solve_sharded(model, dist, rank, world, device_id=dev_id,
-                                            collective_device=cdev, max_iter=W + K)
+                                            collective_device=cdev, native_comm=comm, max_iter=W + K)
     sync()
     wall = time.time() - t0
     tr = sol.trace

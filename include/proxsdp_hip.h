@@ -363,6 +363,16 @@ int  proxsdp_hip_solve(const proxsdp_problem* prob, const proxsdp_options* opt,
 const char* proxsdp_hip_last_error(void);
 int  proxsdp_hip_device_count(void);          /* <0: PROXSDP_E_HIP */
 
+/* ------------------------------------------- RCCL communicator helpers (block-sharded solves)
+ * The library loads librccl at run time (dlopen; it does not link it).  One rank calls _unique_id and
+ * ships the 128 bytes to the others by any means (MPI, torch.distributed, a file); every rank then calls
+ * _comm_init on the GPU it owns and passes the handle as proxsdp_problem.nccl_comm.  A caller that already
+ * has an ncclComm_t (created through the same librccl) passes it directly instead. */
+int  proxsdp_hip_rccl_available(void);                      /* 1 = librccl loaded and usable */
+int  proxsdp_hip_rccl_unique_id(void* id128);               /* NCCL_UNIQUE_ID_BYTES = 128 */
+int  proxsdp_hip_rccl_comm_init(int32_t nranks, const void* id128, int32_t rank, int32_t device_id, void** comm);
+int  proxsdp_hip_rccl_comm_destroy(void* comm);
+
 /* ------------------------------------------- kernel-level test entry points
  * (not part of the drop-in; each is pinned against the oracle in tests/).
  * All pointers are host pointers; data is copied to the device, the kernel(s)

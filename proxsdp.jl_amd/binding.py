@@ -199,6 +199,9 @@ def lib():
     L.proxsdp_host_symeig.argtypes = [i32, pf64, pf64]
     L.proxsdp_host_start_vector.argtypes = [i64, i64, i32, pf64]
     L.proxsdp_host_preprocess.argtypes = [C.POINTER(Problem), pi64, pi64, pf64, pf64]
+    L.proxsdp_hip_rccl_unique_id.argtypes = [C.c_void_p]
+    L.proxsdp_hip_rccl_comm_init.argtypes = [i32, C.c_void_p, i32, i32, C.POINTER(C.c_void_p)]
+    L.proxsdp_hip_rccl_comm_destroy.argtypes = [C.c_void_p]
     if L.proxsdp_hip_abi_version() != 6:
         raise ProxSDPHipError(-1, "ABI version mismatch")
     _lib = L
@@ -326,7 +329,31 @@ class SolveResult:
         return [dict(zip(TRACE_NAMES, row)) for row in self.trace]
 
 
-def solve(prob, options=None, eig_resid=None, trace_capacity=0, reduce=None, coupling=None, index_base=0):
+def rccl_available():
+    return lib().proxsdp_hip_rccl_available() == 1
+
+
+def rccl_unique_id():
+    """128 bytes from ncclGetUniqueId (one rank calls this and ships the bytes to the others)."""
+    buf = C.create_string_buffer(128)
+    _check(lib().proxsdp_hip_rccl_unique_id(buf))
+    return bytes(buf.raw)
+
+
+def rccl_comm_init(nranks, uid, rank, device_id=0):
+    """ncclCommInitRank through the library's librccl; returns the opaque communicator handle (int)."""
+    comm = C.c_void_p()
+    buf = C.create_string_buffer(bytes(uid), 128)
+    _check(lib().proxsdp_hip_rccl_comm_init(int(nranks), buf, int(rank), int(device_id), C.byref(comm)))
+    return comm.value
+
+
+def rccl_comm_destroy(comm):
+    if comm:
+        _check(lib().proxsdp_hip_rccl_comm_destroy(C.c_void_p(comm)))
+
+
+def solve(prob, options=None, eig_resid=None, trace_capacity=0, reduce=None, coupling=None, index_base=0, nccl_comm=None):
     """proxsdp_hip_solve: replaces chambolle_pock(aff, con, options) (MOI_wrapper.jl:310).
     Returns the minimisation objective; sign/constant fix-up is the caller's
     (MOI_wrapper.jl:336-337), see optimizer.Optimizer.
@@ -334,7 +361,9 @@ def solve(prob, options=None, eig_resid=None, trace_capacity=0, reduce=None, cou
     the two arrays in place over the shards of a block-sharded solve (see sharded.py).
     coupling: optional dict(rows=int64 array of this shard's row numbers, owned=int32 0/1 array,
     reduce_vec=callable(ptr: int, length: int, on_device: bool) -> None summing the buffer in place over
-    the shards, on_device=bool) -- the rows shared with other shards (proxsdp_problem.coupling_rows)."""
+    the shards, on_device=bool) -- the rows shared with other shards (proxsdp_problem.coupling_rows).
+    nccl_comm: optional RCCL communicator handle (rccl_comm_init): the library then reduces the scalar record and
+    the coupling rows itself on its own stream (proxsdp_problem.nccl_comm); `reduce` / reduce_vec are not used."""
     L = lib()
     o = options if options is not None else default_options()
     if trace_capacity:
@@ -355,26 +384,30 @@ def solve(prob, options=None, eig_resid=None, trace_capacity=0, reduce=None, cou
         M.keep.append(cb)
         M.P.reduce_fn = C.cast(cb, C.c_void_p)
         M.P.reduce_ctx = None
+    if nccl_comm:
+        # native path: the library issues the collectives itself (RCCL, its own stream); no callbacks
+        M.P.nccl_comm = C.c_void_p(int(nccl_comm))
     if coupling is not None and len(coupling["rows"]) > 0:
         rows = _i(coupling["rows"])                 # 0-based row numbers of [A;G], whatever index_base
         owned = np.ascontiguousarray(coupling["owned"], dtype=np.int32)
-        rv = coupling["reduce_vec"]
-
-        def _cbv(ctx, ptr, length, on_device):
-            try:
-                rv(int(ptr), int(length), bool(on_device))
-                return 0
-            except Exception:
-                import traceback
-                traceback.print_exc()
-                return 1
-        cbv = REDUCE_VEC_FN(_cbv)
-        M.keep += [rows, owned, cbv]
+        M.keep += [rows, owned]
         M.P.n_coupling = len(rows)
         M.P.coupling_rows = _p(rows, pi64)
         M.P.coupling_owned = owned.ctypes.data_as(C.POINTER(i32))
-        M.P.reduce_vec_fn = C.cast(cbv, C.c_void_p)
-        M.P.reduce_vec_on_device = 1 if coupling.get("on_device") else 0
+        rv = coupling.get("reduce_vec")
+        if rv is not None and not nccl_comm:
+            def _cbv(ctx, ptr, length, on_device):
+                try:
+                    rv(int(ptr), int(length), bool(on_device))
+                    return 0
+                except Exception:
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            cbv = REDUCE_VEC_FN(_cbv)
+            M.keep.append(cbv)
+            M.P.reduce_vec_fn = C.cast(cbv, C.c_void_p)
+            M.P.reduce_vec_on_device = 1 if coupling.get("on_device") else 0
     n, p, m = M.P.n, M.P.p, M.P.m
     arrays = [np.zeros(max(k, 1)) for k in (n, n, p, m, p, m)]
     trace = np.zeros((max(o.trace_capacity, 1), TRACE_COLS))

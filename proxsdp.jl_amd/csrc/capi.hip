@@ -95,6 +95,45 @@ int proxsdp_hip_get_option(const proxsdp_options* opt, const char* name, double*
     return rc;
 }
 
+// ---- RCCL communicator helpers (block-sharded solve, native collectives: proxsdp_problem.nccl_comm)
+int proxsdp_hip_rccl_available(void) {
+    return guarded([&]() -> int { return proxsdp::Rccl::get().ok() ? 1 : 0; });
+}
+int proxsdp_hip_rccl_unique_id(void* id128) {
+    return guarded([&]() -> int {
+        if (!id128) throw std::invalid_argument("NULL id buffer");
+        proxsdp::Rccl& rc = proxsdp::Rccl::get();
+        rc.require();
+        ncclUniqueId id;
+        rc.check(rc.GetUniqueId(&id), "ncclGetUniqueId");
+        std::memcpy(id128, id.internal, NCCL_UNIQUE_ID_BYTES);
+        return 0;
+    });
+}
+int proxsdp_hip_rccl_comm_init(int32_t nranks, const void* id128, int32_t rank, int32_t device_id, void** comm) {
+    return guarded([&]() -> int {
+        if (!id128 || !comm || nranks < 1 || rank < 0 || rank >= nranks) throw std::invalid_argument("invalid argument");
+        proxsdp::Rccl& rc = proxsdp::Rccl::get();
+        rc.require();
+        if (hipSetDevice(device_id) != hipSuccess) throw proxsdp::HipError("hipSetDevice failed");
+        ncclUniqueId id;
+        std::memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+        ncclComm_t c = nullptr;
+        rc.check(rc.CommInitRank(&c, nranks, id, rank), "ncclCommInitRank");
+        *comm = c;
+        return 0;
+    });
+}
+int proxsdp_hip_rccl_comm_destroy(void* comm) {
+    return guarded([&]() -> int {
+        if (!comm) return 0;
+        proxsdp::Rccl& rc = proxsdp::Rccl::get();
+        rc.require();
+        rc.check(rc.CommDestroy(static_cast<ncclComm_t>(comm)), "ncclCommDestroy");
+        return 0;
+    });
+}
+
 const char* proxsdp_hip_last_error(void) { return g_last_error.c_str(); }
 
 int proxsdp_hip_device_count(void) {

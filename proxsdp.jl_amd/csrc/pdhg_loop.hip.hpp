@@ -52,7 +52,12 @@ inline void Solver::reduce_coupling(double* Mx_dev) {
     const int nc = (int)coup_rows.size();
     hipLaunchKernelGGL(dev::k_gather_rows, dim3(ceil_div(nc, dev::TPB)), dim3(dev::TPB), 0, stream,
                        (const double*)Mx_dev, (const int*)coup_rows_d.p, nc, coup_buf_d.p);
-    if (reduce_vec_on_device) {
+    if (nccl) {
+        // native: in-place sum over the shards on THIS stream -- no host synchronisation, no callback
+        Rccl& rc = Rccl::get();
+        rc.check(rc.AllReduce(coup_buf_d.p, coup_buf_d.p, (size_t)nc, ncclFloat64, ncclSum, nccl, stream), "ncclAllReduce");
+        st.rccl_reductions++;
+    } else if (reduce_vec_on_device) {
         PX_HIP(hipStreamSynchronize(stream));               // the collective runs on the caller's stream
         if (reduce_vec_fn(reduce_ctx, coup_buf_d.p, nc, 1) != 0) throw std::runtime_error("reduce_vec_fn failed");
     } else {

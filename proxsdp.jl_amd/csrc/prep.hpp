@@ -123,8 +123,8 @@ inline Prep prepare(const proxsdp_problem& P, const proxsdp_options* opt = nullp
     R.n = P.n; R.p = P.p; R.m = P.m; R.Q = P.p + P.m;
     const bool dense = P.M_dense != nullptr;
     if (!dense) check_csc(P.A, P.p, P.n, base, "A");
-    else if (P.reduce_fn != nullptr)
-        throw std::invalid_argument("A_dense cannot be combined with a block-sharded solve (reduce_fn)");
+    else if (P.reduce_fn != nullptr || P.nccl_comm != nullptr)
+        throw std::invalid_argument("A_dense cannot be combined with a block-sharded solve (reduce_fn / nccl_comm)");
     check_csc(P.G, P.m, P.n, base, "G");
     if ((P.p > 0 && !P.b) || (P.m > 0 && !P.h) || (P.n > 0 && !P.c))
         throw std::invalid_argument("b, h or c is NULL");
@@ -232,7 +232,7 @@ inline Prep prepare(const proxsdp_problem& P, const proxsdp_options* opt = nullp
     }
     if (opt != nullptr && opt->equilibration_force) equil = true;
     if (equil) {
-        if (dense || P.reduce_fn != nullptr) throw std::domain_error("equilibration with a dense A or a block-sharded solve is not implemented");
+        if (dense || P.reduce_fn != nullptr || P.nccl_comm != nullptr) throw std::domain_error("equilibration with a dense A or a block-sharded solve is not implemented");
         if (R.Q == 0 || R.n == 0) throw std::invalid_argument("equilibration needs a non-empty M");
         equilibrate_host(R, *opt, R.Ediag, R.Ddiag);
         R.equilibrated = true;

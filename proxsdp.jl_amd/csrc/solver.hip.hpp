@@ -32,6 +32,7 @@
 #include "kernels.hip.hpp"
 #include "lanczos_cycle.hip.hpp"
 #include "sign_project.hip.hpp"
+#include "rccl_dl.hpp"
 #include "prep.hpp"
 
 namespace proxsdp {
@@ -218,11 +219,22 @@ public:
         user_resid = prob.eig_resid;
         reduce_fn = prob.reduce_fn;
         reduce_ctx = prob.reduce_ctx;
+        if (prob.nccl_comm != nullptr) {
+            // native path: the library issues the collectives itself on its own stream (rccl_dl.hpp)
+            Rccl& rc = Rccl::get();
+            rc.require();
+            nccl = static_cast<ncclComm_t>(prob.nccl_comm);
+            rc.check(rc.CommCount(nccl, &nccl_world), "ncclCommCount");
+            rc.check(rc.CommUserRank(nccl, &nccl_rank), "ncclCommUserRank");
+            reduce_fn = nullptr;                     // (ignored when a communicator is given)
+        }
         if (prob.n_coupling > 0) {
-            if (!prob.reduce_fn || !prob.reduce_vec_fn || !prob.coupling_rows || !prob.coupling_owned)
-                throw std::invalid_argument("coupling rows need reduce_fn, reduce_vec_fn, coupling_rows and coupling_owned");
-            reduce_vec_fn = prob.reduce_vec_fn;
-            reduce_vec_on_device = prob.reduce_vec_on_device != 0;
+            if ((!prob.reduce_fn || !prob.reduce_vec_fn) && nccl == nullptr)
+                throw std::invalid_argument("coupling rows need nccl_comm, or reduce_fn and reduce_vec_fn");
+            if (!prob.coupling_rows || !prob.coupling_owned)
+                throw std::invalid_argument("coupling rows need coupling_rows and coupling_owned");
+            reduce_vec_fn = nccl ? nullptr : prob.reduce_vec_fn;
+            reduce_vec_on_device = nccl ? true : prob.reduce_vec_on_device != 0;
             for (int64_t k = 0; k < prob.n_coupling; ++k) {
                 const int64_t r = prob.coupling_rows[k];
                 if (r < 0 || r >= prob.p + prob.m) throw std::invalid_argument("coupling row out of range");
@@ -297,7 +309,15 @@ public:
     // block-sharded solve: scalar all-reduce across shards (include/proxsdp_hip.h)
     int (*reduce_fn)(void*, double*, int32_t, double*, int32_t) = nullptr;
     void* reduce_ctx = nullptr;
-    bool sharded() const { return reduce_fn != nullptr; }
+    bool sharded() const { return reduce_fn != nullptr || nccl != nullptr; }
+    // native RCCL path (proxsdp_problem.nccl_comm): one all-gather of the packed scalar record per reduce, combined
+    // on the host in rank order (the same bits on every rank); all-reduce of the coupling buffer on the stream
+    ncclComm_t nccl = nullptr;
+    int nccl_world = 1, nccl_rank = 0;
+    DevBuf<double> nccl_send, nccl_recv, nccl_tmp;
+    PinnedBuf nccl_host;
+    size_t nccl_cap = 0;
+    void reduce_native(std::vector<double>& sums, std::vector<double>& maxs);
     // coupling rows of a block-sharded solve (include/proxsdp_hip.h): partial M x summed over the shards
     int (*reduce_vec_fn)(void*, double*, int64_t, int32_t) = nullptr;
     bool reduce_vec_on_device = false;
@@ -309,9 +329,20 @@ public:
     void reduce_coupling(double* Mx_dev);          // Mx[coupling rows] <- sum over shards
     void reduce_vec_host(std::vector<double>& v) {
         if (v.empty()) return;
+        if (nccl) {                                  // (exit path: slacks of the coupling rows)
+            Rccl& rc = Rccl::get();
+            if (nccl_tmp.n < v.size()) nccl_tmp.alloc(v.size());
+            nccl_tmp.upload(v.data(), v.size(), stream);
+            rc.check(rc.AllReduce(nccl_tmp.p, nccl_tmp.p, v.size(), ncclFloat64, ncclSum, nccl, stream), "ncclAllReduce");
+            nccl_tmp.download(v.data(), v.size(), stream);
+            PX_HIP(hipStreamSynchronize(stream));
+            st.rccl_reductions++;
+            return;
+        }
         if (reduce_vec_fn(reduce_ctx, v.data(), (int64_t)v.size(), 0) != 0) throw std::runtime_error("reduce_vec_fn failed");
     }
     void reduce(std::vector<double>& sums, std::vector<double>& maxs) {
+        if (nccl) { reduce_native(sums, maxs); return; }
         if (!reduce_fn) return;
         if (reduce_fn(reduce_ctx, sums.data(), (int32_t)sums.size(), maxs.data(), (int32_t)maxs.size()) != 0)
             throw std::runtime_error("reduce_fn failed");
@@ -1431,6 +1462,39 @@ inline void Solver::merge_block_stats() {
         lz_matvec_iter += W.mv_iter; recon_r_iter += W.recon_r;
         W.mv_iter = 0; W.recon_r = 0;
     }
+}
+
+// scalar reduce of a block-sharded solve over RCCL: every rank's packed record [sums | maxs] is all-gathered on the
+// solver's stream (one collective, <= 400 bytes per rank: latency-bound over xGMI) and combined on the host in
+// rank order, so every rank computes the same bits and takes the same step-size / rank / termination decisions
+inline void Solver::reduce_native(std::vector<double>& sums, std::vector<double>& maxs) {
+    const size_t ns = sums.size(), nm = maxs.size(), n = ns + nm;
+    if (n == 0) return;
+    Rccl& rc = Rccl::get();
+    const size_t W = (size_t)nccl_world;
+    if (nccl_cap < n) {
+        nccl_cap = std::max<size_t>(n, 64);
+        nccl_send.alloc(nccl_cap); nccl_recv.alloc(nccl_cap * W); nccl_host.alloc(nccl_cap * (W + 1));
+    }
+    double* h = nccl_host.p;
+    std::copy(sums.begin(), sums.end(), h);
+    std::copy(maxs.begin(), maxs.end(), h + ns);
+    PX_HIP(hipMemcpyAsync(nccl_send.p, h, n * sizeof(double), hipMemcpyHostToDevice, stream));
+    rc.check(rc.AllGather(nccl_send.p, nccl_recv.p, n, ncclFloat64, nccl, stream), "ncclAllGather");
+    double* all = h + nccl_cap;
+    PX_HIP(hipMemcpyAsync(all, nccl_recv.p, n * W * sizeof(double), hipMemcpyDeviceToHost, stream));
+    PX_HIP(hipStreamSynchronize(stream));
+    for (size_t q = 0; q < ns; ++q) {
+        double a = all[q];
+        for (size_t r = 1; r < W; ++r) a += all[r * n + q];
+        sums[q] = a;
+    }
+    for (size_t q = 0; q < nm; ++q) {
+        double a = all[ns + q];
+        for (size_t r = 1; r < W; ++r) a = std::max(a, all[r * n + ns + q]);
+        maxs[q] = a;
+    }
+    st.rccl_reductions++;
 }
 
 }  // namespace proxsdp

@@ -124,9 +124,25 @@ def make_reduce_vec(dist, device=None):
     return reduce_vec
 
 
-def solve_sharded(prob, dist, rank, world, device_id=0, owners=None, collective_device=None, **options):
+def make_native_comm(dist, rank, world, device_id=0):
+    """RCCL communicator for the library's NATIVE collectives (proxsdp_problem.nccl_comm): rank 0 draws the
+    unique id through the library's own librccl, the 128 bytes travel over the existing process group (any
+    backend), every rank joins on the GPU it owns.  torch.distributed's communicator is not reachable from
+    outside torch, and a communicator must belong to the librccl that issues the calls."""
+    from . import binding
+    box = [binding.rccl_unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    return binding.rccl_comm_init(world, box[0], rank, device_id)
+
+
+def solve_sharded(prob, dist, rank, world, device_id=0, owners=None, collective_device=None, native_comm=None,
+                  **options):
     """Every rank calls this with the SAME full model; returns (Optimizer, SolveResult of the
     local shard, index maps).  Objective / gap / status are global and identical on all ranks.
+    native_comm: handle from make_native_comm -> the library reduces scalars and coupling rows itself over RCCL
+    on its own stream (no Python callback per iteration); otherwise the torch.distributed callbacks below
+    (the path the gloo tests use).
     A failure on one rank (bad model, more ranks than blocks, an error inside the library) is
     all-reduced before anybody enters the solve loop's collectives, so all ranks raise together
     instead of leaving the others blocked in an all-reduce."""
@@ -148,9 +164,14 @@ def solve_sharded(prob, dist, rank, world, device_id=0, owners=None, collective_
         raise err if err is not None else RuntimeError("another rank failed to build its shard")
     opt = Optimizer(device_id=device_id, **options)
     coupling = None
+    tcap = int(options.get("max_iter", 0)) if options.get("max_iter", 0) else 0
+    if native_comm:
+        if maps["coupling"] is not None:
+            coupling = dict(maps["coupling"])
+        sol = opt.optimize(sub, coupling=coupling, nccl_comm=native_comm, trace_capacity=tcap)
+        return opt, sol, maps
     if maps["coupling"] is not None:
         coupling = dict(maps["coupling"], reduce_vec=make_reduce_vec(dist, collective_device),
                         on_device=collective_device is not None)
-    sol = opt.optimize(sub, reduce=make_reduce(dist, collective_device, world), coupling=coupling,
-                       trace_capacity=int(options.get("max_iter", 0)) if options.get("max_iter", 0) else 0)
+    sol = opt.optimize(sub, reduce=make_reduce(dist, collective_device, world), coupling=coupling, trace_capacity=tcap)
     return opt, sol, maps

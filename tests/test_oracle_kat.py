@@ -248,3 +248,27 @@ def test_mixed_cone_model_is_solved_by_the_oracle():
     assert np.abs(pr.A @ r.primal - pr.b).max() <= 1e-5 * (1 + np.linalg.norm(pr.b))
     assert (pr.G @ r.primal - pr.h).max() <= 1e-5 * (1 + np.linalg.norm(pr.h))
     assert r.stats["lanczos_matvecs"] > 0 and r.stats["full_eigs"] > 0
+
+
+def test_metric_instance_end_state_is_pinned(golden_dir):
+    """the end state of the metric instance (Max-Cut n=4000, which the oracle cannot run to
+    convergence) is pinned by committed results of tools/gpurun_pin_metric.py instead of by the library's own
+    tol-1e-4 stop rule: (c) two tol-1e-6 solves (reference defaults | rank-64 knob) agree to < 1e-6 and are
+    bracketed by weak duality (LAPACK certificate on the host); (b) the implicit full_eig! regime of the
+    default-options solve gives the same iteration count and objective whether every full_eig! is served by the
+    Lanczos engine or by the exact sign-function projection; the tol-1e-4 legs sit within the slack their own
+    stop rule allows (diag(X) = 1 to tol (1 + |b|): 6.5e-3), NOT within 1e-4 of the optimum -- stated, not hidden."""
+    import json
+    g = json.loads((golden_dir / "maxcut_n4000_tight.json").read_text())
+    assert g["gap"] <= 1e-6 and g["rel_diff_between_the_two_tight_solves"] <= 1e-6
+    assert g["certificate"]["lambda_min_X"] >= -1e-9 and g["certificate"]["max_diag_err"] <= 1e-6 * (1 + 4000 ** 0.5) * 1.01
+    assert g["dual_objective"] <= g["dual_bound"]
+    assert abs(g["objective"] - g["dual_bound"]) <= 1e-4 * (1 + abs(g["objective"]))     # bracket narrower than 1e-4
+    a, b = g["implicit_full_eig_regime_tol1e-4"]["by_lanczos"], g["implicit_full_eig_regime_tol1e-4"]["by_sign_function"]
+    assert a["status"] == b["status"] == "OPTIMAL"
+    assert abs(a["iterations"] - b["iterations"]) <= 0.01 * b["iterations"]
+    assert abs(a["objective"] - b["objective"]) <= 1e-6 * (1 + abs(b["objective"]))
+    assert a["full_eigs_lanczos"] > 0 and a["full_eigs_lanczos_mismatches"] == 0 and b["full_eigs_sign"] == b["full_eigs"]
+    for name, obj in g["tol1e-4_legs"].items():
+        rel = abs(obj - g["objective"]) / (1 + abs(g["objective"]))
+        assert rel <= 2e-3, (name, rel)           # the stop rule's own slack; see the docstring

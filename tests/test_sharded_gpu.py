@@ -36,14 +36,19 @@ def _worker(rank, world, port, q, coupled=False, backend="gloo"):
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     from proxsdp_jl_amd import replicas, sharded
     dev = None
+    native = backend == "native"          # the library's own RCCL collectives; torch.distributed (gloo) only ships the id
     if backend == "nccl":
         import torch
         torch.cuda.set_device(rank)
         dev = torch.device("cuda", rank)
-    dist = replicas.init(backend, rank, world, device=dev)
+    dist = replicas.init("gloo" if native else backend, rank, world, device=dev)
     model = _coupled_model() if coupled else _model()
-    opt, sol, maps = sharded.solve_sharded(model, dist, rank, world, device_id=rank if backend == "nccl" else 0,
-                                           collective_device=dev, max_iter=300)
+    comm = sharded.make_native_comm(dist, rank, world, device_id=rank) if native else None
+    opt, sol, maps = sharded.solve_sharded(model, dist, rank, world, device_id=rank if backend != "gloo" else 0,
+                                           collective_device=dev, native_comm=comm, max_iter=300)
+    if native:
+        assert sol.stats["rccl_reductions"] >= sol.iter, "native RCCL path not taken"
+        B.rccl_comm_destroy(comm)
     q.put((rank, sol.status, int(sol.iter), sol.objval, sol.dual_objval, sol.gap, int(sol.final_rank),
            maps["vars"], sol.primal, sol.trace[:, [1, 2, 7, 11]]))
     dist.destroy_process_group()
@@ -54,21 +59,22 @@ def _ngpu():
     return torch.cuda.device_count()
 
 
-@pytest.mark.parametrize("coupled,backend", [(False, "gloo"), (True, "gloo"), (True, "nccl")],
-                         ids=["block-diagonal-gloo", "coupling-rows-gloo", "coupling-rows-rccl"])
+@pytest.mark.parametrize("coupled,backend", [(False, "gloo"), (True, "gloo"), (True, "nccl"), (True, "native")],
+                         ids=["block-diagonal-gloo", "coupling-rows-gloo", "coupling-rows-rccl", "coupling-rows-rccl-native"])
 def test_two_shards_reproduce_the_single_process_solve(coupled, backend):
     """gloo: both ranks share the one GPU of the test box (coupling rows all-reduced through host
     memory); rccl: one GPU per rank, the coupling rows of M x all-reduced on the library's DEVICE
     buffer over xGMI -- runs only where >= 2 GPUs are visible."""
     assert B.device_count() > 0
-    if backend == "nccl" and _ngpu() < 2:
-        pytest.skip("needs 2 GPUs (RCCL over xGMI); the gloo variant covers the same path on one GPU")
+    if backend in ("nccl", "native") and _ngpu() < 2:
+        pytest.skip("needs 2 GPUs (RCCL over xGMI); the gloo variant covers the same path on one GPU, "
+                    "test_native_rccl_collectives_one_rank the library's own RCCL calls")
     pr = _coupled_model() if coupled else _model()
     opt = Optimizer(max_iter=300, support_path=1)
     ref = opt.optimize(pr, trace_capacity=300)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 300) + (17 if coupled else 0) + (29 if backend == "nccl" else 0)
+    port = 29600 + (os.getpid() % 300) + (17 if coupled else 0) + (29 if backend == "nccl" else 0) + (43 if backend == "native" else 0)
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, coupled, backend)) for r in range(2)]
     for p in procs:
         p.start()
@@ -117,3 +123,43 @@ def test_rccl_collectives_on_raw_device_pointers():
     assert p.exitcode == 0
     assert np.array_equal(t, np.arange(1000) * 0.5)
     assert sums.tolist() == [1.5, 2.5] and maxs.tolist() == [-3.0]
+
+
+def _native_worker(q):
+    """world = 1: the communicator is created and used by the library alone (no torch.distributed at all)"""
+    from proxsdp_jl_amd import sharded
+    assert B.rccl_available(), "librccl could not be loaded by the library"
+    comm = sharded.make_native_comm(None, 0, 1, device_id=0)
+    pr = _coupled_model()
+    sub, maps = sharded.split_block_diagonal(pr, [0, 0], 0)
+    assert maps["coupling"] is None                                   # one shard: nothing couples SHARDS ...
+    # ... so mark the two cross-block rows (the last equality and the last inequality) as coupling rows by hand:
+    # with one rank the all-reduce is the identity, but the gather -> ncclAllReduce -> scatter path runs
+    p_, m_ = sub.A.shape[0], sub.G.shape[0]
+    coupling = dict(rows=np.array([p_ - 1, p_ + m_ - 1], dtype=np.int64), owned=np.array([1, 1], dtype=np.int32))
+    sol = Optimizer(max_iter=300).optimize(sub, coupling=coupling, nccl_comm=comm, trace_capacity=300)
+    B.rccl_comm_destroy(comm)
+    q.put((sol.status, int(sol.iter), sol.objval, sol.dual_objval, sol.primal, sol.trace[:, [1, 2, 7, 11]],
+           int(sol.stats["rccl_reductions"])))
+
+
+def test_native_rccl_collectives_one_rank():
+    """proxsdp_problem.nccl_comm: the library loads librccl itself (dlopen), creates a 1-rank
+    communicator through its helper entry points and issues ncclAllGather (packed scalar record, once per
+    iteration) and ncclAllReduce (coupling rows of M x) on its OWN stream -- no Python callback.  A 1-rank
+    sharded solve must reproduce the plain solve of the same model bit for bit."""
+    assert B.device_count() > 0
+    pr = _coupled_model()
+    ref = Optimizer(max_iter=300, support_path=1).optimize(pr, trace_capacity=300)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_native_worker, args=(q,))
+    p.start()
+    status, it, obj, dobj, primal, tr, nred = q.get(timeout=600)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert status == ref.status and it == ref.iter
+    assert nred >= 2 * it, nred                                      # one scalar all-gather + one coupling all-reduce per iteration
+    assert obj == ref.objval and dobj == ref.dual_objval
+    assert np.array_equal(tr, ref.trace[:, [1, 2, 7, 11]])
+    assert np.array_equal(primal, ref.primal)

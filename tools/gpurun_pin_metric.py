@@ -41,21 +41,34 @@ def leg(cert=False, **kw):
          "full_eigs_lanczos_mismatches": int(s.stats["full_eigs_lanczos_mismatches"]),
          "lanczos_matvecs": int(s.stats["lanczos_matvecs"]), "equa_feasibility": float(s.primal_residual)}
     if cert:
+        # The model is  min c'x = -1/4 <L, X>  s.t. diag(X) = 1, X PSD  (user sense MAX: objective() = -c'x).
+        # RIGOROUS bracket of the optimum p* of the MAX problem, from the returned arrays only (LAPACK on the host):
+        #   lower: X' = D^-1/2 X+ D^-1/2 (X+ = PSD part of the returned X, D = its diagonal) is exactly feasible,
+        #          so p* >= 1/4 <L, X'>;
+        #   upper: weak duality.  The dual slack Z = C - A'(y) (returned as dual_cone) should be PSD; with
+        #          lambda_min(Z) = -e, y' = y - e 1 (in the min-form sign) is dual feasible and moves the dual
+        #          value by n e:  p* <= |b'y| + n e.
         X = P.unpack_psd(s.primal, n)
         Z = P.unpack_psd(s.dual_cone, n)
-        wx = np.linalg.eigvalsh(X)
+        wx, Vx = np.linalg.eigh(X)
         wz = np.linalg.eigvalsh(Z)
+        Xp = (Vx * np.maximum(wx, 0.0)) @ Vx.T
+        dg = np.sqrt(np.maximum(np.diag(Xp), 1e-300))
+        Xf = Xp / np.outer(dg, dg)
+        Cm = P.unpack_psd(pr.c, n)                       # smat of c: off-diagonals of the triangle vector carry 2 C_ij
+        Cm = (Cm + np.diag(np.diag(Cm))) / 2.0           # -> the matrix C with <C, X> = c'x
+        lower = -float(np.sum(Cm * Xf))
         cx = float(pr.c @ s.primal)
         by = float(pr.b @ s.dual_eq)
-        # Max-Cut dual: max b'y s.t. C - A'(y) = Z >= 0.  With lambda_min(Z) = -e the shifted y - e*1 is
-        # dual feasible, so b'y - n e <= optimum <= c'x' for any feasible x'; diag error scales x by at most
-        # 1/(1 - d): both corrections are reported.
         e = max(0.0, -float(wz[0]))
-        dmax = float(np.abs(np.diag(X) - 1).max())
-        d["certificate"] = {"lambda_min_X": float(wx[0]), "rank_X_1e-6": int((wx > 1e-6).sum()), "max_diag_err": dmax,
-                            "primal_value_cx": cx, "dual_value_by": by, "lambda_min_Z": float(wz[0]),
-                            "lambda_max_Z": float(wz[-1]), "dual_bound_shifted": by - n * e,
-                            "bracket_rel_width": abs(cx - (by - n * e)) / (1 + abs(cx))}
+        upper = abs(by) + n * e
+        d["certificate"] = {"lambda_min_X": float(wx[0]), "rank_X_1e-6": int((wx > 1e-6).sum()),
+                            "max_diag_err": float(np.abs(np.diag(X) - 1).max()),
+                            "returned_primal_value": -cx, "returned_dual_value": abs(by),
+                            "lambda_min_Z": float(wz[0]), "lambda_max_Z": float(wz[-1]),
+                            "check_cx_via_matrix": -float(np.sum(Cm * X)),
+                            "feasible_lower_bound": lower, "dual_upper_bound": upper,
+                            "bracket_rel_width": (upper - lower) / (1 + abs(lower))}
     print(json.dumps(d), flush=True)
     return d
 
