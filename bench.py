@@ -96,7 +96,8 @@ def main():
     ap.add_argument("--block-batch", dest="block_batch", type=int, default=None,
                     help="library-only: equal-side PSD blocks in one launch per Lanczos step (-1 auto, 0 off = stream per block)")
     ap.add_argument("--block-threads", dest="block_threads", type=int, default=None)
-    ap.add_argument("--device-restart", dest="device_restart", type=int, default=None)
+    ap.add_argument("--host-eig-merge", dest="host_eig_merge", type=int, default=None,
+                    help="library-only: K x K Rayleigh-quotient eigensolves by split + rank-one merge (-1 auto, 0 = implicit QL)")
     ap.add_argument("--block-eigensolver", dest="block_eigensolver", type=int, default=None)
     ap.add_argument("--rand-n", type=int, default=2000)
     ap.add_argument("--rand-m", type=int, default=4000)
@@ -270,7 +271,7 @@ def main():
                     "full_eigs_lanczos_checks": int(s["full_eigs_lanczos_checks"]),
                     "full_eigs_lanczos_mismatches": int(s["full_eigs_lanczos_mismatches"]),
                     "host_eigensolve_s": s["host_eig_time"], "device_eigensolves": int(s["device_eigs"]),
-                    "device_restarts": int(s["device_restarts"]),
+                    "host_eig_merges": int(s["host_eig_merges"]), "host_eig_overlapped_s": s["host_eig_overlap_time"],
                     "full_eig_solver_s": 1e-3 * s["full_eig_solver_ms"], "full_eig_recon_s": 1e-3 * s["full_eig_recon_ms"],
                     "options": kw}
         # THE metric's second half: the reference's own options (options.jl defaults: Krylov path up to target
@@ -369,7 +370,7 @@ def extra_opts(args):
     """library-only knobs passed through to every GPU leg (empty = the KrylovKit-faithful parity path)"""
     kw = {}
     for name in ("lanczos_warm_start", "lanczos_cycle_kernel", "full_eig_lanczos", "reconstruct_mfma", "full_eig_sign",
-                 "psd_sign_engine", "block_batch", "block_threads", "device_restart", "block_eigensolver"):
+                 "psd_sign_engine", "block_batch", "block_threads", "host_eig_merge", "block_eigensolver"):
         v = getattr(args, name, None)
         if v is not None:
             kw[name] = v

@@ -251,9 +251,12 @@ typedef struct proxsdp_options {
                                   * measured slower on the MI355X host; results are bit-identical) */
     int32_t block_threads;       /* host worker threads driving concurrent per-block projections (one HIP stream
                                   * per block): -1 auto = min(8, blocks), 0 = blocks in sequence */
-    int32_t device_restart;      /* thick restart of the Lanczos engine on the DEVICE (K x K Rayleigh-quotient
-                                  * eigensolve, basis rotation and convergence test chained on the stream; the host
-                                  * reads back once per projection): -1 auto, 0 = host eigensolve per restart, 1 = on */
+    int32_t host_eig_merge;      /* K x K Rayleigh-quotient eigensolve of the thick-restart Lanczos by SPLIT + RANK-ONE MERGE
+                                  * (csrc/host_eig_merge.hpp: the arrow part / first half is decomposed while the GPU still
+                                  * runs the cycle -- its coefficients are read back early on a side stream -- and only the
+                                  * small tail + one secular-equation merge stay on the critical path; only the Ritz vectors
+                                  * actually needed are formed): -1 auto = from krylovdim 64 on, 0 = implicit QL always,
+                                  * 1 = from krylovdim 24 on.  Same decomposition to rounding (orthogonality ~1e-14). */
     int32_t block_batch;         /* PSD blocks of equal side projected by ONE launch per Lanczos step (grid.z = block)
                                   * instead of one stream + host thread per block: -1 auto, 0 off, 1 on */
     int32_t block_eigensolver;   /* 0 (default) = KrylovKit's single-vector thick-restart Lanczos (the reference's
@@ -319,7 +322,10 @@ typedef struct proxsdp_stats {
     int64_t block_eig_steps;         /* block steps of the block eigensolver (block_eigensolver) */
     int64_t batched_profiled_blocks; /* block mat-vecs inside the event-bracketed batched launches (symv_profiled
                                       * counts launches; bytes of those launches = this x (8 N + 16 n)) */
-    int64_t reserved[5];
+    int64_t host_eig_merges;         /* K x K eigensolves done by split + rank-one merge (host_eig_merge); host_eig_time
+                                      * then counts only their critical-path part */
+    double  host_eig_overlap_time;   /* s: the part of those eigensolves done while the GPU was running the cycle */
+    int64_t reserved[3];
 } proxsdp_stats;
 
 /* Result (structs.jl:60-81).  Arrays are caller-allocated with the stated
@@ -466,6 +472,12 @@ int proxsdp_host_symeig_threads(int32_t k, double* a, double* d, int32_t threads
  * below m unused). */
 int proxsdp_host_symeig_arrow(int32_t K, int32_t m, const double* D, const double* f,
                               const double* al, const double* be, double* U, double* d);
+/* the same matrix decomposed by a split at k1 and ONE rank-one merge (one level of Cuppen's divide and conquer with
+ * Gu-Eisenstat eigenvectors, csrc/host_eig_merge.hpp): what the Lanczos driver uses from krylovdim 64 on, with the first
+ * part solved while the GPU still runs the cycle.  k1 = m + 1 when m > 0 (the arrow with its hub), 1 <= k1 < K when
+ * m = 0.  info[3] (optional): non-deflated poles, deflated poles, most secular iterations of a root. */
+int proxsdp_host_symeig_split(int32_t K, int32_t m, int32_t k1, const double* D, const double* f,
+                              const double* al, const double* be, double* U, double* d, int32_t* info);
 /* the library's Lanczos start vector (init 3/2/1 as options.jl:98-103) */
 int proxsdp_host_start_vector(int64_t n, int64_t seed, int32_t init, double* out);
 /* preprocess!/norm_scaling (scaling.jl): returns the variable order, the

@@ -111,7 +111,9 @@ struct Stats                     # proxsdp_stats
     device_restarts::Int64
     block_eig_steps::Int64
     batched_profiled_blocks::Int64
-    reserved::NTuple{5,Int64}
+    host_eig_merges::Int64
+    host_eig_overlap_time::Float64
+    reserved::NTuple{3,Int64}
 end
 
 mutable struct CResult           # proxsdp_result

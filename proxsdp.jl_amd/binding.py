@@ -109,7 +109,7 @@ def _opt_fields():
     a("reconstruct_mfma", i32); a("small_block_batch", i32); a("full_eig_sign", i32); a("psd_sign_engine", i32)
     a("full_eig_lanczos_verify", i32); a("full_eig_lanczos_posres", f64); a("full_eig_lanczos_kdim10", i32)
     a("sign_small_tile_max", i32); a("host_eig_threads", i32); a("block_threads", i32)
-    a("device_restart", i32); a("block_batch", i32); a("block_eigensolver", i32); a("rocsolver_warmup", i32)
+    a("host_eig_merge", i32); a("block_batch", i32); a("block_eigensolver", i32); a("rocsolver_warmup", i32)
     a("reserved_i", i32 * 6); a("reserved_d", f64 * 2)
     return F
 
@@ -134,7 +134,8 @@ class Stats(C.Structure):
                 ("sign_engine_checks", i64), ("sign_engine_mismatches", i64),
                 ("full_eigs_lanczos_checks", i64), ("full_eigs_lanczos_mismatches", i64),
                 ("batched_block_steps", i64), ("rccl_reductions", i64), ("device_restarts", i64),
-                ("block_eig_steps", i64), ("batched_profiled_blocks", i64), ("reserved", i64 * 5)]
+                ("block_eig_steps", i64), ("batched_profiled_blocks", i64), ("host_eig_merges", i64),
+                ("host_eig_overlap_time", f64), ("reserved", i64 * 3)]
 
 
 class Result(C.Structure):
@@ -555,6 +556,21 @@ def host_start_vector(n, seed=1234, init=3):
     out = np.zeros(n)
     _check(lib().proxsdp_host_start_vector(n, seed, init, _p(out)))
     return out
+
+
+def host_symeig_split(D, f, al, be, k1):
+    """proxsdp_host_symeig_split: eigen-decomposition of the restarted Rayleigh quotient (as host_symeig_arrow) by a
+    split at k1 + rank-one merge.  Returns (d ascending, U, info dict)."""
+    D = _f(D); f = _f(f); al = _f(al); be = _f(be)
+    K, m = len(al), len(D)
+    U = np.zeros((K, K))
+    d = np.zeros(K)
+    info = (i32 * 3)()
+    L = lib()
+    L.proxsdp_host_symeig_split.argtypes = [i32, i32, i32, pf64, pf64, pf64, pf64, pf64, pf64, C.POINTER(i32)]
+    _check(L.proxsdp_host_symeig_split(K, m, int(k1), _p(D) if m else None, _p(f) if m else None, _p(al), _p(be),
+                                       _p(U), _p(d), info))
+    return d, U.T.copy(), dict(nondeflated=info[0], deflated=info[1], max_secular_iterations=info[2])
 
 
 def host_preprocess(prob, index_base=0):

@@ -473,6 +473,19 @@ int proxsdp_host_symeig_arrow(int32_t K, int32_t m, const double* D, const doubl
     return 0;
 }
 
+int proxsdp_host_symeig_split(int32_t K, int32_t m, int32_t k1, const double* D, const double* f,
+                              const double* al, const double* be, double* U, double* d, int32_t* info) {
+    return guarded([&]() -> int {
+        if (K < 2 || m < 0 || m >= K || k1 < 1 || k1 >= K || !al || !be || !U || !d) throw std::invalid_argument("invalid argument");
+        proxsdp::SplitEig S;
+        if (S.first(k1, m, D, f, al, be) != 0 || S.second(K, al, be) != 0) throw std::invalid_argument("split eigensolver failed");
+        std::vector<int> cols(K);
+        for (int c = 0; c < K; ++c) { cols[c] = c; d[c] = S.M.evals[c]; }
+        S.M.vectors(cols.data(), K, U);
+        if (info) { info[0] = S.M.k; info[1] = (int)S.M.df.size(); info[2] = S.M.max_iter_seen; }
+        return 0;
+    });
+}
 int proxsdp_host_start_vector(int64_t n, int64_t seed, int32_t init, double* out) {
     if (n < 0 || !out) { g_last_error = "invalid argument"; return PROXSDP_E_INVALID; }
     proxsdp::start_vector(n, (uint64_t)seed, init, out);

