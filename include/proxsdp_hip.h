@@ -225,8 +225,10 @@ typedef struct proxsdp_options {
     int32_t full_eig_sign;       /* full_eig! of a dense block without an eigendecomposition: X+ = (X + X sign(X)) / 2
                                   * with sign(X) from an odd-polynomial iteration of fp64 MFMA products (57 products of
                                   * n x n symmetric matrices; every |eigenvalue| >= 1e-10 ||X|| is resolved to 1e-15,
-                                  * smaller ones contribute an error <= their own size): -1 auto (33 <= n <= 4096),
-                                  * 1 always, 0 = rocSOLVER dsyevd + reconstruction */
+                                  * smaller ones contribute an error <= their own size): -1 auto (33 <= n <= 4096 and
+                                  * every requested tolerance >= 1e-8: below that the 1e-10 floor of this path could
+                                  * stall a solve, and the dense eigensolver is used), 1 always, 0 = rocSOLVER dsyevd +
+                                  * reconstruction */
     int32_t psd_sign_engine;     /* 1: on the Krylov branch, let the sign-function projection stand in for the Lanczos
                                   * engine when it is measured to be the cheaper way to the SAME matrix (fewer than
                                   * target_rank positive eigenvalues => the truncated projection is the exact one and

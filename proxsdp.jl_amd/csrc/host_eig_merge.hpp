@@ -27,8 +27,38 @@
 #include <cmath>
 #include <limits>
 #include <vector>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 namespace proxsdp {
+
+#if defined(__x86_64__)
+// 8 rows x 4 columns of  U[r0+r.., c] = sum_jj Q[:, qcol[jj]] w_c[jj]  with the accumulators in registers.
+// (FMA is switched on for this one routine: the rest of the host code is built with contraction off.)
+__attribute__((target("avx2,fma")))
+static inline void rank1_panel_8x4(const double* Qf, int K, const int* qcol, int kk, int row, const double* w0,
+                                   const double* w1, const double* w2, const double* w3, double* u0, double* u1,
+                                   double* u2, double* u3) {
+    __m256d a00 = _mm256_setzero_pd(), a10 = a00, a01 = a00, a11 = a00, a02 = a00, a12 = a00, a03 = a00, a13 = a00;
+    for (int jj = 0; jj < kk; ++jj) {
+        const double* qc = Qf + (size_t)qcol[jj] * K + row;
+        const __m256d q0 = _mm256_loadu_pd(qc), q1 = _mm256_loadu_pd(qc + 4);
+        __m256d w = _mm256_broadcast_sd(w0 + jj);
+        a00 = _mm256_fmadd_pd(q0, w, a00); a10 = _mm256_fmadd_pd(q1, w, a10);
+        w = _mm256_broadcast_sd(w1 + jj);
+        a01 = _mm256_fmadd_pd(q0, w, a01); a11 = _mm256_fmadd_pd(q1, w, a11);
+        w = _mm256_broadcast_sd(w2 + jj);
+        a02 = _mm256_fmadd_pd(q0, w, a02); a12 = _mm256_fmadd_pd(q1, w, a12);
+        w = _mm256_broadcast_sd(w3 + jj);
+        a03 = _mm256_fmadd_pd(q0, w, a03); a13 = _mm256_fmadd_pd(q1, w, a13);
+    }
+    if (u0) { _mm256_storeu_pd(u0, a00); _mm256_storeu_pd(u0 + 4, a10); }
+    if (u1) { _mm256_storeu_pd(u1, a01); _mm256_storeu_pd(u1 + 4, a11); }
+    if (u2) { _mm256_storeu_pd(u2, a02); _mm256_storeu_pd(u2 + 4, a12); }
+    if (u3) { _mm256_storeu_pd(u3, a03); _mm256_storeu_pd(u3 + 4, a13); }
+}
+#endif
 
 struct Rank1Merge {
     int K = 0, k1 = 0, k2 = 0, k = 0;      // k = number of non-deflated poles
@@ -278,40 +308,49 @@ struct Rank1Merge {
             if (t == 1 || t == 3) top.push_back(j);
             if (t == 2 || t == 3) bot.push_back(j);
         }
+        // register-blocked panel product: 8 rows x 4 output columns per inner loop (accumulators stay in registers,
+        // every column of Q is read once per 4 columns of U)
         auto panel = [&](const std::vector<int>& idx, int r0, int nr) {
             const int kk = (int)idx.size();
-            // 4 output columns at a time: every column of Q is read once per 4 columns of U
+            if (kk == 0 || nr <= 0) return;
+            std::vector<double> wbuf((size_t)4 * kk);
+            std::vector<int> qcol(kk);
+            for (int jj = 0; jj < kk; ++jj) qcol[jj] = nd[idx[jj]];
             for (int c0 = 0; c0 < ncols; c0 += 4) {
                 const int cb = std::min(4, ncols - c0);
-                double* u[4];
-                const double* s[4];
-                bool root[4];
-                for (int q = 0; q < cb; ++q) {
-                    u[q] = U + (size_t)(c0 + q) * K + r0;
-                    const int sc = src[cols[c0 + q]];
-                    root[q] = sc >= 0;
-                    s[q] = root[q] ? S.data() + (size_t)sc * k : nullptr;
-                }
-                for (int jj = 0; jj < kk; ++jj) {
-                    const int j = idx[jj];
-                    const double* __restrict__ qc = Qf.data() + (size_t)nd[j] * K + r0;
-                    double w[4];
-                    for (int q = 0; q < cb; ++q) w[q] = root[q] ? s[q][j] : 0.0;
-                    if (cb == 4) {
-                        double* __restrict__ u0 = u[0]; double* __restrict__ u1 = u[1];
-                        double* __restrict__ u2 = u[2]; double* __restrict__ u3 = u[3];
-                        const double w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
-                        for (int r = 0; r < nr; ++r) {
-                            const double qv = qc[r];
-                            u0[r] += w0 * qv; u1[r] += w1 * qv; u2[r] += w2 * qv; u3[r] += w3 * qv;
+                double* u[4] = {nullptr, nullptr, nullptr, nullptr};
+                for (int q = 0; q < 4; ++q) {
+                    double* wq = wbuf.data() + (size_t)q * kk;
+                    if (q < cb) {
+                        u[q] = U + (size_t)(c0 + q) * K + r0;
+                        const int sc = src[cols[c0 + q]];
+                        if (sc >= 0) {
+                            const double* sp = S.data() + (size_t)sc * k;
+                            for (int jj = 0; jj < kk; ++jj) wq[jj] = sp[idx[jj]];
+                        } else {
+                            for (int jj = 0; jj < kk; ++jj) wq[jj] = 0.0;
                         }
                     } else {
-                        for (int q = 0; q < cb; ++q) {
-                            double* __restrict__ uq = u[q];
-                            const double wq = w[q];
-                            for (int r = 0; r < nr; ++r) uq[r] += wq * qc[r];
-                        }
+                        for (int jj = 0; jj < kk; ++jj) wq[jj] = 0.0;
                     }
+                }
+                const double* w0 = wbuf.data(); const double* w1 = w0 + kk; const double* w2 = w1 + kk; const double* w3 = w2 + kk;
+                int r = 0;
+#if defined(__x86_64__)
+                for (; r + 8 <= nr; r += 8)
+                    rank1_panel_8x4(Qf.data(), K, qcol.data(), kk, r0 + r, w0, w1, w2, w3, u[0] ? u[0] + r : nullptr,
+                                    u[1] ? u[1] + r : nullptr, u[2] ? u[2] + r : nullptr, u[3] ? u[3] + r : nullptr);
+#endif
+                for (; r < nr; ++r) {
+                    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                    for (int jj = 0; jj < kk; ++jj) {
+                        const double qv = Qf[(size_t)qcol[jj] * K + r0 + r];
+                        a0 += qv * w0[jj]; a1 += qv * w1[jj]; a2 += qv * w2[jj]; a3 += qv * w3[jj];
+                    }
+                    if (u[0]) u[0][r] = a0;
+                    if (u[1]) u[1][r] = a1;
+                    if (u[2]) u[2][r] = a2;
+                    if (u[3]) u[3][r] = a3;
                 }
             }
         };

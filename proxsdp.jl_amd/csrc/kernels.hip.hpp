@@ -975,6 +975,52 @@ k_lz_rotate(const double* __restrict__ V, int ldv, int n, int K, const double* _
     if (copy_src >= 0 && wv == 0) out[(long long)copy_dst * ldo + i] = V[(long long)copy_src * ldv + i];
 }
 
+// batched form (grid.z = block) for the restarts / final Ritz vectors of lanczos_batch: one launch instead of one per block
+struct LzRot {
+    const double* V; const double* U; double* out;
+    int K, ncols, copy_src, copy_dst;
+};
+struct LzRotBatch {
+    LzRot r[LZB_MAX];
+    int npad, nb;
+};
+__global__ void __launch_bounds__(TPB)
+k_lzb_rotate(LzRotBatch B) {
+    extern __shared__ double s_mem[];
+    const LzRot& q = B.r[blockIdx.z];
+    const int K = q.K, ncols = q.ncols;
+    if (ncols <= 0 && q.copy_src < 0) return;
+    double* s_U = s_mem;
+    double* s_V = s_mem + (size_t)K * ncols;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = blockIdx.x * LZ_ROWS + lane;
+    const int ldv = B.npad;
+    for (int t = threadIdx.x; t < K * ncols; t += TPB) s_U[t] = q.U[t];           // compact K x ncols
+    for (int j = wv; j < K; j += NWAVE) s_V[j * (LZ_ROWS + 1) + lane] = q.V[(long long)j * ldv + i];
+    __syncthreads();
+    for (int c = wv; c < ncols; c += NWAVE) {
+        const double* u = s_U + (size_t)c * K;
+        double a0 = 0.0, a1 = 0.0;
+        int j = 0;
+        for (; j + 1 < K; j += 2) {
+            a0 += s_V[j * (LZ_ROWS + 1) + lane] * u[j];
+            a1 += s_V[(j + 1) * (LZ_ROWS + 1) + lane] * u[j + 1];
+        }
+        if (j < K) a0 += s_V[j * (LZ_ROWS + 1) + lane] * u[j];
+        q.out[(long long)c * ldv + i] = a0 + a1;
+    }
+    if (q.copy_src >= 0 && wv == 0) q.out[(long long)q.copy_dst * ldv + i] = q.V[(long long)q.copy_src * ldv + i];
+}
+// every block's record [alphas | betas | ctl] into one buffer (pinned host memory: no copy engine round trip)
+__global__ void __launch_bounds__(TPB)
+k_lzb_gather_rec(LzBatch B, double* __restrict__ out, int rec_doubles) {
+    const LzBlk& b = B.b[blockIdx.z];
+    if (b.mode == 0) return;
+    const double* src = b.alphas;                        // the record starts at the alphas
+    for (int t = blockIdx.x * TPB + threadIdx.x; t < rec_doubles; t += gridDim.x * TPB)
+        out[(long long)blockIdx.z * rec_doubles + t] = src[t];
+}
+
 // ---------------------------------------------------------------------------
 // Rank-r reconstruction written directly in packed form:
 //   xp[(i,j)] = s_ij * sum_k lambda_k Z[i,k] Z[j,k],  s = sqrt2 off-diagonal, 1 on it

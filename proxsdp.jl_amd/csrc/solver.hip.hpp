@@ -137,6 +137,27 @@ struct StreamRef {
     operator hipStream_t() const { return tl ? tl : main; }
 };
 
+// Host state of ONE thick-restart Lanczos run (one PSD block): what KrylovKit keeps between the restarts of an
+// eigsolve call.  Split out of Solver::lanczos so that the single-block driver and the batched multi-block driver
+// (lanczos_batch: one launch per step for several blocks) share the restart logic line by line.
+struct LzRun {
+    int nev = 0, krylovdim = 0, ld = 0;
+    bool arpack = false, positive_part = false;
+    double tol = 0.0, step_tol = 0.0;
+    long long maxiter = 0;
+    std::vector<double> T, Tw, D, U, f, al, be, Qa, da, ea;
+    int howmany = 0, numiter = 1, converged = 0, K = 0, kfirst = 0, pos_count = -1, m_arrow = 0;
+    bool pos_fail = false, presymv = false;
+    double betaK = 0.0;
+    // split + rank-one merge (host_eig_merge.hpp): first part solved under the GPU's cycle.  The solver object lives
+    // in the block's workspace (its ~0.5 MB of tables are reused across projections, not re-allocated per call)
+    SplitEig* splitp = nullptr;
+    SplitEig& split_ref() { return *splitp; }
+    bool split_ready = false;         // split.first() succeeded for the cycle in progress
+    bool merge_active = false;        // D / f of the last eigensolve came from the merge: U holds no vectors yet
+    std::vector<double> erow;
+};
+
 struct EigWork {
     int n = 0, nt = 0, npad = 0, nwg = 0, cap = 0, pld = 0;   // cap = columns of V (krylovdim_max + 1)
     int64_t N = 0;
@@ -176,6 +197,8 @@ struct EigWork {
     hipStream_t side = nullptr;
     hipEvent_t ev_mid = nullptr, ev_early = nullptr;
     PinnedBuf rec_early;
+    SplitEig split;
+    LzRun lzrun;                                   // host state of the run in progress (buffers reused across projections)
     long long fel_served = 0;                      // full_eig! calls of this block served by the Lanczos engine
     bool fel_disabled = false;                     // ... switched off after a failed verification (full_eig_lanczos_verify)
     // persistent Lanczos cycle kernel (lanczos_cycle.hip.hpp): granule buffers, epoch counter, error word
@@ -213,6 +236,13 @@ struct EigWork {
     DevBuf<double> sg_out;
 };
 
+
+// requests of one batched rotation launch (lanczos_batch): filled through Solver::rotate while a sink is installed
+struct RotSink {
+    struct Req { EigWork* W; const double* V; double* out; int K, ncols, copy_src, copy_dst; size_t off, arrow_off; bool has_arrow; };
+    std::vector<Req> reqs;
+    size_t used = 0;                 // doubles of the staging buffer in use
+};
 
 class Solver {
 public:
@@ -279,6 +309,12 @@ public:
     void alloc_eigwork(EigWork& W, int n, int max_nev);
     void lanczos(EigWork& W, const double* xp, int nev, bool positive_part = false);
     void lanczos_batch(const std::vector<int>& blocks, const double* xbase, const std::vector<int>& nevs);
+    // batched rotations: U of every block staged in ONE pinned buffer, one upload, one launch (grid.z = block)
+    RotSink* rot_sink = nullptr;
+    DevBuf<double> lzb_U, lzb_rec;
+    PinnedBuf lzb_U_host, lzb_rec_host;
+    static constexpr size_t LZB_USTRIDE = 64 * 64 + 2 * dev::MAXK;
+    void flush_rotations(RotSink& sink);
     bool lz_init(EigWork& W, struct LzRun& R, int nev, bool positive_part);
     void lz_prepare_arrow(struct LzRun& R);
     bool lz_after_cycle(EigWork& W, struct LzRun& R, bool speculated);
@@ -537,6 +573,7 @@ inline void Solver::setup_device() {
     rotate_lds_cap = (hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_lz_rotate),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) == hipSuccess)
                          ? 144 * 1024 : 60 * 1024;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_lzb_rotate), hipFuncAttributeMaxDynamicSharedMemorySize, rotate_lds_cap);
     if (std::getenv("PROXSDP_HIP_DEBUG_CYCLE") != nullptr) { cy_dbg.alloc(16); cy_dbg.zero(stream); }
     cycle_lds_cap = 0;
     for (int kb : {160, 156, 152, 144, 128, 96, 64}) {
@@ -758,6 +795,21 @@ inline void Solver::rotate(EigWork& W, int K, const std::vector<double>& U, int 
     // U: host column-major (ldu x >=ncols); upload the K x ncols part compactly from a
     // staging buffer that alternates between two slots: two rotations can be in flight
     // between host synchronisations (restart rotation, then the final Ritz-vector one)
+    if (rot_sink != nullptr) {
+        // batched run: stage the compact K x ncols part (+ the arrow) for ONE upload and ONE launch per cycle
+        RotSink& S = *rot_sink;
+        RotSink::Req q{&W, W.V.p, out, K, ncols, copy_src, copy_dst, S.used, 0, nextra > 0};
+        double* dst = lzb_U_host.p + S.used;
+        for (int c = 0; c < ncols; ++c)
+            for (int j = 0; j < K; ++j) dst[(size_t)c * K + j] = U[(size_t)c * ldu + j];
+        size_t len = (size_t)K * std::max(ncols, 0);
+        q.arrow_off = S.used + len;
+        for (int t = 0; t < nextra; ++t) dst[len + t] = extra[t];
+        len += (size_t)std::max(nextra, 0);
+        S.used += (len + 7) & ~(size_t)7;
+        S.reqs.push_back(q);
+        return;
+    }
     std::vector<double>& tmp = W.Ustage[W.ustage_next];
     W.ustage_next ^= 1;
     // `extra` (the arrow part f | D of the restarted Rayleigh quotient) rides behind U in the same
@@ -802,25 +854,6 @@ inline void Solver::rotate(EigWork& W, int K, const std::vector<double>& U, int 
 // below zero while small positive eigenvalues are still unresolved -- measured on gpp500-1.)
 // Returns the j positive pairs (count = j, possibly 0, converged = true), or converged = false when
 // more than nev Ritz values are positive / maxiter is hit.
-// Host state of ONE thick-restart Lanczos run (one PSD block): what KrylovKit keeps between the restarts of an
-// eigsolve call.  Split out of Solver::lanczos so that the single-block driver and the batched multi-block driver
-// (lanczos_batch: one launch per step for several blocks) share the restart logic line by line.
-struct LzRun {
-    int nev = 0, krylovdim = 0, ld = 0;
-    bool arpack = false, positive_part = false;
-    double tol = 0.0, step_tol = 0.0;
-    long long maxiter = 0;
-    std::vector<double> T, Tw, D, U, f, al, be, Qa, da, ea;
-    int howmany = 0, numiter = 1, converged = 0, K = 0, kfirst = 0, pos_count = -1, m_arrow = 0;
-    bool pos_fail = false, presymv = false;
-    double betaK = 0.0;
-    // split + rank-one merge (host_eig_merge.hpp): first part solved under the GPU's cycle
-    SplitEig split;
-    bool split_ready = false;         // split.first() succeeded for the cycle in progress
-    bool merge_active = false;        // D / f of the last eigensolve came from the merge: U holds no vectors yet
-    std::vector<double> erow;
-};
-
 // parameters of the run and the per-call reset of W; false = the call ends at once (dsaupd argument errors)
 inline bool Solver::lz_init(EigWork& W, LzRun& R, int nev, bool positive_part) {
     R.nev = nev; R.positive_part = positive_part;
@@ -848,6 +881,7 @@ inline bool Solver::lz_init(EigWork& W, LzRun& R, int nev, bool positive_part) {
     R.howmany = nev; R.numiter = 1; R.converged = 0; R.K = 0; R.kfirst = 0; R.pos_count = -1;
     R.pos_fail = false; R.presymv = false; R.betaK = 0.0;
     R.split_ready = false; R.merge_active = false;
+    R.splitp = &W.split;
     return true;
 }
 
@@ -858,7 +892,7 @@ inline void Solver::lz_merge_vectors(EigWork& W, LzRun& R, int ncols) {
     std::vector<int> cols(std::max(ncols, 1));
     for (int c = 0; c < ncols; ++c) cols[c] = K - 1 - c;              // evals are ascending
     R.U.assign((size_t)K * std::max(ncols, 1), 0.0);
-    if (ncols > 0) R.split.M.vectors(cols.data(), ncols, R.U.data());
+    if (ncols > 0) R.split_ref().M.vectors(cols.data(), ncols, R.U.data());
     W.lst.host_eig_time += now_s() - t0;
 }
 
@@ -915,11 +949,11 @@ inline bool Solver::lz_after_cycle(EigWork& W, LzRun& R, bool speculated) {
     if (K > 1 && R.split_ready && K == krylovdim) {
         // split + rank-one merge: T1' was decomposed while the GPU ran the cycle; here the tail and the merge
         const double te0 = now_s();
-        if (R.split.second(K, al.data(), be.data()) == 0) {
+        if (R.split_ref().second(K, al.data(), be.data()) == 0) {
             R.erow.resize(K);
-            R.split.M.row_of_vectors(K - 1, R.erow.data());
+            R.split_ref().M.row_of_vectors(K - 1, R.erow.data());
             for (int c = 0; c < K; ++c) {                // :LR -> descending
-                D[c] = R.split.M.evals[K - 1 - c];
+                D[c] = R.split_ref().M.evals[K - 1 - c];
                 f[c] = betaK * R.erow[K - 1 - c];
             }
             R.merge_active = true;
@@ -1053,7 +1087,7 @@ inline bool Solver::lz_split_first(EigWork& W, LzRun& R, int k1) {
     if (ok) {
         std::vector<double> Dk(std::max(m, 1)), fk(std::max(m, 1));
         for (int j = 0; j < m; ++j) { Dk[j] = R.T[(size_t)j * R.ld + j]; fk[j] = R.T[(size_t)j * R.ld + m]; }
-        ok = R.split.first(k1, m, Dk.data(), fk.data(), al_e, be_e) == 0;
+        ok = R.split_ref().first(k1, m, Dk.data(), fk.data(), al_e, be_e) == 0;
     }
     R.split_ready = ok;
     W.lst.host_eig_overlap_time += now_s() - t0;
@@ -1061,7 +1095,7 @@ inline bool Solver::lz_split_first(EigWork& W, LzRun& R, int k1) {
 }
 
 inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive_part) {
-    LzRun R;
+    LzRun& R = W.lzrun;
     if (!lz_init(W, R, nev, positive_part)) return;
     const int krylovdim = R.krylovdim;
     const double step_tol = R.step_tol;
@@ -1099,7 +1133,9 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive
         const int kfirst = R.kfirst;
         // split point: the arrow with its hub after a restart, the first half of the tridiagonal in the first cycle;
         // the coefficients of step k1 - 1 exist once the launch of step k1 has closed it
-        const int k1 = (kfirst == 0) ? krylovdim / 2 : kfirst + 1;
+        // (first cycle: T1 takes 72 % of the steps -- its QL, ~0.45 ms (k1/127)^3, still ends before the remaining
+        // steps do, and the tail left for the critical path shrinks to a quarter of the basis: (0.28)^3 of the QL work)
+        const int k1 = (kfirst == 0) ? (18 * krylovdim) / 25 : kfirst + 1;
         const bool split_cycle = use_split && k1 >= 1 && k1 <= krylovdim - 2;
         if (cyc) {
             launch_cycle(W, kfirst, krylovdim, step_tol, cyR, cyG, cyF);
@@ -1219,6 +1255,25 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive
     lz_finish_run(W, R);
 }
 
+inline void Solver::flush_rotations(RotSink& S) {
+    if (S.reqs.empty()) { S.used = 0; return; }
+    if (S.reqs.size() > (size_t)dev::LZB_MAX) throw std::logic_error("flush_rotations: too many requests");
+    PX_HIP(hipMemcpyAsync(lzb_U.p, lzb_U_host.p, S.used * sizeof(double), hipMemcpyHostToDevice, stream));
+    dev::LzRotBatch B{};
+    B.npad = S.reqs[0].W->npad; B.nb = (int)S.reqs.size();
+    size_t lds = 0;
+    int nt = S.reqs[0].W->nt;
+    for (size_t q = 0; q < S.reqs.size(); ++q) {
+        const RotSink::Req& r = S.reqs[q];
+        B.r[q] = dev::LzRot{r.V, lzb_U.p + r.off, r.out, r.K, r.ncols, r.copy_src, r.copy_dst};
+        lds = std::max(lds, ((size_t)r.K * std::max(r.ncols, 0) + (size_t)r.K * (dev::LZ_ROWS + 1)) * sizeof(double));
+        if (r.has_arrow) r.W->arrow_p = lzb_U.p + r.arrow_off;
+    }
+    if ((int)lds > rotate_lds_cap) throw std::logic_error("flush_rotations: LDS budget exceeded");
+    hipLaunchKernelGGL(dev::k_lzb_rotate, dim3(nt, 1, B.nb), dim3(dev::TPB), lds, stream, B);
+    S.reqs.clear(); S.used = 0;
+}
+
 // KrylovKit eigsolve of SEVERAL blocks of equal side at once (kernels.hip.hpp "BATCHED Lanczos step"): one
 // launch per step for all of them (grid.z = block) on the solver's stream, per-block host restart logic
 // (lz_after_cycle) between the cycles.  Per block the arithmetic, the mat-vec count and the restart count are
@@ -1227,7 +1282,9 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive
 inline void Solver::lanczos_batch(const std::vector<int>& blocks, const double* xbase, const std::vector<int>& nevs) {
     const int nb = (int)blocks.size();
     if (nb < 1 || nb > dev::LZB_MAX) throw std::invalid_argument("lanczos_batch: 1..LZB_MAX blocks");
-    std::vector<LzRun> R(nb);
+    std::vector<LzRun*> Rp(nb);
+    for (int q = 0; q < nb; ++q) Rp[q] = &eig[blocks[q]].lzrun;
+    struct RunRefs { std::vector<LzRun*>& p; LzRun& operator[](int q) { return *p[q]; } } R{Rp};
     std::vector<char> live(nb, 0), ran(nb, 0);
     EigWork& W0 = eig[blocks[0]];
     dev::LzBatch B{};
@@ -1249,6 +1306,13 @@ inline void Solver::lanczos_batch(const std::vector<int>& blocks, const double* 
         return b;
     };
     const int ntile = 8 * ceil_div(W0.nt * (W0.nt + 1) / 2, 8);
+    if (lzb_U.n == 0) {
+        lzb_U.alloc(dev::LZB_MAX * LZB_USTRIDE); lzb_U_host.alloc(dev::LZB_MAX * LZB_USTRIDE);
+        lzb_rec.alloc(dev::LZB_MAX * EigWork::REC_DOUBLES); lzb_rec_host.alloc(dev::LZB_MAX * EigWork::REC_DOUBLES);
+    }
+    RotSink sink;
+    struct SinkGuard { Solver& s; ~SinkGuard() { s.rot_sink = nullptr; } } guard{*this};
+    rot_sink = &sink;
     for (int q = 0; q < nb; ++q) fill(q).mode = live[q] ? 1 : 0;
     hipLaunchKernelGGL(dev::k_lzb_begin, dim3(ceil_div(W0.npad, dev::TPB), 1, nb), dim3(dev::TPB), 0, stream, B);
     const double mv_bytes = 8.0 * (double)W0.N + 16.0 * (double)W0.n;
@@ -1294,13 +1358,14 @@ inline void Solver::lanczos_batch(const std::vector<int>& blocks, const double* 
             hipLaunchKernelGGL(dev::k_lzb_orth, dim3(W0.nt, 1, nb), dim3(dev::TPB), 0, stream, B);
             st.batched_block_steps += nlive;
         }
-        for (int q = 0; q < nb; ++q) {
-            if (!live[q]) continue;
-            EigWork& W = eig[blocks[q]];
-            PX_HIP(hipMemcpyAsync(W.rec_host, W.rec.p, EigWork::REC_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, stream));
-        }
+        // every live block's record [alphas | betas | ctl] in ONE gather launch + ONE copy
+        for (int q = 0; q < nb; ++q) fill(q).mode = live[q] ? 1 : 0;
+        hipLaunchKernelGGL(dev::k_lzb_gather_rec, dim3(1, 1, nb), dim3(dev::TPB), 0, stream, B, lzb_rec.p, (int)EigWork::REC_DOUBLES);
+        PX_HIP(hipMemcpyAsync(lzb_rec_host.p, lzb_rec.p, (size_t)nb * EigWork::REC_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, stream));
         for (int q = 0; q < nb; ++q) if (live[q]) lz_prepare_arrow(R[q]);
         PX_HIP(hipStreamSynchronize(stream));
+        for (int q = 0; q < nb; ++q)
+            if (live[q]) std::memcpy(eig[blocks[q]].rec_host, lzb_rec_host.p + (size_t)q * EigWork::REC_DOUBLES, EigWork::REC_DOUBLES * sizeof(double));
         for (size_t sl = 0; sl < W0.ev.used; ++sl) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, W0.ev.e0[sl], W0.ev.e1[sl]) == hipSuccess) {
@@ -1310,8 +1375,10 @@ inline void Solver::lanczos_batch(const std::vector<int>& blocks, const double* 
         W0.ev.used = 0;
         for (int q = 0; q < nb; ++q)
             if (live[q]) live[q] = lz_after_cycle(eig[blocks[q]], R[q], false) ? 1 : 0;
+        flush_rotations(sink);                       // the restart rotations of this cycle: one upload, one launch
     }
     for (int q = 0; q < nb; ++q) if (ran[q]) lz_finish_run(eig[blocks[q]], R[q]);
+    flush_rotations(sink);                           // the Ritz vectors of every block
     st.batched_profiled_blocks += prof_blocks;       // blocks served by the event-bracketed launches (bytes = this x (8N + 16n))
 }
 
@@ -1369,6 +1436,9 @@ inline bool Solver::full_eig_by_sign(int idx, const double* xp_in, double* xp_ou
     if (!force) {
         if (opt.full_eig_sign == 0) return false;
         if (opt.full_eig_sign < 0 && (n < 33 || n > 4096)) return false;     // auto: measured window
+        // auto: X+ carries an absolute error of up to ~1e-10 x the spectral scale on this path (l_0 of the
+        // iteration): users who ask for tolerances near that floor get the LAPACK-accurate dense eigensolver
+        if (opt.full_eig_sign < 0 && std::min({opt.tol_gap, opt.tol_feasibility, opt.tol_primal, opt.tol_dual}) < 1e-8) return false;
     }
     const int ld = W.nt * dev::TILE;
     const int ntile = W.nt * (W.nt + 1) / 2, grid = 8 * ceil_div(ntile, 8);
