@@ -98,7 +98,6 @@ def main():
     ap.add_argument("--block-threads", dest="block_threads", type=int, default=None)
     ap.add_argument("--host-eig-merge", dest="host_eig_merge", type=int, default=None,
                     help="library-only: K x K Rayleigh-quotient eigensolves by split + rank-one merge (-1 auto, 0 = implicit QL)")
-    ap.add_argument("--block-eigensolver", dest="block_eigensolver", type=int, default=None)
     ap.add_argument("--rand-n", type=int, default=2000)
     ap.add_argument("--rand-m", type=int, default=4000)
     ap.add_argument("--blocks", type=int, default=8)
@@ -179,7 +178,8 @@ def main():
                    "lanczos_matvecs_per_step": mv_step, "linesearch_trials_per_step": trials_step,
                    "lanczos_restarts_per_step": st["lanczos_restarts"] / max(1, int(sol.iter)),
                    "host_eigensolve_ms_per_step": 1e3 * st["host_eig_time"] / max(1, int(sol.iter)),
-                   "device_eigensolves_per_step": st["device_eigs"] / max(1, int(sol.iter)),
+                   "host_eigensolve_overlapped_ms_per_step": 1e3 * st["host_eig_overlap_time"] / max(1, int(sol.iter)),
+                   "host_eig_merges_per_step": st["host_eig_merges"] / max(1, int(sol.iter)),
                    "full_eigs": int(st["full_eigs"]),
                    "options": {"initial_target_rank": r0, "max_target_rank_krylov_eigs": kry, **extra_opts(args)}},
         "roofline": step_roofline(st, n, N, r0, krylovdim, mv_step, 1e3 * t_steps / K),
@@ -270,7 +270,7 @@ def main():
                     "full_eigs_lanczos": int(s["full_eigs_lanczos"]),
                     "full_eigs_lanczos_checks": int(s["full_eigs_lanczos_checks"]),
                     "full_eigs_lanczos_mismatches": int(s["full_eigs_lanczos_mismatches"]),
-                    "host_eigensolve_s": s["host_eig_time"], "device_eigensolves": int(s["device_eigs"]),
+                    "host_eigensolve_s": s["host_eig_time"],
                     "host_eig_merges": int(s["host_eig_merges"]), "host_eig_overlapped_s": s["host_eig_overlap_time"],
                     "full_eig_solver_s": 1e-3 * s["full_eig_solver_ms"], "full_eig_recon_s": 1e-3 * s["full_eig_recon_ms"],
                     "options": kw}
@@ -370,7 +370,7 @@ def extra_opts(args):
     """library-only knobs passed through to every GPU leg (empty = the KrylovKit-faithful parity path)"""
     kw = {}
     for name in ("lanczos_warm_start", "lanczos_cycle_kernel", "full_eig_lanczos", "reconstruct_mfma", "full_eig_sign",
-                 "psd_sign_engine", "block_batch", "block_threads", "host_eig_merge", "block_eigensolver"):
+                 "psd_sign_engine", "block_batch", "block_threads", "host_eig_merge"):
         v = getattr(args, name, None)
         if v is not None:
             kw[name] = v

@@ -261,11 +261,8 @@ typedef struct proxsdp_options {
                                   * 1 = from krylovdim 24 on.  Same decomposition to rounding (orthogonality ~1e-14). */
     int32_t block_batch;         /* PSD blocks of equal side projected by ONE launch per Lanczos step (grid.z = block)
                                   * instead of one stream + host thread per block: -1 auto, 0 off, 1 on */
-    int32_t block_eigensolver;   /* 0 (default) = KrylovKit's single-vector thick-restart Lanczos (the reference's
-                                  * algorithm, mat-vec counts as the oracle's); b > 1 = warm-started BLOCK eigensolver of
-                                  * width b (library-only: same wanted pairs to krylovkit_tol, different Krylov space) */
     int32_t rocsolver_warmup;    /* 1 = load rocSOLVER's code objects from a background thread at start-up (default 0) */
-    int32_t reserved_i[6];       /* zero */
+    int32_t reserved_i[7];       /* zero */
     double  reserved_d[2];       /* zero */
 } proxsdp_options;
 
@@ -298,7 +295,7 @@ typedef struct proxsdp_stats {
     int64_t exit_matvecs;        /* mat-vecs of the exit path's lambda_min(dual cone) Lanczos   */
     double  host_eig_time;       /* s: K x K Rayleigh-quotient eigensolves done on the HOST     */
     int64_t host_eigs;           /* how many of them                                            */
-    int64_t device_eigs;         /* K x K eigensolves done by the device eigensolver            */
+    int64_t device_eigs;         /* unused (0): a device-side K x K eigensolver was measured and dropped, DESIGN.md section 8 */
     int64_t batched_small_eigs;  /* small-block (n <= 32) projections done by the batched Jacobi kernel */
     int64_t mfma_reconstructions;/* reconstructions that took the MFMA (v_mfma_f64_16x16x4) SYRK */
     int64_t orth_profiled;       /* k_lz_orth launches bracketed by events (profile_symv_every)  */
@@ -320,14 +317,12 @@ typedef struct proxsdp_stats {
     int64_t full_eigs_lanczos_mismatches; /* ... that disagreed: the block went back to the dense engine */
     int64_t batched_block_steps;     /* Lanczos steps launched for several blocks at once (block_batch) */
     int64_t rccl_reductions;         /* collectives issued by the library itself on its own stream (nccl_comm) */
-    int64_t device_restarts;         /* thick restarts done entirely on the device (device_restart) */
-    int64_t block_eig_steps;         /* block steps of the block eigensolver (block_eigensolver) */
     int64_t batched_profiled_blocks; /* block mat-vecs inside the event-bracketed batched launches (symv_profiled
                                       * counts launches; bytes of those launches = this x (8 N + 16 n)) */
     int64_t host_eig_merges;         /* K x K eigensolves done by split + rank-one merge (host_eig_merge); host_eig_time
                                       * then counts only their critical-path part */
     double  host_eig_overlap_time;   /* s: the part of those eigensolves done while the GPU was running the cycle */
-    int64_t reserved[3];
+    int64_t reserved[5];
 } proxsdp_stats;
 
 /* Result (structs.jl:60-81).  Arrays are caller-allocated with the stated

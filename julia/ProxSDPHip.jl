@@ -108,12 +108,10 @@ struct Stats                     # proxsdp_stats
     full_eigs_lanczos_mismatches::Int64
     batched_block_steps::Int64
     rccl_reductions::Int64
-    device_restarts::Int64
-    block_eig_steps::Int64
     batched_profiled_blocks::Int64
     host_eig_merges::Int64
     host_eig_overlap_time::Float64
-    reserved::NTuple{3,Int64}
+    reserved::NTuple{5,Int64}
 end
 
 mutable struct CResult           # proxsdp_result

@@ -1618,7 +1618,7 @@ inline void Solver::merge_block_stats() {
         st.symv_profiled += a.symv_profiled; st.symv_profiled_ms += a.symv_profiled_ms;
         st.orth_profiled += a.orth_profiled; st.orth_profiled_ms += a.orth_profiled_ms;
         st.full_eig_solver_ms += a.full_eig_solver_ms; st.full_eig_recon_ms += a.full_eig_recon_ms;
-        st.full_eigs_lanczos += a.full_eigs_lanczos; st.full_eigs_sign += a.full_eigs_sign; st.sign_products += a.sign_products; st.sign_engine_projections += a.sign_engine_projections; st.sign_engine_rejected += a.sign_engine_rejected; st.sign_engine_checks += a.sign_engine_checks; st.sign_engine_mismatches += a.sign_engine_mismatches; st.full_eigs_lanczos_checks += a.full_eigs_lanczos_checks; st.full_eigs_lanczos_mismatches += a.full_eigs_lanczos_mismatches; st.batched_block_steps += a.batched_block_steps; st.device_restarts += a.device_restarts; st.block_eig_steps += a.block_eig_steps; st.host_eig_merges += a.host_eig_merges; st.host_eig_overlap_time += a.host_eig_overlap_time; st.warm_starts += a.warm_starts; st.device_eigs += a.device_eigs; st.mfma_reconstructions += a.mfma_reconstructions; st.cycle_launches += a.cycle_launches;
+        st.full_eigs_lanczos += a.full_eigs_lanczos; st.full_eigs_sign += a.full_eigs_sign; st.sign_products += a.sign_products; st.sign_engine_projections += a.sign_engine_projections; st.sign_engine_rejected += a.sign_engine_rejected; st.sign_engine_checks += a.sign_engine_checks; st.sign_engine_mismatches += a.sign_engine_mismatches; st.full_eigs_lanczos_checks += a.full_eigs_lanczos_checks; st.full_eigs_lanczos_mismatches += a.full_eigs_lanczos_mismatches; st.batched_block_steps += a.batched_block_steps; st.host_eig_merges += a.host_eig_merges; st.host_eig_overlap_time += a.host_eig_overlap_time; st.warm_starts += a.warm_starts; st.device_eigs += a.device_eigs; st.mfma_reconstructions += a.mfma_reconstructions; st.cycle_launches += a.cycle_launches;
         st.cycle_steps += a.cycle_steps; st.cycle_ms += a.cycle_ms;
         st.symv_bytes += a.symv_bytes; st.host_eig_time += a.host_eig_time; st.host_eigs += a.host_eigs;
         st.fop_projections += a.fop_projections;

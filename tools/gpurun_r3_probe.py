@@ -45,7 +45,7 @@ if "merge" in which:
     a, b = out["merge_0"], out["merge_-1"]
     print("same matvecs:", a["matvecs"] == b["matvecs"], "obj rel diff %.2e" % (abs(a["prim_obj_last"] - b["prim_obj_last"]) / abs(a["prim_obj_last"])))
     for tk in (16, 64):
-        for hm in (0, -1):
+        for hm in ((0, -1) if tk == 16 else (0, -1, 1)):
             o = Optimizer(time_limit=200.0, max_target_rank_krylov_eigs=tk, host_eig_merge=hm)
             s = o.optimize(pr)
             out[f"t2t_k{tk}_merge{hm}"] = dict(status=s.status, iter=int(s.iter), obj=s.objval, time=s.time, host_eig_s=s.stats["host_eig_time"],
