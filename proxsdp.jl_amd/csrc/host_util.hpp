@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <cstddef>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -445,6 +446,85 @@ inline int symeig_tridiag_from(int K, int m, const double* Qa, const double* da,
     for (int j = m + 1; j < K; ++j) e[j] = be[j - 1];
     return ql_implicit(K, U, d, e.data());
 }
+
+// ------------------------------------------------------------------ spin pool
+// A few helper threads for SHORT independent host jobs on the critical path (the per-block restart logic of a batched
+// multi-block Lanczos run: 8 K x K eigensolves of ~10 us each per cycle).  Waking a sleeping thread costs more than such a
+// job, so the helpers sleep only while the pool is DISARMED; armed (for the duration of one batched projection) they spin
+// on a generation counter, the caller takes part in the work, and completion is a spin on a counter.
+class SpinPool {
+public:
+    explicit SpinPool(int nthreads) {
+        for (int t = 0; t < nthreads; ++t) th_.emplace_back([this]() { loop(); });
+    }
+    ~SpinPool() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_.store(true); }
+        cv_.notify_all();
+        for (auto& t : th_) if (t.joinable()) t.join();
+    }
+    SpinPool(const SpinPool&) = delete;
+    SpinPool& operator=(const SpinPool&) = delete;
+    int helpers() const { return (int)th_.size(); }
+    void arm() {
+        { std::lock_guard<std::mutex> lk(mu_); armed_.store(true, std::memory_order_release); }
+        cv_.notify_all();
+    }
+    void disarm() { armed_.store(false, std::memory_order_release); }
+    // fn(i) for every i in [0, n), on the helpers and the calling thread; returns when all are done.
+    // fn must not throw (callers catch inside and report through their own state).
+    template <typename F>
+    void run(int n, F&& fn) {
+        if (n <= 0) return;
+        std::function<void(int)> f = fn;
+        job_ = &f;
+        njobs_ = n;
+        done_.store(0, std::memory_order_relaxed);
+        next_.store(0, std::memory_order_release);
+        gen_.fetch_add(1, std::memory_order_acq_rel);
+        work();
+        while (done_.load(std::memory_order_acquire) < n) {
+#if defined(__x86_64__)
+            _mm_pause();
+#endif
+        }
+    }
+private:
+    void work() {
+        for (;;) {
+            const int i = next_.fetch_add(1, std::memory_order_acq_rel);
+            if (i >= njobs_) break;
+            (*job_)(i);
+            done_.fetch_add(1, std::memory_order_acq_rel);
+        }
+    }
+    void loop() {
+        long long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&]() { return stop_.load() || armed_.load(std::memory_order_acquire); });
+                if (stop_.load()) return;
+            }
+            while (armed_.load(std::memory_order_acquire) && !stop_.load(std::memory_order_relaxed)) {
+                const long long g = gen_.load(std::memory_order_acquire);
+                if (g != seen) { seen = g; work(); }
+                else {
+#if defined(__x86_64__)
+                    _mm_pause();
+#endif
+                }
+            }
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::atomic<bool> armed_{false}, stop_{false};
+    std::atomic<long long> gen_{0};
+    std::atomic<int> next_{1 << 30}, done_{0};
+    int njobs_ = 0;
+    const std::function<void(int)>* job_ = nullptr;
+};
 
 // ------------------------------------------------------------------ split + rank-one merge (host_eig_merge.hpp)
 // The same K x K Rayleigh quotient T as symeig_tridiag_from (m = 0: plain tridiagonal), decomposed in two phases:

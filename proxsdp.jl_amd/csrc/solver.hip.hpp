@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <array>
+#include <memory>
 #include <mutex>
 #include <condition_variable>
 #include <functional>
@@ -198,6 +199,7 @@ struct EigWork {
     hipEvent_t ev_mid = nullptr, ev_early = nullptr;
     PinnedBuf rec_early;
     SplitEig split;
+    int batch_slot = 0;                            // position of this block in the batched run in progress
     LzRun lzrun;                                   // host state of the run in progress (buffers reused across projections)
     long long fel_served = 0;                      // full_eig! calls of this block served by the Lanczos engine
     bool fel_disabled = false;                     // ... switched off after a failed verification (full_eig_lanczos_verify)
@@ -239,9 +241,11 @@ struct EigWork {
 
 // requests of one batched rotation launch (lanczos_batch): filled through Solver::rotate while a sink is installed
 struct RotSink {
-    struct Req { EigWork* W; const double* V; double* out; int K, ncols, copy_src, copy_dst; size_t off, arrow_off; bool has_arrow; };
-    std::vector<Req> reqs;
-    size_t used = 0;                 // doubles of the staging buffer in use
+    // one slot per block of the batch: filled by that block's restart logic (possibly on a helper thread), packed into
+    // the contiguous pinned staging buffer by flush_rotations on the calling thread
+    struct Req { EigWork* W = nullptr; const double* V = nullptr; double* out = nullptr; int K = 0, ncols = 0, copy_src = -1,
+                 copy_dst = 0, nextra = 0; bool valid = false; std::vector<double> data; };
+    std::array<Req, dev::LZB_MAX> slot;
 };
 
 class Solver {
@@ -311,6 +315,7 @@ public:
     void lanczos_batch(const std::vector<int>& blocks, const double* xbase, const std::vector<int>& nevs);
     // batched rotations: U of every block staged in ONE pinned buffer, one upload, one launch (grid.z = block)
     RotSink* rot_sink = nullptr;
+    std::unique_ptr<SpinPool> restart_pool;        // helper threads for the per-block restart logic of a batched run
     DevBuf<double> lzb_U, lzb_rec;
     PinnedBuf lzb_U_host, lzb_rec_host;
     static constexpr size_t LZB_USTRIDE = 64 * 64 + 2 * dev::MAXK;
@@ -797,17 +802,13 @@ inline void Solver::rotate(EigWork& W, int K, const std::vector<double>& U, int 
     // between host synchronisations (restart rotation, then the final Ritz-vector one)
     if (rot_sink != nullptr) {
         // batched run: stage the compact K x ncols part (+ the arrow) for ONE upload and ONE launch per cycle
-        RotSink& S = *rot_sink;
-        RotSink::Req q{&W, W.V.p, out, K, ncols, copy_src, copy_dst, S.used, 0, nextra > 0};
-        double* dst = lzb_U_host.p + S.used;
+        RotSink::Req& q = rot_sink->slot[W.batch_slot];
+        q.W = &W; q.V = W.V.p; q.out = out; q.K = K; q.ncols = ncols; q.copy_src = copy_src; q.copy_dst = copy_dst;
+        q.nextra = std::max(nextra, 0); q.valid = true;
+        q.data.resize((size_t)K * std::max(ncols, 0) + (size_t)q.nextra);
         for (int c = 0; c < ncols; ++c)
-            for (int j = 0; j < K; ++j) dst[(size_t)c * K + j] = U[(size_t)c * ldu + j];
-        size_t len = (size_t)K * std::max(ncols, 0);
-        q.arrow_off = S.used + len;
-        for (int t = 0; t < nextra; ++t) dst[len + t] = extra[t];
-        len += (size_t)std::max(nextra, 0);
-        S.used += (len + 7) & ~(size_t)7;
-        S.reqs.push_back(q);
+            for (int j = 0; j < K; ++j) q.data[(size_t)c * K + j] = U[(size_t)c * ldu + j];
+        for (int t = 0; t < q.nextra; ++t) q.data[(size_t)K * std::max(ncols, 0) + t] = extra[t];
         return;
     }
     std::vector<double>& tmp = W.Ustage[W.ustage_next];
@@ -1256,22 +1257,25 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive
 }
 
 inline void Solver::flush_rotations(RotSink& S) {
-    if (S.reqs.empty()) { S.used = 0; return; }
-    if (S.reqs.size() > (size_t)dev::LZB_MAX) throw std::logic_error("flush_rotations: too many requests");
-    PX_HIP(hipMemcpyAsync(lzb_U.p, lzb_U_host.p, S.used * sizeof(double), hipMemcpyHostToDevice, stream));
     dev::LzRotBatch B{};
-    B.npad = S.reqs[0].W->npad; B.nb = (int)S.reqs.size();
-    size_t lds = 0;
-    int nt = S.reqs[0].W->nt;
-    for (size_t q = 0; q < S.reqs.size(); ++q) {
-        const RotSink::Req& r = S.reqs[q];
-        B.r[q] = dev::LzRot{r.V, lzb_U.p + r.off, r.out, r.K, r.ncols, r.copy_src, r.copy_dst};
+    size_t used = 0, lds = 0;
+    int nt = 0;
+    for (RotSink::Req& r : S.slot) {
+        if (!r.valid) continue;
+        r.valid = false;
+        const size_t len = r.data.size();
+        if (used + len > (size_t)dev::LZB_MAX * LZB_USTRIDE) throw std::logic_error("flush_rotations: staging buffer too small");
+        std::memcpy(lzb_U_host.p + used, r.data.data(), len * sizeof(double));
+        B.r[B.nb++] = dev::LzRot{r.V, lzb_U.p + used, r.out, r.K, r.ncols, r.copy_src, r.copy_dst};
+        if (r.nextra > 0) r.W->arrow_p = lzb_U.p + used + (size_t)r.K * std::max(r.ncols, 0);
         lds = std::max(lds, ((size_t)r.K * std::max(r.ncols, 0) + (size_t)r.K * (dev::LZ_ROWS + 1)) * sizeof(double));
-        if (r.has_arrow) r.W->arrow_p = lzb_U.p + r.arrow_off;
+        B.npad = r.W->npad; nt = r.W->nt;
+        used += (len + 7) & ~(size_t)7;
     }
+    if (B.nb == 0) return;
     if ((int)lds > rotate_lds_cap) throw std::logic_error("flush_rotations: LDS budget exceeded");
+    PX_HIP(hipMemcpyAsync(lzb_U.p, lzb_U_host.p, used * sizeof(double), hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(dev::k_lzb_rotate, dim3(nt, 1, B.nb), dim3(dev::TPB), lds, stream, B);
-    S.reqs.clear(); S.used = 0;
 }
 
 // KrylovKit eigsolve of SEVERAL blocks of equal side at once (kernels.hip.hpp "BATCHED Lanczos step"): one
@@ -1292,6 +1296,7 @@ inline void Solver::lanczos_batch(const std::vector<int>& blocks, const double* 
     for (int q = 0; q < nb; ++q) {
         EigWork& W = eig[blocks[q]];
         W.use_fop = false;
+        W.batch_slot = q;
         live[q] = ran[q] = lz_init(W, R[q], nevs[q], false) ? 1 : 0;
         if (R[q].krylovdim > 63) throw std::invalid_argument("lanczos_batch: krylovdim > 63");
         B.tol = R[q].step_tol;
@@ -1311,8 +1316,14 @@ inline void Solver::lanczos_batch(const std::vector<int>& blocks, const double* 
         lzb_rec.alloc(dev::LZB_MAX * EigWork::REC_DOUBLES); lzb_rec_host.alloc(dev::LZB_MAX * EigWork::REC_DOUBLES);
     }
     RotSink sink;
-    struct SinkGuard { Solver& s; ~SinkGuard() { s.rot_sink = nullptr; } } guard{*this};
+    // helper threads for the restart logic (options.block_threads: -1 auto = one per block up to 8, 0 = none): they spin
+    // only while this projection is in progress
+    const int nhelp = std::min(nb, opt.block_threads < 0 ? 8 : (int)opt.block_threads) - 1;
+    if (nhelp >= 1 && (!restart_pool || restart_pool->helpers() < nhelp)) restart_pool.reset(new SpinPool(nhelp));
+    SpinPool* pool = (nhelp >= 1) ? restart_pool.get() : nullptr;
+    struct SinkGuard { Solver& s; SpinPool* p; ~SinkGuard() { s.rot_sink = nullptr; if (p) p->disarm(); } } guard{*this, pool};
     rot_sink = &sink;
+    if (pool) pool->arm();
     for (int q = 0; q < nb; ++q) fill(q).mode = live[q] ? 1 : 0;
     hipLaunchKernelGGL(dev::k_lzb_begin, dim3(ceil_div(W0.npad, dev::TPB), 1, nb), dim3(dev::TPB), 0, stream, B);
     const double mv_bytes = 8.0 * (double)W0.N + 16.0 * (double)W0.n;
@@ -1373,8 +1384,16 @@ inline void Solver::lanczos_batch(const std::vector<int>& blocks, const double* 
             }
         }
         W0.ev.used = 0;
-        for (int q = 0; q < nb; ++q)
-            if (live[q]) live[q] = lz_after_cycle(eig[blocks[q]], R[q], false) ? 1 : 0;
+        // per-block restart logic (K x K eigensolve, convergence, rotation matrix): independent, on the helper threads
+        std::exception_ptr err[dev::LZB_MAX] = {};
+        auto job = [&](int q) {
+            if (!live[q]) return;
+            try { live[q] = lz_after_cycle(eig[blocks[q]], R[q], false) ? 1 : 0; }
+            catch (...) { err[q] = std::current_exception(); live[q] = 0; }
+        };
+        if (pool) pool->run(nb, job);
+        else for (int q = 0; q < nb; ++q) job(q);
+        for (int q = 0; q < nb; ++q) if (err[q]) std::rethrow_exception(err[q]);
         flush_rotations(sink);                       // the restart rotations of this cycle: one upload, one launch
     }
     for (int q = 0; q < nb; ++q) if (ran[q]) lz_finish_run(eig[blocks[q]], R[q]);
