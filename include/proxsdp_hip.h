@@ -243,7 +243,7 @@ typedef struct proxsdp_options {
                                   * block and every k-th after it are ALSO computed by the reference's engine (sign-function /
                                   * dense eigensolver) on the same input and compared (max |difference| <= 1e-8 max |X+|); a
                                   * mismatch hands the block back to the dense engine for the rest of the solve
-                                  * (stats.full_eigs_lanczos_checks / _mismatches).  -1 auto = 128, 0 = never */
+                                  * (stats.full_eigs_lanczos_checks / _mismatches).  -1 auto = 256, 0 = never */
     double  full_eig_lanczos_posres; /* acceptance of that engine: the first strictly negative Ritz pair must be resolved to
                                   * posres x spectral scale (default 1e-7 = tol_psd's magnitude) */
     int32_t full_eig_lanczos_kdim10; /* its Krylov dimension = max(2 g + 1, g x kdim10 / 10 + 8), default 30 */

@@ -316,7 +316,7 @@ inline bool Solver::full_eig_by_lanczos(int idx, const double* xp, double* xo, b
     // k-th after it the reference's engine (full_eig_project: sign function / dsyevd) ALSO projects the same input
     // (into a scratch buffer, BEFORE the reconstruction overwrites an in-place input); the results are compared
     // below and a mismatch hands the block back to the dense engine for the rest of the solve.
-    const int vk = opt.full_eig_lanczos_verify < 0 ? 128 : opt.full_eig_lanczos_verify;
+    const int vk = opt.full_eig_lanczos_verify < 0 ? 256 : opt.full_eig_lanczos_verify;
     bool verify = vk > 0 && (W.fel_served % vk) == 0;
     long long ref_rank = 0;
     int ref_npos = 0;

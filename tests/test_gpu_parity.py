@@ -1255,35 +1255,35 @@ def test_implicit_full_eig_regime_served_by_lanczos(n, seed):
 
 @pytest.mark.parametrize("n", [150, 420])
 def test_lanczos_served_full_eig_is_verified_against_the_dense_engine(n):
-    """full_eig! served by the Lanczos engine is the library's own algorithm, and single-vector
-    Lanczos returns ONE eigenvector per distinct eigenvalue.  With a repeated positive eigenvalue the engine's X+
-    loses copies; options.full_eig_lanczos_verify (auto: the first call of a block and every 128th) runs the dense
-    engine on the same input, detects it, and hands the dense result back (psd_project mode 2: fell_back = 1).
-    With a simple spectrum the check passes and the Lanczos result is kept."""
+    """full_eig! served by the Lanczos engine is the library's own algorithm; a single-vector
+    Krylov space that is DEFICIENT in an eigendirection (a repeated eigenvalue shows one copy; a start vector with no
+    component along an eigenvector never finds it) silently drops positive eigenpairs from X+.  Made exact here: a
+    diagonal matrix and a start vector with zeros at two of the positive coordinates -- those coordinates stay
+    exactly zero through every mat-vec and re-orthogonalisation, so the engine cannot see lambda = 7 and lambda = 2.
+    options.full_eig_lanczos_verify (auto: the first call of a block, then periodically) runs the dense engine on
+    the same input, detects the difference and hands the dense result back (psd_project mode 2: fell_back = 1).
+    With a generic start vector the check passes and the Lanczos result is kept."""
     rng = np.random.default_rng(n)
-    Qm, _ = np.linalg.qr(rng.standard_normal((n, n)))
-    neg = -rng.uniform(0.5, 3.0, n)
-    for name, top in (("repeated", [7.0, 7.0, 7.0, 3.0, 3.0, 1.0]), ("simple", [9.0, 7.0, 5.0, 3.0, 2.0, 1.0])):
-        lam = neg.copy()
-        lam[:len(top)] = top
-        X = (Qm * lam) @ Qm.T
-        X = (X + X.T) / 2
-        w, V = np.linalg.eigh(X)
-        ref = svec((V * np.maximum(w, 0.0)) @ V.T)
-        out, info = B.psd_project(svec(X), n, len(top), mode=2)
-        assert np.abs(out - ref).max() <= 1e-9 * np.abs(w).max(), (name, np.abs(out - ref).max())
-        assert info["rank"] == len(top) and info["min_eig"] == 0.0
-        if name == "simple":
-            assert info["fell_back"] == 0, "verification must not reject a correct Lanczos-served projection"
-        else:
-            o = B.default_options()
-            B.set_option(o, "full_eig_lanczos_verify", 0)
-            raw, info0 = B.psd_project(svec(X), n, len(top), mode=2, options=o)
-            lost = np.abs(raw - ref).max() > 1e-6
-            print(n, "repeated eigenvalues: unverified engine", "LOSES copies" if lost else "happened to find all copies",
-                  "| verified call fell back:", info["fell_back"])
-            if lost:
-                assert info["fell_back"] == 1
+    lam = -rng.uniform(0.5, 3.0, n)
+    top = [9.0, 7.0, 5.0, 3.0, 2.0, 1.0]
+    lam[:len(top)] = top
+    X = np.diag(lam)
+    ref = svec(np.diag(np.maximum(lam, 0.0)))
+    generic = rng.standard_normal(n)
+    deficient = generic.copy()
+    deficient[[1, 4]] = 0.0
+    out, info = B.psd_project(svec(X), n, len(top), mode=2, resid=generic)
+    assert np.abs(out - ref).max() <= 1e-9 * 9.0 and info["rank"] == len(top) and info["fell_back"] == 0
+    # the hazard, unverified: two positive eigenpairs are lost
+    o = B.default_options()
+    B.set_option(o, "full_eig_lanczos_verify", 0)
+    raw, info0 = B.psd_project(svec(X), n, len(top), mode=2, options=o, resid=deficient)
+    assert info0["fell_back"] == 0 and info0["rank"] == len(top) - 2
+    assert abs(np.abs(raw - ref).max() - 7.0) <= 1e-9
+    # verified (the default): the dense engine's projection is returned
+    out, info = B.psd_project(svec(X), n, len(top), mode=2, resid=deficient)
+    assert info["fell_back"] == 1 and info["rank"] == len(top) and info["min_eig"] == 0.0
+    assert np.abs(out - ref).max() <= 1e-9 * 9.0
 
 
 def test_final_rank_of_the_sign_path_is_bounded_against_the_reference_count():
