@@ -575,9 +575,14 @@ inline void Solver::setup_device() {
     if (opt.device_id < 0 || opt.device_id >= ndev) throw std::invalid_argument("device_id out of range");
     PX_HIP(hipSetDevice(opt.device_id));
     PX_HIP(hipStreamCreate(&stream.main));
-    rotate_lds_cap = (hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_lz_rotate),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) == hipSuccess)
-                         ? 144 * 1024 : 60 * 1024;
+    // gfx950: 160 KiB of LDS per CU.  The restart rotation at K = 127, keep = 78 needs 145 KiB (U tile + V tile): with 144 KiB
+    // it fell into two launches (54 us on average, profiles/r03a); take the largest grant the runtime accepts
+    rotate_lds_cap = 60 * 1024;
+    for (int kb : {160, 156, 152, 144}) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_lz_rotate),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kb * 1024) == hipSuccess) { rotate_lds_cap = kb * 1024; break; }
+        (void)hipGetLastError();
+    }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_lzb_rotate), hipFuncAttributeMaxDynamicSharedMemorySize, rotate_lds_cap);
     if (std::getenv("PROXSDP_HIP_DEBUG_CYCLE") != nullptr) { cy_dbg.alloc(16); cy_dbg.zero(stream); }
     cycle_lds_cap = 0;

@@ -708,6 +708,28 @@ def test_batched_multi_block_lanczos_equals_the_per_block_path_and_the_oracle(ki
           "| batched block-steps", sb.stats["batched_block_steps"], "| restarts", sb.stats["lanczos_restarts"])
 
 
+def test_mimo_config4_at_its_full_shape_batched_against_per_block():
+    """BASELINE config 4 at its ACTUAL shape (VERDICT r2 config note): 8 MIMO detection SDPs of n = 512 (PSD side 513,
+    263 682 box rows each: Nx = 1.05 M, Q = 2.11 M) as one block-diagonal model on one GPU.  The oracle needs ~1 s per
+    iteration here, so the checks are: the batched launches (grid.z = block) and the per-block stream path give the
+    same bits over the whole solve; OPTIMAL; and the reference's own MIMO criterion on every block
+    (test/moi_mimo.jl:71-75: every |X_ij| in (0.99, 1.01))."""
+    nb, n = 8, 512
+    pr = P.block_diag_problems([P.mimo(n, seed=s_) for s_ in range(nb)])
+    a = Optimizer(block_batch=1, time_limit=120.0, tol_gap=1e-5, tol_feasibility=1e-5).optimize(pr, trace_capacity=2000)
+    b = Optimizer(block_batch=0, time_limit=120.0, tol_gap=1e-5, tol_feasibility=1e-5).optimize(pr, trace_capacity=2000)
+    assert a.status == b.status == 1 and a.iter == b.iter
+    cols = [c for c in range(14) if c != 12]
+    assert np.array_equal(a.trace[:, cols], b.trace[:, cols])
+    assert a.stats["batched_block_steps"] > 0 and b.stats["batched_block_steps"] == 0
+    assert a.stats["lanczos_matvecs"] == b.stats["lanczos_matvecs"]
+    side = n + 1
+    L = side * (side + 1) // 2
+    for k in range(nb):
+        X = P.unpack_psd(a.primal[k * L:(k + 1) * L], side)
+        assert 0.99 < np.abs(X).min() and np.abs(X).max() < 1.01, k
+
+
 def test_support_and_dense_paths_agree_on_maxcut():
     """Max-Cut n=300, 150 iterations: the support-aware passes and the dense passes are the
     same arithmetic on the support and exact zeros elsewhere."""
