@@ -213,10 +213,12 @@ typedef struct proxsdp_options {
                                   * dots through that XCD's L2, instead of two launches per step (same arithmetic per
                                   * step; falls back to the step kernels if its bounded spins time out).  -1 auto = 0 =
                                   * off: measured gain 1.3x per step, +5 % iterations/s. */
-    int32_t lanczos_warm_start;  /* 0 (default): every projection starts from the fixed start vector, as the
+    int32_t lanczos_warm_start;  /* 0 (default): every KrylovKit projection starts from the fixed start vector, as the
                                   * reference does (krylovkit_reset_resid = false).  1: start from the normalised sum of
                                   * the previous projection's Ritz vectors (+ 1e-3 x the fixed vector).  Changes the
-                                  * Krylov space, not what is converged (krylovkit_tol). */
+                                  * Krylov space, not what is converged (krylovkit_tol).  The Lanczos-served full_eig!
+                                  * (full_eig_lanczos: the library's own engine, not KrylovKit's call) warm-starts at 0 and
+                                  * 1; -1 = fixed start vector there too. */
     int32_t reconstruct_mfma;    /* rank-r reconstruction V Lam+ V': -1 auto, 0 scalar-FMA kernel, 1 fp64 MFMA
                                   * (v_mfma_f64_16x16x4_f64) kernel */
     int32_t small_block_batch;   /* project the small PSD blocks in ONE batched Jacobi launch instead of one dense

@@ -1106,9 +1106,12 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive
     const int krylovdim = R.krylovdim;
     const double step_tol = R.step_tol;
     if (krylovdim >= 96) QlPool::get().arm();            // host eigensolve helpers wake up under the first Lanczos cycle
-    if (opt.lanczos_warm_start != 0 && !positive_part && W.fop_ok && W.have_factors && W.F_r > 0 && W.tpart.n > 0) {
-        // start from the previous projection's Ritz vectors (library-only knob; the reference starts
-        // every projection from the same fixed vector, krylovkit_reset_resid = false)
+    // start from the previous projection's Ritz vectors: on the Krylov branch only on request (library-only knob; the
+    // reference starts every projection from the same fixed vector, krylovkit_reset_resid = false); in positive-part mode
+    // (full_eig! served by this engine: the library's own algorithm, the start vector is its own choice) by default
+    // -- same X+ to krylovkit_tol, fewer restarts (lanczos_warm_start = -1 switches it off there too)
+    const bool warm_start = positive_part ? (opt.lanczos_warm_start >= 0) : (opt.lanczos_warm_start > 0);
+    if (warm_start && W.fop_ok && W.have_factors && W.F_r > 0 && W.tpart.n > 0) {
         const int nb = ceil_div(W.npad, dev::TPB);
         hipLaunchKernelGGL(dev::k_lz_warm_sum, dim3(nb), dim3(dev::TPB), 0, stream,
                            W.V.p, (const double*)(W.F.p + (size_t)W.F_first * W.npad), W.npad, W.F_r,
