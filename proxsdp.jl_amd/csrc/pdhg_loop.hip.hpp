@@ -82,7 +82,8 @@ inline bool Solver::krylov_branch(int idx) const {
 inline bool Solver::batch_eligible(int idx, bool fuse) const {
     const EigWork& W = eig[idx];
     if (opt.block_batch == 0 || !krylov_branch(idx)) return false;
-    if (opt.eigsolver == 1 || opt.psd_sign_engine == 1 || opt.lanczos_warm_start != 0 || opt.lanczos_cycle_kernel == 1)
+    if (opt.eigsolver == 1 || opt.psd_sign_engine == 1 || opt.lanczos_warm_start > 0 || opt.lanczos_cycle_kernel == 1 ||
+        opt.krylovkit_eager)
         return false;
     // operator-form blocks keep their own path (their step kernels take per-block factor ranks)
     if (fuse && use_support && opt.lanczos_operator != 0 && W.fop_ok && (W.have_factors || W.x_prev_sparse)) return false;
@@ -129,7 +130,7 @@ inline void Solver::project_block(int idx, const double* xin, double* xout, bool
     // operator-form mat-vec: legal when this block's x_prev is known in factored form (or is
     // zero off the support) and the update is the sparse support update of this iteration
     W.use_fop = !lanczos_done && fuse && use_support && opt.lanczos_operator != 0 && W.fop_ok && krylov &&
-                (W.have_factors || W.x_prev_sparse);
+                (W.have_factors || W.x_prev_sparse) && !(opt.krylovkit_eager && opt.eigsolver != 1);
     if (W.use_fop) {
         if (!W.have_factors) { W.F_r = 0; W.F_first = 0; }
         W.esv = esv_d.p + (W.have_factors ? 0 : ns);

@@ -324,6 +324,7 @@ public:
     void lz_prepare_arrow(struct LzRun& R);
     bool lz_after_cycle(EigWork& W, struct LzRun& R, bool speculated);
     void lz_finish_run(EigWork& W, struct LzRun& R);
+    void lanczos_eager(EigWork& W, const double* xp, int nev);
     void lz_merge_vectors(EigWork& W, struct LzRun& R, int ncols);
     bool lz_split_first(EigWork& W, struct LzRun& R, int k1);
     void full_eig_values(EigWork& W, const double* xp, double offscale, bool vectors, std::vector<double>& Dhost);
@@ -875,7 +876,6 @@ inline bool Solver::lz_init(EigWork& W, LzRun& R, int nev, bool positive_part) {
     R.krylovdim = krylovdim;
     R.tol = R.arpack ? opt.arpack_tol : opt.krylovkit_tol;
     R.maxiter = R.arpack ? (long long)opt.arpack_max_iter : (long long)opt.krylovkit_max_iter;
-    if (!R.arpack && opt.krylovkit_eager) throw std::invalid_argument("krylovkit_eager=true is not implemented");
     W.prev_numiter = std::max(W.numiter, 1);
     W.converged = false; W.count = 0; W.converged_eigs = 0; W.numiter = 0; W.vals.clear();
     W.lst.lanczos_calls++;
@@ -1076,6 +1076,110 @@ inline void Solver::lz_finish_run(EigWork& W, LzRun& R) {
     rotate(W, K, R.U, K, howmany, W.Z.p, -1, 0, nullptr, 0);          // Ritz vectors B*v
 }
 
+// KrylovKit's `eager = true` (options.jl:112, eigsolver.jl:809): the Rayleigh quotient is decomposed and the convergence
+// test made after EVERY expansion step once the basis holds `howmany` vectors, not only when it is full -- a projection
+// ends as soon as its wanted pairs have converged.  Off by default in the reference; here every such step is a
+// mini-cycle of the same kernels: mat-vec on the exact v_k, recurrence + full re-orthogonalisation (`first` form of
+// k_lz_orth with the coupling beta_{k-1} e_{k-1} as its "arrow"), step closing, read-back, K x K eigensolve on the
+// host.  Three launches and one synchronisation per step: a faithful, not a fast, mode.  Packed-triangle operator.
+inline void Solver::lanczos_eager(EigWork& W, const double* xp, int nev) {
+    LzRun& R = W.lzrun;
+    W.use_fop = false;
+    if (!lz_init(W, R, nev, false)) return;
+    if (R.arpack) throw std::invalid_argument("krylovkit_eager applies to eigsolver = 2 (KrylovKit) only");
+    const int kd = R.krylovdim, ld = R.ld;
+    const double tol = R.tol;
+    hipLaunchKernelGGL(dev::k_lz_begin, dim3(ceil_div(W.npad, dev::TPB)), dim3(dev::TPB), 0, stream,
+                       W.V.p, (const double*)W.resid.p, W.npad, W.ctl_p);
+    std::vector<double>& T = R.T; std::vector<double>& D = R.D; std::vector<double>& U = R.U; std::vector<double>& f = R.f;
+    std::vector<double> fstep(2 * dev::MAXK, 0.0), Dasc;
+    int K = 0, kfirst = 0, converged = 0;
+    double beta = 0.0;
+    auto launch_orth = [&](int k, int keep) {
+        const int nch = (k + 1 <= 64) ? 1 : (k + 1 <= 128) ? 2 : (k + 1 <= 192) ? 3 : 4;
+        double* hp[2] = {W.hpart1.p, W.hpart2.p};
+        dev::FopArgs fo{};
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3(W.nt), dim3(dev::TPB), 0, stream,
+                               (const double*)W.Ppart.p, W.nt, W.npad, (const double*)W.V.p, W.npad, k, W.w.p,
+                               (const double*)W.hred.p, hp[k & 1], W.pld, W.hsum1.p, (const dev::LanczosCtl*)W.ctl_p,
+                               (const double*)W.alphas_p, (const double*)W.betas_p, (const double*)W.Apart.p, W.napart, 1,
+                               (const double*)W.arrow_p, keep, fo);
+        };
+        if (nch == 1) go(dev::k_lz_orth<1, 0>); else if (nch == 2) go(dev::k_lz_orth<2, 0>);
+        else if (nch == 3) go(dev::k_lz_orth<3, 0>); else go(dev::k_lz_orth<4, 0>);
+    };
+    while (true) {
+        const int k = K;                                  // expand: v_k is an exact, normalised basis vector
+        launch_symv(W, xp, W.V.p + (size_t)k * W.npad, true);
+        int keep = kfirst;
+        if (k > kfirst) {                                 // ordinary step: w -= beta_{k-1} v_{k-1}
+            std::fill(fstep.begin(), fstep.begin() + k, 0.0);
+            fstep[k - 1] = beta;
+            W.arrow.upload(fstep.data(), (size_t)k, stream);
+            W.arrow_p = W.arrow.p;
+            keep = k;
+        }
+        launch_orth(k, keep);
+        auto klf = (k + 1 <= 64) ? dev::k_lz_finish<1> : (k + 1 <= 128) ? dev::k_lz_finish<2> : (k + 1 <= 192) ? dev::k_lz_finish<3> : dev::k_lz_finish<4>;
+        hipLaunchKernelGGL(klf, dim3(W.nt), dim3(dev::TPB), 0, stream, W.w.p, W.n, W.V.p, W.npad, k, lz_hpart(W, k), W.pld,
+                           W.hsum1.p, W.alphas_p, W.betas_p, W.ctl_p, 0.0, 0, W.hred.p);
+        PX_HIP(hipMemcpyAsync(W.rec_host, W.rec.p, EigWork::REC_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, stream));
+        PX_HIP(hipStreamSynchronize(stream));
+        const double al_k = W.rec_host[k];
+        beta = W.rec_host[dev::MAXK + k];
+        W.lst.lanczos_matvecs++; W.mv_iter++;
+        if (!(beta == beta) || !(al_k == al_k)) { R.pos_fail = true; R.K = K; break; }      // NaN guard
+        T[(size_t)k * ld + k] = al_k;
+        if (k > kfirst) { T[(size_t)(k - 1) * ld + k] = T[(size_t)k * ld + (k - 1)] = W.rec_host[dev::MAXK + k - 1]; }
+        K = k + 1;
+        if (beta <= tol && K < R.howmany) R.howmany = K;
+        if (K == kd || beta <= tol || K >= R.howmany) {
+            if (K == 1) {
+                D[0] = T[0]; U.assign(1, 1.0); f[0] = beta;
+            } else {
+                R.Tw.assign((size_t)K * K, 0.0);
+                for (int c = 0; c < K; ++c)
+                    for (int r = 0; r < K; ++r) R.Tw[(size_t)c * K + r] = T[(size_t)c * ld + r];
+                Dasc.resize(K);
+                const double te0 = now_s();
+                symeig_dense(K, R.Tw.data(), Dasc.data(), false);
+                W.lst.host_eig_time += now_s() - te0; W.lst.host_eigs++;
+                U.assign((size_t)K * K, 0.0);
+                for (int c = 0; c < K; ++c) {
+                    D[c] = Dasc[K - 1 - c];
+                    for (int r = 0; r < K; ++r) U[(size_t)c * K + r] = R.Tw[(size_t)(K - 1 - c) * K + r];
+                    f[c] = beta * U[(size_t)c * K + (K - 1)];
+                }
+            }
+            converged = 0;
+            while (converged < K && std::fabs(f[converged]) <= tol) ++converged;
+            R.K = K; R.converged = converged;
+            if (converged >= R.howmany) break;
+        }
+        if (K < kd) {
+            if (beta <= tol) { R.K = K; break; }          // invariant subspace (howmany was reduced above: not reached normally)
+            continue;
+        }
+        if (R.numiter == R.maxiter) break;
+        // thick restart, as lz_after_cycle
+        const int keepn = (3 * kd + 2 * converged) / 5;
+        for (int j = 0; j < keepn; ++j) { W.arrow_host.p[j] = f[j]; W.arrow_host.p[dev::MAXK + j] = D[j]; }
+        rotate(W, K, U, K, keepn, W.Z.p, K, keepn, W.arrow_host.p, 2 * dev::MAXK);
+        std::swap(W.V.p, W.Z.p);
+        std::fill(T.begin(), T.end(), 0.0);
+        for (int j = 0; j < keepn; ++j) {
+            T[(size_t)j * ld + j] = D[j];
+            T[(size_t)j * ld + keepn] = f[j];
+            T[(size_t)keepn * ld + j] = f[j];
+        }
+        kfirst = keepn; K = keepn;
+        ++R.numiter;
+        W.lst.lanczos_restarts++;
+    }
+    lz_finish_run(W, R);
+}
+
 // first phase of the split eigensolve, while the GPU runs the rest of the cycle: wait for the early copy of the
 // recurrence coefficients (side stream), decompose T1' = [arrow / first half] - |b| e e'
 inline bool Solver::lz_split_first(EigWork& W, LzRun& R, int k1) {
@@ -1101,6 +1205,7 @@ inline bool Solver::lz_split_first(EigWork& W, LzRun& R, int k1) {
 }
 
 inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive_part) {
+    if (opt.krylovkit_eager && opt.eigsolver != 1 && !positive_part) { lanczos_eager(W, xp, nev); return; }
     LzRun& R = W.lzrun;
     if (!lz_init(W, R, nev, positive_part)) return;
     const int krylovdim = R.krylovdim;

@@ -198,6 +198,40 @@ def test_lanczos_edge_cases():
     assert np.allclose(v1[:2], v2[:2], atol=1e-12) and i1["nmatvec"] == i2["nmatvec"]
 
 
+def test_krylovkit_eager_mode_against_oracle():
+    """krylovkit_eager = true (options.jl:112 -> KrylovKit's `eager`, eigsolver.jl:809; off by default): the
+    convergence test runs after every expansion step once `howmany` vectors exist, so a projection stops as soon as
+    its pairs have converged.  Library vs oracle: the same mat-vec and restart counts on planted spectra, the same
+    eigenvalues, and a PDHG run (Max-Cut n = 200) with identical per-iteration mat-vec counts and trace; the eager
+    run needs fewer mat-vecs than the default one."""
+    o = B.default_options()
+    B.set_option(o, "krylovkit_eager", 1)
+    for n, nev, top in [(101, 2, [40.0, 25.0, 9.0, 4.0]), (300, 6, [50.0, 40.0, 30.0, 20.0, 10.0, 9.0, 8.0])]:
+        x = planted_packed(n, 11, top, bulk=(-5.0, 1.0))
+        vals, vecs, info = B.eigsolve(x, n, nev, options=o)
+        X = smat(x, n)
+        ovals, ovecs, oconv, onumiter, onumops = oeig.krylovkit_eigsolve(
+            lambda v: X @ v, oeig.start_vector(n), nev, max(2 * nev + 1, 25), 100, 1e-12, eager=True)
+        assert info["nmatvec"] == onumops and info["numiter"] == onumiter, (n, info, onumops, onumiter)
+        k = min(len(vals), len(ovals), nev)
+        assert np.allclose(vals[:k], ovals[:k], rtol=0, atol=1e-10 * max(top))
+        assert np.allclose(vals[:k], np.sort(np.linalg.eigvalsh(X))[::-1][:k], rtol=0, atol=1e-10 * max(top))
+        vals0, _, info0 = B.eigsolve(x, n, nev)
+        assert info["nmatvec"] <= info0["nmatvec"]
+    pr = P.maxcut(200, seed=0)
+    iters = 60
+    oo = Options(); oo.max_iter = iters; oo.krylovkit_eager = True
+    omv = []
+    ref = oracle.solve(pr, oo, trace=True, proj_callback=lambda it, xi, xo, p_, arc: omv.append(int(arc[0].matvecs)))
+    per_it = np.diff(np.array([0] + omv))
+    sol = Optimizer(max_iter=iters, krylovkit_eager=1).optimize(pr, trace_capacity=iters)
+    assert sol.status == ref.status and sol.iter == ref.iter
+    assert np.array_equal(sol.trace[:, 13], per_it.astype(float)), (sol.trace[:, 13], per_it)
+    G, T = _trace_cols(ref.trace), sol.trace[:, [1, 2, 3, 4, 7, 11]]
+    assert np.array_equal(T[:, 5], G[:, 5])
+    assert np.allclose(T, G, rtol=1e-8, atol=1e-10 * np.abs(G).max())
+
+
 @pytest.mark.parametrize("case", PROJ_CASES, ids=[c[0] for c in PROJ_CASES])
 def test_psd_projection_matches_golden_and_oracle(case, golden_dir):
     name, n, seed, top, tr, full = case
