@@ -137,7 +137,10 @@ def krylovkit_eigsolve(matvec, x0, howmany, krylovdim, maxiter, tol, eager=False
     while True:
         if beta <= tol and K < howmany:
             howmany = K              # invariant subspace smaller than requested
-        if K == krylovdim or beta <= tol or (eager and K >= howmany):
+        # (eager: right after a restart KrylovKit's test sees the kept pairs with their old residuals f[:keep] --
+        # fewer than `howmany` converged, or the run would have ended before the restart -- and expands; the dense
+        # form kept here has no residual vector for that state, so the test is skipped until the next expansion)
+        if K == krylovdim or beta <= tol or (eager and K >= howmany and not coupling_set):
             if K == 1:
                 D = np.array([T[0, 0]])
                 U = np.ones((1, 1))
