@@ -114,9 +114,7 @@ struct Rank1Merge {
             for (int j = 0; j < k; ++j) zz += zn[j] * zn[j];
             org = k - 1; lo = 0.0; hi = rho * zz;                            // lambda_max <= d_max + rho |z|^2
         }
-        // start: the two-pole model with the other poles frozen at the bracket's far end / middle
-        double tau = 0.5 * (lo + hi);
-        if (last) tau = hi;
+        double tau = 0.5 * (lo + hi);                         // start in the middle of the bracket
         double f = 0.0;
         int it = 0;
         for (; it < 80; ++it) {
@@ -128,18 +126,12 @@ struct Rank1Merge {
             const double erretm = 8.0 * (std::fabs(psi) + std::fabs(phi)) + 2.0 + std::fabs(tau) * (dpsi + dphi);
             if (std::fabs(f) <= eps * erretm) break;
             if (f < 0.0) lo = tau; else hi = tau;
-            if (hi - lo <= 2.0 * eps * std::max(std::fabs(lo), std::fabs(hi))) { tau = (f < 0.0) ? hi : lo; tau = 0.5 * (lo + hi); break; }
+            if (hi - lo <= 2.0 * eps * std::max(std::fabs(lo), std::fabs(hi))) { tau = 0.5 * (lo + hi); break; }
             // middle way: psi ~ r + s / (da - lambda), phi ~ R + S / (db - lambda), value and slope matched at tau
             const double Da = (dn[ia] - dn[org]) - tau, Db = (dn[ib] - dn[org]) - tau;
-            double s, Sb, c;
-            if (!last) {
-                s = dpsi * Da * Da; Sb = dphi * Db * Db;
-                c = f - dpsi * Da - dphi * Db;
-            } else {
-                // last root: both kept poles lie to the left; phi is the single pole ib (exact), psi the rest
-                s = dpsi * Da * Da; Sb = dphi * Db * Db;
-                c = f - dpsi * Da - dphi * Db;
-            }
+            // (last root: both kept poles lie to the left of it; phi is then the single pole ib, represented exactly)
+            const double s = dpsi * Da * Da, Sb = dphi * Db * Db;
+            const double c = f - dpsi * Da - dphi * Db;
             const double bq = c * (Da + Db) + s + Sb;
             const double w = Da * Db * f;
             double eta;

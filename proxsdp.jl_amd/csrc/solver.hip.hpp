@@ -1399,9 +1399,7 @@ inline void Solver::flush_rotations(RotSink& S) {
 inline void Solver::lanczos_batch(const std::vector<int>& blocks, const double* xbase, const std::vector<int>& nevs) {
     const int nb = (int)blocks.size();
     if (nb < 1 || nb > dev::LZB_MAX) throw std::invalid_argument("lanczos_batch: 1..LZB_MAX blocks");
-    std::vector<LzRun*> Rp(nb);
-    for (int q = 0; q < nb; ++q) Rp[q] = &eig[blocks[q]].lzrun;
-    struct RunRefs { std::vector<LzRun*>& p; LzRun& operator[](int q) { return *p[q]; } } R{Rp};
+    auto Rq = [&](int q) -> LzRun& { return eig[blocks[q]].lzrun; };     // host state of block q's run (lives in its workspace)
     std::vector<char> live(nb, 0), ran(nb, 0);
     EigWork& W0 = eig[blocks[0]];
     dev::LzBatch B{};
@@ -1410,9 +1408,9 @@ inline void Solver::lanczos_batch(const std::vector<int>& blocks, const double* 
         EigWork& W = eig[blocks[q]];
         W.use_fop = false;
         W.batch_slot = q;
-        live[q] = ran[q] = lz_init(W, R[q], nevs[q], false) ? 1 : 0;
-        if (R[q].krylovdim > 63) throw std::invalid_argument("lanczos_batch: krylovdim > 63");
-        B.tol = R[q].step_tol;
+        live[q] = ran[q] = lz_init(W, Rq(q), nevs[q], false) ? 1 : 0;
+        if (Rq(q).krylovdim > 63) throw std::invalid_argument("lanczos_batch: krylovdim > 63");
+        B.tol = Rq(q).step_tol;
     }
     auto fill = [&](int q) -> dev::LzBlk& {
         EigWork& W = eig[blocks[q]];
@@ -1444,7 +1442,7 @@ inline void Solver::lanczos_batch(const std::vector<int>& blocks, const double* 
     while (true) {
         int tmax = 0, nlive = 0;
         for (int q = 0; q < nb; ++q)
-            if (live[q]) { tmax = std::max(tmax, R[q].krylovdim - R[q].kfirst); ++nlive; }
+            if (live[q]) { tmax = std::max(tmax, Rq(q).krylovdim - Rq(q).kfirst); ++nlive; }
         if (nlive == 0) break;
         for (int t = 0; t <= tmax; ++t) {
             bool any_orth = false;
@@ -1452,8 +1450,8 @@ inline void Solver::lanczos_batch(const std::vector<int>& blocks, const double* 
                 dev::LzBlk& b = fill(q);               // (V / arrow pointers change at a restart)
                 b.mode = 0;
                 if (!live[q]) continue;
-                const int k = R[q].kfirst + t, kd = R[q].krylovdim;
-                b.k = k; b.keep = R[q].kfirst;
+                const int k = Rq(q).kfirst + t, kd = Rq(q).krylovdim;
+                b.k = k; b.keep = Rq(q).kfirst;
                 b.mode = (t == 0) ? 1 : (k < kd) ? 2 : (k == kd) ? 3 : 0;
                 if (k < kd) {
                     any_orth = true;
@@ -1478,7 +1476,7 @@ inline void Solver::lanczos_batch(const std::vector<int>& blocks, const double* 
             hipLaunchKernelGGL(dev::k_lzb_mv, dim3(W0.nt + ntile, 1, nb), dim3(dev::TPB), 0, stream, B);
             if (!any_orth) continue;
             for (int q = 0; q < nb; ++q)
-                if (B.b[q].mode == 3 || (live[q] && B.b[q].k >= R[q].krylovdim)) B.b[q].mode = 0;
+                if (B.b[q].mode == 3 || (live[q] && B.b[q].k >= Rq(q).krylovdim)) B.b[q].mode = 0;
             hipLaunchKernelGGL(dev::k_lzb_orth, dim3(W0.nt, 1, nb), dim3(dev::TPB), 0, stream, B);
             st.batched_block_steps += nlive;
         }
@@ -1486,7 +1484,7 @@ inline void Solver::lanczos_batch(const std::vector<int>& blocks, const double* 
         for (int q = 0; q < nb; ++q) fill(q).mode = live[q] ? 1 : 0;
         hipLaunchKernelGGL(dev::k_lzb_gather_rec, dim3(1, 1, nb), dim3(dev::TPB), 0, stream, B, lzb_rec.p, (int)EigWork::REC_DOUBLES);
         PX_HIP(hipMemcpyAsync(lzb_rec_host.p, lzb_rec.p, (size_t)nb * EigWork::REC_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, stream));
-        for (int q = 0; q < nb; ++q) if (live[q]) lz_prepare_arrow(R[q]);
+        for (int q = 0; q < nb; ++q) if (live[q]) lz_prepare_arrow(Rq(q));
         PX_HIP(hipStreamSynchronize(stream));
         for (int q = 0; q < nb; ++q)
             if (live[q]) std::memcpy(eig[blocks[q]].rec_host, lzb_rec_host.p + (size_t)q * EigWork::REC_DOUBLES, EigWork::REC_DOUBLES * sizeof(double));
@@ -1501,7 +1499,7 @@ inline void Solver::lanczos_batch(const std::vector<int>& blocks, const double* 
         std::exception_ptr err[dev::LZB_MAX] = {};
         auto job = [&](int q) {
             if (!live[q]) return;
-            try { live[q] = lz_after_cycle(eig[blocks[q]], R[q], false) ? 1 : 0; }
+            try { live[q] = lz_after_cycle(eig[blocks[q]], Rq(q), false) ? 1 : 0; }
             catch (...) { err[q] = std::current_exception(); live[q] = 0; }
         };
         if (pool) pool->run(nb, job);
@@ -1509,7 +1507,7 @@ inline void Solver::lanczos_batch(const std::vector<int>& blocks, const double* 
         for (int q = 0; q < nb; ++q) if (err[q]) std::rethrow_exception(err[q]);
         flush_rotations(sink);                       // the restart rotations of this cycle: one upload, one launch
     }
-    for (int q = 0; q < nb; ++q) if (ran[q]) lz_finish_run(eig[blocks[q]], R[q]);
+    for (int q = 0; q < nb; ++q) if (ran[q]) lz_finish_run(eig[blocks[q]], Rq(q));
     flush_rotations(sink);                           // the Ritz vectors of every block
     st.batched_profiled_blocks += prof_blocks;       // blocks served by the event-bracketed launches (bytes = this x (8N + 16n))
 }
