@@ -385,7 +385,7 @@ def pmc_traffic(kind, n):
         rec = json.load(open(path))[kind][str(n)]
         return rec["bytes_per_launch"], "profiles/pmc_traffic.json <- " + rec["source"]
     except (OSError, KeyError, ValueError):
-        return None, "no PMC record for %s n=%d under profiles/" % (kind, n)
+        return None, "no PMC record for %s n=%s under profiles/" % (kind, n)
 
 
 def step_roofline(st, n, N, rank, krylovdim, mv_step, ms_step):
@@ -413,6 +413,9 @@ def step_roofline(st, n, N, rank, krylovdim, mv_step, ms_step):
     ach = (b_mv + b_or) / t_pair / 1e9 if t_pair > 0 else None
     return {"bound": "latency" if fop else "hbm", "kernel": kern, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": None,
+            "traffic_note": "rocprofv3 --pmc does not survive n >= 3000 solves in this image; at n = 2000 (rank 45) the two step "
+                            "launches move 4.1 + 2.6 MB by PMC (profiles/r03_pmc_traffic.md) against 16 MB for one pass over the "
+                            "packed triangle" if fop else None,
             "bytes_per_step_model": b_mv + b_or, "avg_matvec_launch_ms": ms_mv, "avg_orth_launch_ms": ms_or,
             "launches_profiled": [int(st["symv_profiled"]), int(st["orth_profiled"])],
             "launch_arithmetic": {"lanczos_steps_per_iteration": mv_step, "launches_per_step": 2,
@@ -640,10 +643,12 @@ def bench_mimo(args, torch, dist, rank, world, dev_id, backend):
             ms = st["symv_profiled_ms"] / st["symv_profiled"]
             blocks_per_launch = (st["batched_profiled_blocks"] / st["symv_profiled"]) if st["batched_profiled_blocks"] > 0 else 1.0
             byts = blocks_per_launch * (8.0 * Nb + 16.0 * side)
-            roof = {"bound": "hbm", "kernel": "k_lzb_mv (batched: grid.z = block) -- step-closing workgroups + packed-triangle "
+            traffic, tsrc = pmc_traffic("lzb_mv", "%dx%d" % (side, args.blocks))
+            roof = {"traffic_source": tsrc,
+                    "bound": "hbm", "kernel": "k_lzb_mv (batched: grid.z = block) -- step-closing workgroups + packed-triangle "
                                               "mat-vec tiles of every live block" if st["batched_block_steps"] > 0 else "k_symv_finish (one launch per block)",
                     "achieved": byts / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                    "frac": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                     "bytes_per_launch": byts, "blocks_per_launch": blocks_per_launch, "avg_launch_ms": ms,
                     "launches_profiled": int(st["symv_profiled"]),
                     "note": "%d triangles of %.2f MB: L2/Infinity-Cache resident and far too small to fill the chip -- a "
