@@ -611,6 +611,31 @@ def test_maxcut_n1000_objective_matches_oracle_solve(golden_dir):
     assert abs(sol.iter - gold["iter"]) <= 0.25 * gold["iter"]
 
 
+def test_maxcut_n2000_solve_matches_oracle_through_the_implicit_full_eig_regime(golden_dir):
+    """Max-Cut ER n = 2000 solved to tol 1e-4 with REFERENCE DEFAULT options by the oracle
+    (tests/golden/make_golden_large.py solve2000: 7098 iterations, 30 min of CPU; from iteration 6369 on target_rank
+    is 17 > max_target_rank_krylov_eigs, so its last 730 iterations are LAPACK full_eig! calls) against the
+    library, whose implicit regime is served by the Lanczos engine (verified against the sign projection): same
+    status, same rank schedule, same iteration count, objective to 1e-9 relative."""
+    gold = json.loads((golden_dir / "solve_maxcut_n2000.json").read_text())
+    pr = P.maxcut(gold["n"], seed=gold["seed"])
+    opt = Optimizer()
+    sol = opt.optimize(pr, trace_capacity=gold["iter"] + 200)
+    sched = []
+    for row in sol.trace:
+        if not sched or sched[-1][1] != int(row[10]):
+            sched.append([int(row[0]), int(row[10])])
+    print("gpu", sol.status, sol.iter, opt.objective_value(), sol.stats["full_eigs"], sol.stats["full_eigs_lanczos"],
+          sol.stats["full_eigs_lanczos_checks"], "oracle", gold["iter"], gold["objval"], gold["full_eigs"])
+    assert sol.status == gold["status"] == 1
+    assert sched == gold["rank_schedule"]
+    assert sol.iter == gold["iter"]
+    assert sol.stats["full_eigs"] == gold["full_eigs"] and sol.stats["full_eigs_lanczos"] >= gold["full_eigs"] - 5
+    assert sol.stats["full_eigs_lanczos_mismatches"] == 0
+    assert abs(opt.objective_value() - gold["objval"]) <= 1e-9 * (1 + abs(gold["objval"]))
+    assert sol.final_rank == gold["final_rank"]
+
+
 @pytest.mark.parametrize("fname,lit,tol", [("mcp124-1", -141.99, 1e-3), ("gpp124-2", 46.8623, 1e-3),
                                            ("mcp124-1", -141.99, 1e-4)])
 def test_sdplib_against_oracle(fname, lit, tol, golden_dir):

@@ -6,7 +6,7 @@ from proxsdp_jl_amd import problems as P
 from proxsdp_jl_amd.optimizer import Optimizer
 pr = P.maxcut(4000, seed=0)
 out = {}
-for kd in (30, 40, 50):
+for kd in (20, 25, 30, 40, 50):
     o = Optimizer(time_limit=200.0, full_eig_lanczos_kdim10=kd)
     s = o.optimize(pr)
     out[kd] = dict(status=s.status, iter=int(s.iter), obj=s.objval, time=s.time, matvecs=int(s.stats["lanczos_matvecs"]),
