@@ -264,7 +264,10 @@ typedef struct proxsdp_options {
     int32_t block_batch;         /* PSD blocks of equal side projected by ONE launch per Lanczos step (grid.z = block)
                                   * instead of one stream + host thread per block: -1 auto, 0 off, 1 on */
     int32_t rocsolver_warmup;    /* 1 = load rocSOLVER's code objects from a background thread at start-up (default 0) */
-    int32_t reserved_i[7];       /* zero */
+    int32_t debug_fail_iteration;/* k > 0: FAULT INJECTION for tests -- this process throws inside the PSD projection of
+                                  * iteration k (a block-sharded solve must then abort on EVERY shard after that
+                                  * iteration's scalar reduce instead of leaving the peers in a collective); 0 = never */
+    int32_t reserved_i[6];       /* zero */
     double  reserved_d[2];       /* zero */
 } proxsdp_options;
 

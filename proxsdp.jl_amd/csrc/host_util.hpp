@@ -627,7 +627,7 @@ inline const std::vector<OptEntry>& option_table() {
         PX_OPT(full_eig_lanczos_verify, OT_I32), PX_OPT(full_eig_lanczos_posres, OT_F64), PX_OPT(full_eig_lanczos_kdim10, OT_I32),
         PX_OPT(sign_small_tile_max, OT_I32), PX_OPT(host_eig_threads, OT_I32), PX_OPT(block_threads, OT_I32),
         PX_OPT(host_eig_merge, OT_I32), PX_OPT(block_batch, OT_I32),
-        PX_OPT(rocsolver_warmup, OT_I32),
+        PX_OPT(rocsolver_warmup, OT_I32), PX_OPT(debug_fail_iteration, OT_I32),
     };
     return t;
 }

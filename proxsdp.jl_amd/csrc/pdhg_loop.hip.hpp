@@ -446,7 +446,18 @@ inline void Solver::primal_step_dev() {
                            xcur, supp_d.p, MtyS_cur.p, cS_d.p, primal_step, xsave_d.p, ns, esv_d.p);
         std::fill(min_eig.begin(), min_eig.end(), 0.0);
         double t0 = now_s();
-        project_blocks(big_blocks, xcur, xnew, true);
+        // block-sharded solve: a shard whose projection fails (e.g. non-finite input) must still join this
+        // iteration's collectives, or its peers wait in them for ever: the error is kept, a flag travels with the
+        // iteration's scalar record (linesearch_residual_support), and every shard aborts after that reduce
+        if (sharded()) {
+            try {
+                if (opt.debug_fail_iteration > 0 && iter == opt.debug_fail_iteration)
+                    throw std::runtime_error("injected projection failure (options.debug_fail_iteration)");
+                project_blocks(big_blocks, xcur, xnew, true);
+            } catch (...) { shard_error = std::current_exception(); }
+        } else {
+            project_blocks(big_blocks, xcur, xnew, true);
+        }
         st.t_psd += now_s() - t0;
         if (P.sdplen < P.n)
             hipLaunchKernelGGL(dev::k_tail_copy_res, dim3(n_res_wg - tile_base.back()), dim3(dev::TPB), 0, stream,
@@ -1084,7 +1095,14 @@ inline int Solver::linesearch_residual_support() {
         for (size_t idx = 0; idx < P.blocks.size(); ++idx) below = below || target_rank[idx] < P.blocks[idx].n;
         maxs.push_back(below ? 1.0 : 0.0);                    // any block with target_rank < side
         maxs.push_back(now_s() - time0);                      // one clock for the limits
+        maxs.push_back(shard_error ? 1.0 : 0.0);              // a shard failed in this iteration's projection
+        if (shard_error)                                      // (its own partials may be garbage: keep them finite)
+            for (double& v : sums) if (!(v == v)) v = 0.0;
         reduce(sums, maxs);
+        if (maxs.back() > 0.5) {
+            if (shard_error) { std::exception_ptr e = shard_error; shard_error = nullptr; std::rethrow_exception(e); }
+            throw std::runtime_error("another shard of the block-sharded solve failed in this iteration");
+        }
         size_t si = 0, mi = 0;
         for (int c = 0; c < NC; ++c) {
             double* sc = hbscal.data() + 11 * c;

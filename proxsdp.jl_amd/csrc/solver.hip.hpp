@@ -361,6 +361,7 @@ public:
     int (*reduce_fn)(void*, double*, int32_t, double*, int32_t) = nullptr;
     void* reduce_ctx = nullptr;
     bool sharded() const { return reduce_fn != nullptr || nccl != nullptr; }
+    std::exception_ptr shard_error;                 // this shard's projection failed in the current iteration (see primal_step_dev)
     // native RCCL path (proxsdp_problem.nccl_comm): one all-gather of the packed scalar record per reduce, combined
     // on the host in rank order (the same bits on every rank); all-reduce of the coupling buffer on the stream
     ncclComm_t nccl = nullptr;

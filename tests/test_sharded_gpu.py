@@ -163,3 +163,38 @@ def test_native_rccl_collectives_one_rank():
     assert obj == ref.objval and dobj == ref.dual_objval
     assert np.array_equal(tr, ref.trace[:, [1, 2, 7, 11]])
     assert np.array_equal(primal, ref.primal)
+
+
+def _failing_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from proxsdp_jl_amd import replicas, sharded
+    dist = replicas.init("gloo", rank, world)
+    kw = dict(max_iter=300)
+    if rank == 1:
+        kw["debug_fail_iteration"] = 7            # this shard's projection throws in iteration 7
+    try:
+        sharded.solve_sharded(_coupled_model(), dist, rank, world, device_id=0, **kw)
+        q.put((rank, "returned"))
+    except B.ProxSDPHipError as e:
+        q.put((rank, str(e)))
+    dist.destroy_process_group()
+
+
+def test_a_failing_shard_makes_every_shard_abort_instead_of_hanging():
+    """if one shard throws inside its loop the others used to wait in the next collective for ever.
+    Now the failing shard keeps its exception, still joins the iteration's collectives (coupling all-reduce, scalar
+    record) with a flag in the record, and every shard aborts right after that reduce: the failing one with its own
+    error, the others with "another shard ... failed".  Fault injected through options.debug_fail_iteration."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29870 + (os.getpid() % 100)
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=300) for _ in procs)              # a hang shows up as queue.Empty here
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert "injected projection failure" in out[1], out
+    assert "another shard" in out[0], out
