@@ -1245,6 +1245,61 @@ k_reconstruct_mfma(const double* __restrict__ Z, int ldz, const double* __restri
 }
 
 // ---------------------------------------------------------------------------
+// Basis rotation out[:, c] = sum_j V[:, j] U[j, c] as fp64 MFMA tiles (round 3).  At K = 127 the scalar k_lz_rotate
+// takes 55-60 us for 63-100 columns (4-5 % of the rank-63 iteration: 1.5 rotations per iteration); it is a skinny
+// GEMM -- 64 rows x ncols x K per workgroup -- so: the workgroup's V tile (K x 64, zero padded to a multiple of 4) goes
+// to LDS once, U is staged in groups of 48 columns, wave w owns rows [16 w, 16 w + 16) of the tile and forms
+// D[c][i] = sum_j U[j][c] V[i][j] with v_mfma_f64_16x16x4_f64 (transposed like the reconstruction: a lane holds 16
+// consecutive ROWS of one output column, so the stores are 128-byte pieces of columns).  U is the compact K x ncols
+// column-major matrix the host uploads.  Same sums in a different order: results agree with the scalar kernel to rounding.
+// ---------------------------------------------------------------------------
+constexpr int RM_LDV = TILE + 16;        // LDS row stride of the V tile (as MF_LD)
+constexpr int RM_CG = 48;                // U columns staged per group (3 MFMA column blocks)
+__global__ void __launch_bounds__(TPB)
+k_lz_rotate_mfma(const double* __restrict__ V, int ldv, int K, const double* __restrict__ U, int ncols,
+                 double* __restrict__ out, int ldo, int copy_src, int copy_dst) {
+    extern __shared__ double s_mem[];
+    const int Kp = (K + 3) & ~3;
+    const int ldu = Kp + 2;
+    double* s_V = s_mem;                           // [Kp][RM_LDV]: s_V[j][row]
+    double* s_U = s_mem + (size_t)Kp * RM_LDV;     // [RM_CG][ldu]: s_U[c][j]
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int i0 = blockIdx.x * LZ_ROWS;
+    for (int j = w; j < Kp; j += NWAVE) s_V[j * RM_LDV + lane] = (j < K) ? V[(long long)j * ldv + i0 + lane] : 0.0;
+    for (int c0 = 0; c0 < ncols; c0 += RM_CG) {
+        const int cn = min(RM_CG, ncols - c0);
+        __syncthreads();                           // previous group's reads of s_U are done (and s_V is complete)
+        for (int t = threadIdx.x; t < RM_CG * Kp; t += TPB) {
+            const int c = t / Kp, j = t - c * Kp;
+            s_U[c * ldu + j] = (c < cn && j < K) ? U[(long long)(c0 + c) * K + j] : 0.0;
+        }
+        __syncthreads();
+        v4f64 acc[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc[b] = (v4f64){0.0, 0.0, 0.0, 0.0};
+        for (int q = 0; q < Kp / 4; ++q) {
+            const double bv = s_V[(4 * q + l4) * RM_LDV + w * 16 + l15];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const double av = s_U[(b * 16 + l15) * ldu + 4 * q + l4];
+                acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[b], 0, 0, 0);
+            }
+        }
+        // D[c][i]: c = b*16 + l4 + 4 reg (column of this group), i = w*16 + l15 (row of the tile)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int c = b * 16 + l4 + 4 * reg;
+                if (c < cn) out[(long long)(c0 + c) * ldo + i0 + w * 16 + l15] = acc[b][reg];
+            }
+    }
+    if (copy_src >= 0 && w == 0) out[(long long)copy_dst * ldo + i0 + lane] = V[(long long)copy_src * ldv + i0 + lane];
+}
+
+// ---------------------------------------------------------------------------
 // Batched projection of SMALL PSD blocks (2 <= n <= 64): full_eig! (prox_operators.jl:111-126) for
 // every block in ONE launch, one workgroup per block.  The reference (and the large-block path here)
 // calls a dense eigensolver per block per iteration -- on multi-block SDPLIB models (truss, control,

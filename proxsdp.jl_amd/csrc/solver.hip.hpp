@@ -446,6 +446,7 @@ private:
     std::vector<double> hscal;
     bool csr_wave = false;
     int rotate_lds_cap = 60 * 1024;           // dynamic LDS granted to k_lz_rotate (setup_device)
+    int rotate_mfma_lds_cap = 0;              // ... to k_lz_rotate_mfma
     // rows longer than LONG_ROW entries: segmented SpMV (kernels.hip.hpp k_spmv_csr_seg)
     static constexpr int LONG_ROW = 8192;
     DevBuf<int> seg_lo_d, seg_hi_d, long_row_d, long_ptr_d;
@@ -586,6 +587,11 @@ inline void Solver::setup_device() {
         (void)hipGetLastError();
     }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_lzb_rotate), hipFuncAttributeMaxDynamicSharedMemorySize, rotate_lds_cap);
+    for (int kb : {156, 152, 144, 128, 96, 64}) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_lz_rotate_mfma),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kb * 1024) == hipSuccess) { rotate_mfma_lds_cap = kb * 1024; break; }
+        (void)hipGetLastError();
+    }
     if (std::getenv("PROXSDP_HIP_DEBUG_CYCLE") != nullptr) { cy_dbg.alloc(16); cy_dbg.zero(stream); }
     cycle_lds_cap = 0;
     for (int kb : {160, 156, 152, 144, 128, 96, 64}) {
@@ -828,6 +834,16 @@ inline void Solver::rotate(EigWork& W, int K, const std::vector<double>& U, int 
     for (int q = 0; q < nextra; ++q) tmp[(size_t)K * ncols + q] = extra[q];
     W.U.upload(tmp.data(), (size_t)K * ncols + (size_t)std::max(nextra, 0), stream);
     if (nextra > 0) W.arrow_p = W.U.p + (size_t)K * ncols;
+    // fp64 MFMA form from K = 32 / 16 columns on (skinny GEMM: 55-60 us -> ~15 us at K = 127); LDS: V tile + 48-column U group
+    {
+        const int Kp = (K + 3) & ~3;
+        const size_t lds_m = ((size_t)Kp * dev::RM_LDV + (size_t)dev::RM_CG * (Kp + 2)) * sizeof(double);
+        if (K >= 32 && ncols >= 16 && (int)lds_m <= rotate_mfma_lds_cap) {
+            hipLaunchKernelGGL(dev::k_lz_rotate_mfma, dim3(W.nt), dim3(dev::TPB), lds_m, stream,
+                               (const double*)W.V.p, W.npad, K, (const double*)W.U.p, ncols, out, W.npad, copy_src, copy_dst);
+            return;
+        }
+    }
     // dynamic LDS: U chunk (K x cn) + V tile (K x 65).  gfx950 has 160 KiB of LDS per CU: the
     // kernel is allowed 144 KiB (setup_device), so a whole restart rotation is ONE launch up to
     // K = 127 (with a 60 KiB cap the V tile alone no longer fitted at K >= 116 and the loop
