@@ -579,7 +579,7 @@ inline void Solver::setup_device() {
     PX_HIP(hipSetDevice(opt.device_id));
     PX_HIP(hipStreamCreate(&stream.main));
     // gfx950: 160 KiB of LDS per CU.  The restart rotation at K = 127, keep = 78 needs 145 KiB (U tile + V tile): with 144 KiB
-    // it fell into two launches (54 us on average, profiles/r03a); take the largest grant the runtime accepts
+    // it fell into two launches (54 us on average, profiles/r03b); take the largest grant the runtime accepts
     rotate_lds_cap = 60 * 1024;
     for (int kb : {160, 156, 152, 144}) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_lz_rotate),

@@ -1152,6 +1152,43 @@ def test_randsdp_dense_matrix_on_device_lanczos_size():
     assert torch.equal(pr_d.M_dense.cpu(), torch.from_numpy(M))        # borrowed matrix untouched
 
 
+def test_randsdp_config3_at_its_full_size_dense_passes_against_torch():
+    """BASELINE config 3 at its ACTUAL size (VERDICT r2 config note): randSDP n = 2000, m = 4000 -- the coefficient
+    matrix is 4000 x 2 001 000 doubles = 64 GB, generated in HBM and borrowed by the library as a device pointer.
+    No oracle can hold it, so the two dense passes are checked against PLAIN TORCH on the same tensor: the exit
+    path's A x (slack_eq + b) against `M @ x`, and its c + A'y + G'y (dual_cone) against `M.T @ y`; plus: the
+    borrowed matrix is bit-identical afterwards, the projection ran at target rank 50 on the Lanczos path, and
+    every iteration streamed the matrix (dense_passes)."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 90 * 2 ** 30:
+        pytest.skip("needs 90 GB of free HBM")
+    n, m = 2000, 4000
+    pr = P.randsdp_device(n, m, seed=0, device="cuda:0")
+    M = pr.M_dense
+    chk0 = (float(M[::97].sum()), float(M[:, ::1013].abs().sum()))
+    iters = 12
+    sol = Optimizer(max_iter=iters, initial_target_rank=50, max_target_rank_krylov_eigs=50).optimize(pr, trace_capacity=iters)
+    assert sol.iter == iters and sol.stats["dense_passes"] >= 2 * iters and sol.stats["lanczos_matvecs"] > 0
+    assert np.all(np.isfinite(sol.trace[:, 1:7]))
+    x = torch.from_numpy(sol.primal).to("cuda:0")
+    ax = (M @ x).cpu().numpy()
+    sc = max(1.0, np.abs(ax).max())
+    assert np.abs((sol.slack_eq + pr.b) - ax).max() <= 1e-11 * sc * n              # A x, 2.0e6-term dot products
+    jj = np.repeat(np.arange(n), np.arange(1, n + 1))
+    ii = np.arange(pr.n) - jj * (jj + 1) // 2
+    w = np.where(ii == jj, 1.0, 2.0)
+    ye = torch.from_numpy(sol.dual_eq).to("cuda:0")
+    aty = (M.T @ ye).cpu().numpy() + pr.G.T @ sol.dual_in
+    lhs = sol.dual_cone * w - pr.c                                                   # = +-(A'y + G'y): the sign is the dual's convention
+    err = min(np.abs(lhs - aty).max(), np.abs(lhs + aty).max())
+    assert err <= 1e-11 * max(1.0, np.abs(aty).max()) * m
+    chk1 = (float(M[::97].sum()), float(M[:, ::1013].abs().sum()))
+    assert chk0 == chk1, "the borrowed 64 GB matrix was modified"
+    del M, x, ye
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("fname,iters", [("maxG51", 40), ("gpp500-1", 40)])
 def test_sdplib_full_eig_fallback_config(fname, iters, golden_dir):
     """BASELINE config 'SDPLIB maxG51 / gpp500-1, full-rank fallback eig path'
