@@ -253,16 +253,20 @@ typedef struct proxsdp_options {
                                   * above (default 3072, measured cross-over ~ 3500) */
     int32_t host_eig_threads;    /* helper threads of the host K x K eigensolver's rotation replay (default 0:
                                   * measured slower on the MI355X host; results are bit-identical) */
-    int32_t block_threads;       /* host worker threads driving concurrent per-block projections (one HIP stream
-                                  * per block): -1 auto = min(8, blocks), 0 = blocks in sequence */
+    int32_t block_threads;       /* host threads for several eigensolver-sized PSD blocks: worker threads driving per-block
+                                  * streams (blocks that are not batched) and the helper threads of a batched run's
+                                  * per-block restart logic (they spin only while a batched projection is in progress):
+                                  * -1 auto = min(8, blocks), 0 = none (blocks / restart logic in sequence) */
     int32_t host_eig_merge;      /* K x K Rayleigh-quotient eigensolve of the thick-restart Lanczos by SPLIT + RANK-ONE MERGE
                                   * (csrc/host_eig_merge.hpp: the arrow part / first half is decomposed while the GPU still
                                   * runs the cycle -- its coefficients are read back early on a side stream -- and only the
                                   * small tail + one secular-equation merge stay on the critical path; only the Ritz vectors
                                   * actually needed are formed): -1 auto = from krylovdim 64 on, 0 = implicit QL always,
                                   * 1 = from krylovdim 24 on.  Same decomposition to rounding (orthogonality ~1e-14). */
-    int32_t block_batch;         /* PSD blocks of equal side projected by ONE launch per Lanczos step (grid.z = block)
-                                  * instead of one stream + host thread per block: -1 auto, 0 off, 1 on */
+    int32_t block_batch;         /* PSD blocks of EQUAL side whose projections take the Krylov branch (KrylovKit mode,
+                                  * packed-triangle operator, krylovdim <= 63) advance their Lanczos recurrences in ONE
+                                  * launch per step (grid.z = block; groups of up to 8) instead of one stream + host thread
+                                  * per block: -1 auto = 1 = on, 0 = off.  Per block the arithmetic is unchanged. */
     int32_t rocsolver_warmup;    /* 1 = load rocSOLVER's code objects from a background thread at start-up (default 0) */
     int32_t debug_fail_iteration;/* k > 0: FAULT INJECTION for tests -- this process throws inside the PSD projection of
                                   * iteration k (a block-sharded solve must then abort on EVERY shard after that
