@@ -304,3 +304,30 @@ def test_split_and_rank_one_merge_eigensolver_against_lapack(K):
         assert info["nondeflated"] + info["deflated"] == K and info["max_secular_iterations"] <= 40, (name, info)
         if name == "decoupled":
             assert info["nondeflated"] == 0
+
+
+def test_julia_shim_constructs_the_problem_struct_with_every_field():
+    """julia/ProxSDPHip.jl cannot be executed here; at least its positional `Problem(...)` constructor call must
+    pass exactly one argument per field of the struct it mirrors (a field added to proxsdp_problem and to the Julia
+    struct but not to the call would be a MethodError in Julia), with index_base = 1 in the 15th position."""
+    import re
+    jl = (B.HEADER_PATH.parent.parent / "julia" / "ProxSDPHip.jl").read_text()
+    body = re.search(r"struct Problem\b.*?\n(.*?)\nend", jl, re.S).group(1)
+    nfields = len([ln for ln in body.splitlines() if re.match(r"\s*\w+::", ln)])
+    call = jl[jl.index("prob = Problem("):]
+    depth, args, cur = 0, [], ""
+    for ch in call[len("prob = Problem("):]:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            if depth == 0:
+                args.append(cur)
+                break
+            depth -= 1
+        if ch == "," and depth == 0:
+            args.append(cur); cur = ""
+        else:
+            cur += ch
+    args = [re.sub(r"#.*", "", a, flags=re.M).strip() for a in args]
+    assert len(args) == nfields == len(B.Problem._fields_), (len(args), nfields)
+    assert args[14] == "Int32(1)"                        # index_base: Julia indices are 1-based
