@@ -17,7 +17,10 @@ collective, scaling "weak"; value = total iterations of all ranks / max time.
 
 The timed window is PINNED at the metric's regime, target rank round(sqrt n) = 63
 (library-only knob initial_target_rank; Lanczos path kept by
-max_target_rank_krylov_eigs), so --steps/--warmup do not select the regime.
+max_target_rank_krylov_eigs), so --steps/--warmup do not select the regime; --settle
+(default 200, stated in config.settle_iterations) untimed iterations precede the
+warm-up inside the same solve, so that the window sits in the steady rank-63 regime
+whatever --steps/--warmup are ("cold_start_window" reports the --settle 0 window).
 
 Extra objects on the JSON line: "roofline" for the two launches of a Lanczos
 step (HIP events recorded by the library on its own stream around every 16th
@@ -26,10 +29,13 @@ launch inside the timed solve; bytes actually moved, so frac <= 1) and
 reference, which cannot run here -- on a bounded sample of the same instance at
 the same pinned rank, rank 0, N = 1 only), plus "early_iterations" (first
 iterations at rank 2..5), "packed_operator" (the reference's mat-vec operator:
-the HBM-bound kernel, with an n = 16000 HBM-resident leg), "time_to_tol" (rank
-64 knob) and "time_to_tol_default_options" (reference defaults), and
+the HBM-bound kernel, with an n = 16000 HBM-resident leg), "time_to_tol"
+(REFERENCE DEFAULT options), "time_to_tol_krylov_rank64" (Lanczos path kept to rank
+64) and "..._warm_start", each with "objective_rel_diff_vs_tight" against the pinned
+optimum of the instance (tests/golden/maxcut_n4000_tight.json), and
 "config_maxcut_n1000" (BASELINE config 2 on both sides, incl. solve to tol
-against the committed oracle solve).
+against the committed oracle solve).  cpu_baseline.parity_on_the_sample compares
+the oracle's sample iterations with the headline solve's own first iterations.
 """
 import argparse
 import json
