@@ -454,8 +454,9 @@ def _assert_trace_rows(T, G, upto, what):
         assert np.allclose(T[:upto, col], G[:upto, col], rtol=1e-7, atol=1e-12), (what, nm)
 
 
+@pytest.mark.parametrize("merge", [-1, 1], ids=["eigensolve-auto", "eigensolve-by-merge"])
 @pytest.mark.parametrize("name", ["maxcut_readme_n4", "sdplib_mcp124-1", "maxcut_er_n200_s0"])
-def test_iteration_traces_match_golden(name, golden_dir):
+def test_iteration_traces_match_golden(name, merge, golden_dir):
     """Per-iteration parity with the oracle's committed traces (fp64 both sides), THROUGH the Lanczos
     restarts.  The comparison is tight on every row up to the first iteration whose projection input
     has lambda_r == lambda_{r+1} (recorded by the fixture generator with LAPACK, `degenerate_iters`):
@@ -463,7 +464,9 @@ def test_iteration_traces_match_golden(name, golden_dir):
     inside the eigenspace (mcp124-1, iteration 53: lambda_2 = ... = lambda_6 = 36.83154802, gap
     4e-11), so two correct eigensolvers legitimately continue on different trajectories.  From that
     row on the per-iterate criterion of test_projection_parity_on_oracle_iterates applies instead
-    (same input to both projections); no sanity bounds are used."""
+    (same input to both projections); no sanity bounds are used.
+    `eigensolve-by-merge` (host_eig_merge = 1): the K x K Rayleigh-quotient eigensolves of these runs (krylovdim 25)
+    go through the split + rank-one merge path that auto mode reserves for krylovdim >= 64 -- same rows."""
     gold = json.loads((golden_dir / "traces.json").read_text())[name]
     if name == "maxcut_readme_n4":
         pr, iters = P.maxcut_readme(), 200
@@ -471,10 +474,12 @@ def test_iteration_traces_match_golden(name, golden_dir):
         pr, iters = P.sdplib(golden_dir / "sdplib" / "mcp124-1.dat-s"), 120
     else:
         pr, iters = P.maxcut(200, seed=0), 120
-    opt = Optimizer(max_iter=iters)
+    opt = Optimizer(max_iter=iters, host_eig_merge=merge)
     sol = opt.optimize(pr, trace_capacity=iters)
     rows = np.array(gold["rows"])
     assert sol.status == gold["status"] and sol.iter == gold["iter"]
+    if merge == 1 and name != "maxcut_readme_n4":
+        assert sol.stats["host_eig_merges"] > 0
     k = min(len(rows), len(sol.trace))
     assert k == len(rows)
     deg = gold["degenerate_iters"]
