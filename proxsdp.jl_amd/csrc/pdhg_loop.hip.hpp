@@ -1686,6 +1686,10 @@ inline void Solver::run() {
         cache_solution(P.c_orig);
     }
     (void)n_snap;
+    if (debug && dbg_batch[4] > 0)
+        std::fprintf(stderr, "[dbg] batched Lanczos: %.0f cycles; per cycle enqueue %.1f us, wait %.1f us, restart logic %.1f us, flush %.1f us\n",
+                     dbg_batch[4], 1e6 * dbg_batch[0] / dbg_batch[4], 1e6 * dbg_batch[1] / dbg_batch[4],
+                     1e6 * dbg_batch[2] / dbg_batch[4], 1e6 * dbg_batch[3] / dbg_batch[4]);
     res.stats = st;
 }
 

@@ -314,6 +314,7 @@ public:
     void lanczos(EigWork& W, const double* xp, int nev, bool positive_part = false);
     void lanczos_batch(const std::vector<int>& blocks, const double* xbase, const std::vector<int>& nevs);
     // batched rotations: U of every block staged in ONE pinned buffer, one upload, one launch (grid.z = block)
+    double dbg_batch[5] = {0, 0, 0, 0, 0};         // debug: enqueue | wait | restart logic | flush seconds, cycles
     RotSink* rot_sink = nullptr;
     std::unique_ptr<SpinPool> restart_pool;        // helper threads for the per-block restart logic of a batched run
     DevBuf<double> lzb_U, lzb_rec;
@@ -347,6 +348,7 @@ public:
     double test_min_eig() const { return min_eig.empty() ? 0.0 : min_eig[0]; }
     void test_spmv(bool transpose, const double* in, double* out);
 
+    bool debug = std::getenv("PROXSDP_HIP_DEBUG") != nullptr;
     proxsdp_options opt;
     proxsdp_result& res;
     double time0 = 0;               // (declared before P: initialised first)
@@ -507,7 +509,6 @@ private:
     void bump_rank(int idx);
     std::vector<double> b_host, h_host, c_host;   // current (possibly zeroed by a certificate search)
     bool have_snapshot = false;
-    bool debug = std::getenv("PROXSDP_HIP_DEBUG") != nullptr;
     // support-aware vector passes
     bool use_support = false;
     int ns = 0, rstride = 0, n_res_wg = 0;
@@ -1456,6 +1457,8 @@ inline void Solver::lanczos_batch(const std::vector<int>& blocks, const double* 
     hipLaunchKernelGGL(dev::k_lzb_begin, dim3(ceil_div(W0.npad, dev::TPB), 1, nb), dim3(dev::TPB), 0, stream, B);
     const double mv_bytes = 8.0 * (double)W0.N + 16.0 * (double)W0.n;
     long long nlaunch = 0, prof_blocks = 0;
+    double tp0 = debug ? now_s() : 0.0;                  // PROXSDP_HIP_DEBUG: host-time split of the batched run
+    auto lap = [&](double& acc) { if (debug) { const double t = now_s(); acc += t - tp0; tp0 = t; } };
     while (true) {
         int tmax = 0, nlive = 0;
         for (int q = 0; q < nb; ++q)
@@ -1502,7 +1505,9 @@ inline void Solver::lanczos_batch(const std::vector<int>& blocks, const double* 
         hipLaunchKernelGGL(dev::k_lzb_gather_rec, dim3(1, 1, nb), dim3(dev::TPB), 0, stream, B, lzb_rec.p, (int)EigWork::REC_DOUBLES);
         PX_HIP(hipMemcpyAsync(lzb_rec_host.p, lzb_rec.p, (size_t)nb * EigWork::REC_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, stream));
         for (int q = 0; q < nb; ++q) if (live[q]) lz_prepare_arrow(Rq(q));
+        lap(dbg_batch[0]);                               // enqueue (+ arrow reductions)
         PX_HIP(hipStreamSynchronize(stream));
+        lap(dbg_batch[1]);                               // waiting for the GPU
         for (int q = 0; q < nb; ++q)
             if (live[q]) std::memcpy(eig[blocks[q]].rec_host, lzb_rec_host.p + (size_t)q * EigWork::REC_DOUBLES, EigWork::REC_DOUBLES * sizeof(double));
         for (size_t sl = 0; sl < W0.ev.used; ++sl) {
@@ -1522,7 +1527,10 @@ inline void Solver::lanczos_batch(const std::vector<int>& blocks, const double* 
         if (pool) pool->run(nb, job);
         else for (int q = 0; q < nb; ++q) job(q);
         for (int q = 0; q < nb; ++q) if (err[q]) std::rethrow_exception(err[q]);
+        lap(dbg_batch[2]);                               // restart logic
         flush_rotations(sink);                       // the restart rotations of this cycle: one upload, one launch
+        lap(dbg_batch[3]);
+        dbg_batch[4] += 1.0;
     }
     for (int q = 0; q < nb; ++q) if (ran[q]) lz_finish_run(eig[blocks[q]], Rq(q));
     flush_rotations(sink);                           // the Ritz vectors of every block
