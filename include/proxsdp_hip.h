@@ -271,7 +271,11 @@ typedef struct proxsdp_options {
     int32_t debug_fail_iteration;/* k > 0: FAULT INJECTION for tests -- this process throws inside the PSD projection of
                                   * iteration k (a block-sharded solve must then abort on EVERY shard after that
                                   * iteration's scalar reduce instead of leaving the peers in a collective); 0 = never */
-    int32_t reserved_i[6];       /* zero */
+    int32_t host_wait_spin;      /* how the solver thread waits for the GPU at its per-cycle / per-iteration read-backs:
+                                  * 1 = poll hipStreamQuery (no sleep: the wake-up of a blocked wait costs tens of
+                                  * microseconds per synchronisation and leaves the core cold for the K x K eigensolve
+                                  * that follows), 0 = hipStreamSynchronize, -1 auto = 1 */
+    int32_t reserved_i[5];       /* zero */
     double  reserved_d[2];       /* zero */
 } proxsdp_options;
 

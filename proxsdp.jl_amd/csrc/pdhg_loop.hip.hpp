@@ -1144,7 +1144,7 @@ inline int Solver::linesearch_residual_support() {
                            (const double*)bpart.p, PSTRIDE, std::max(gq, gs), ismax, bscal.p, nc * 11,
                            (const double*)respart_d.p, rstride, n_res_wg, bscal.p + NC * 11);
         PX_HIP(hipMemcpyAsync(hbscal.data(), bscal.p, (NC * 11 + 2) * sizeof(double), hipMemcpyDeviceToHost, stream));
-        PX_HIP(hipStreamSynchronize(stream));
+        wait_stream();
         reduce_candidates(nc);
         for (int c = 0; c < nc; ++c) {
             ++trials;

@@ -381,6 +381,19 @@ public:
     DevBuf<double> coup_buf_d, roww_d;
     std::vector<double> coup_host;
     void reduce_coupling(double* Mx_dev);          // Mx[coupling rows] <- sum over shards
+    // wait for the solver's (or the calling block thread's) stream at a read-back on the critical path
+    void wait_stream() {
+        hipStream_t s = stream;
+        if (opt.host_wait_spin == 0) { PX_HIP(hipStreamSynchronize(s)); return; }
+        for (;;) {
+            const hipError_t e = hipStreamQuery(s);
+            if (e == hipSuccess) return;
+            if (e != hipErrorNotReady) PX_HIP(e);
+#if defined(__x86_64__)
+            _mm_pause();
+#endif
+        }
+    }
     void reduce_vec_host(std::vector<double>& v) {
         if (v.empty()) return;
         if (nccl) {                                  // (exit path: slacks of the coupling rows)
@@ -1350,7 +1363,7 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive
         PX_HIP(hipMemcpyAsync(W.rec_host, W.rec.p, EigWork::REC_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, stream));
         // host work under the GPU's cycle: the first part of the split eigensolve, or the arrow reduction of the QL path
         if (!(split_cycle && lz_split_first(W, R, k1))) lz_prepare_arrow(R);
-        PX_HIP(hipStreamSynchronize(stream));
+        wait_stream();
         if (W.cye_pending) {
             W.cye_pending = false;
             float ms = 0.f;
@@ -1506,7 +1519,7 @@ inline void Solver::lanczos_batch(const std::vector<int>& blocks, const double* 
         PX_HIP(hipMemcpyAsync(lzb_rec_host.p, lzb_rec.p, (size_t)nb * EigWork::REC_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, stream));
         for (int q = 0; q < nb; ++q) if (live[q]) lz_prepare_arrow(Rq(q));
         lap(dbg_batch[0]);                               // enqueue (+ arrow reductions)
-        PX_HIP(hipStreamSynchronize(stream));
+        wait_stream();
         lap(dbg_batch[1]);                               // waiting for the GPU
         for (int q = 0; q < nb; ++q)
             if (live[q]) std::memcpy(eig[blocks[q]].rec_host, lzb_rec_host.p + (size_t)q * EigWork::REC_DOUBLES, EigWork::REC_DOUBLES * sizeof(double));
