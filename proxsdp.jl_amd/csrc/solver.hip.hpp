@@ -173,11 +173,12 @@ struct EigWork {
     PinnedBuf rec_pinned;           // pinned mirror of `rec`
     double* rec_host = nullptr;
     static constexpr size_t REC_DOUBLES = 2 * dev::MAXK + sizeof(dev::LanczosCtl) / sizeof(double);
+    static constexpr size_t USTAGE_DOUBLES = (size_t)dev::MAXK * dev::MAXK + 2 * dev::MAXK;
     // full-eig fallback
     DevBuf<double> A, D, E;
     DevBuf<rocblas_int> info;
     std::vector<double> resid_host;
-    std::vector<double> Ustage[2];
+    PinnedBuf Ustage[2];            // pinned: the upload is a truly asynchronous copy (a pageable source makes the runtime stage and wait)
     int ustage_next = 0;
     // results of the last call
     std::vector<double> vals;
@@ -576,7 +577,8 @@ inline void Solver::alloc_eigwork(EigWork& W, int n, int max_nev) {
     W.ctl_p = reinterpret_cast<dev::LanczosCtl*>(W.rec.p + 2 * dev::MAXK);
     W.rec_pinned.alloc(EigWork::REC_DOUBLES);
     W.rec_host = W.rec_pinned.p;
-    W.U.alloc((size_t)dev::MAXK * dev::MAXK + 2 * dev::MAXK);
+    W.U.alloc(EigWork::USTAGE_DOUBLES);
+    W.Ustage[0].alloc(EigWork::USTAGE_DOUBLES); W.Ustage[1].alloc(EigWork::USTAGE_DOUBLES);
     W.arrow_p = W.arrow.p;
     W.lam.alloc(std::max(n, dev::MAXK));
     W.resid.alloc(W.npad);
@@ -838,15 +840,16 @@ inline void Solver::rotate(EigWork& W, int K, const std::vector<double>& U, int 
         for (int t = 0; t < q.nextra; ++t) q.data[(size_t)K * std::max(ncols, 0) + t] = extra[t];
         return;
     }
-    std::vector<double>& tmp = W.Ustage[W.ustage_next];
+    double* tmp = W.Ustage[W.ustage_next].p;
     W.ustage_next ^= 1;
     // `extra` (the arrow part f | D of the restarted Rayleigh quotient) rides behind U in the same
     // host-to-device copy; the kernels find it at W.arrow_p
-    tmp.resize((size_t)K * std::max(ncols, 1) + (size_t)std::max(nextra, 0));
+    if ((size_t)K * std::max(ncols, 1) + (size_t)std::max(nextra, 0) > EigWork::USTAGE_DOUBLES)
+        throw std::logic_error("rotation staging buffer too small");
     for (int c = 0; c < ncols; ++c)
         for (int j = 0; j < K; ++j) tmp[(size_t)c * K + j] = U[(size_t)c * ldu + j];
     for (int q = 0; q < nextra; ++q) tmp[(size_t)K * ncols + q] = extra[q];
-    W.U.upload(tmp.data(), (size_t)K * ncols + (size_t)std::max(nextra, 0), stream);
+    W.U.upload(tmp, (size_t)K * ncols + (size_t)std::max(nextra, 0), stream);
     if (nextra > 0) W.arrow_p = W.U.p + (size_t)K * ncols;
     // fp64 MFMA form from K = 32 / 16 columns on (skinny GEMM: 55-60 us -> ~15 us at K = 127); LDS: V tile + 48-column U group
     {
