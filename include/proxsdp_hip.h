@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PROXSDP_HIP_ABI_VERSION 6
+#define PROXSDP_HIP_ABI_VERSION 7
 
 /* error codes (negative return values) */
 #define PROXSDP_E_INVALID  (-1)   /* invalid argument / inconsistent problem data */
@@ -275,7 +275,17 @@ typedef struct proxsdp_options {
                                   * 1 = poll hipStreamQuery (no sleep: the wake-up of a blocked wait costs tens of
                                   * microseconds per synchronisation and leaves the core cold for the K x K eigensolve
                                   * that follows), 0 = hipStreamSynchronize, -1 auto = 1 */
-    int32_t reserved_i[5];       /* zero */
+    int32_t sign_start_row;      /* sign-function projection: row of the coefficient table the iteration starts at.  The
+                                  * table resolves |eigenvalues| down to 1e-10 x the spectral scale in 19 steps; the
+                                  * iterates of a solve rarely come closer to singular than 1e-5, so the iteration starts
+                                  * further down the table, TESTS the result (sum t^2 (1 - t^2) over the eigenvalues t of
+                                  * the computed sign matrix, from two Frobenius norms) and continues with the rows it
+                                  * skipped only when the test fails -- same error bound either way.
+                                  * -1 auto: adaptive per block (starts at row 8: 35 products instead of 57; moves up
+                                  * after 32 passes in a row, down after a failure); 0 = the full table, no test
+                                  * (round-2 behaviour); k > 0 = always start at row k (capped where the test stops
+                                  * resolving 1e-10) */
+    int32_t reserved_i[4];       /* zero */
     double  reserved_d[2];       /* zero */
 } proxsdp_options;
 
@@ -335,7 +345,9 @@ typedef struct proxsdp_stats {
     int64_t host_eig_merges;         /* K x K eigensolves done by split + rank-one merge (host_eig_merge); host_eig_time
                                       * then counts only their critical-path part */
     double  host_eig_overlap_time;   /* s: the part of those eigensolves done while the GPU was running the cycle */
-    int64_t reserved[5];
+    int64_t sign_short_pass;         /* sign-function projections whose shortened schedule passed its test (sign_start_row) */
+    int64_t sign_short_fail;         /* ... that failed it and continued with the skipped rows */
+    int64_t reserved[3];
 } proxsdp_stats;
 
 /* Result (structs.jl:60-81).  Arrays are caller-allocated with the stated
@@ -434,9 +446,10 @@ int proxsdp_hip_reconstruct_kernel(const double* Z, const double* lambda, int64_
                                    double* packed_out, int32_t repeat, double* ms);
 
 /* full_eig! (prox_operators.jl:111-126) of one packed block, timed: sign = 0 rocSOLVER dsyevd + reconstruction,
- * 1 = the sign-function projection (options.full_eig_sign); ms = wall time per call over `repeat` calls on
+ * 1 = the sign-function projection (options.full_eig_sign) with the default options.sign_start_row, 100 + k = the
+ * same with sign_start_row = k (100: the full table); ms = wall time per call over `repeat` calls on
  * device-resident data, out_rank = #{lambda > tol_psd} (dsyevd) / #{lambda > 0} (sign), out_products = MFMA
- * products per call */
+ * products per call (averaged over the warm-up call and the timed ones) */
 int proxsdp_hip_full_eig_kernel(const double* packed_in, int64_t n, int32_t sign, double* packed_out,
                                 int32_t repeat, double* ms, int32_t* out_rank, int64_t* out_products);
 

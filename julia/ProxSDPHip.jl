@@ -111,7 +111,9 @@ struct Stats                     # proxsdp_stats
     batched_profiled_blocks::Int64
     host_eig_merges::Int64
     host_eig_overlap_time::Float64
-    reserved::NTuple{5,Int64}
+    sign_short_pass::Int64
+    sign_short_fail::Int64
+    reserved::NTuple{3,Int64}
 end
 
 mutable struct CResult           # proxsdp_result

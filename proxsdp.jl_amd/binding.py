@@ -110,7 +110,7 @@ def _opt_fields():
     a("full_eig_lanczos_verify", i32); a("full_eig_lanczos_posres", f64); a("full_eig_lanczos_kdim10", i32)
     a("sign_small_tile_max", i32); a("host_eig_threads", i32); a("block_threads", i32)
     a("host_eig_merge", i32); a("block_batch", i32); a("rocsolver_warmup", i32); a("debug_fail_iteration", i32); a("host_wait_spin", i32)
-    a("reserved_i", i32 * 5); a("reserved_d", f64 * 2)
+    a("sign_start_row", i32); a("reserved_i", i32 * 4); a("reserved_d", f64 * 2)
     return F
 
 
@@ -135,7 +135,8 @@ class Stats(C.Structure):
                 ("full_eigs_lanczos_checks", i64), ("full_eigs_lanczos_mismatches", i64),
                 ("batched_block_steps", i64), ("rccl_reductions", i64),
                 ("batched_profiled_blocks", i64), ("host_eig_merges", i64),
-                ("host_eig_overlap_time", f64), ("reserved", i64 * 5)]
+                ("host_eig_overlap_time", f64), ("sign_short_pass", i64), ("sign_short_fail", i64),
+                ("reserved", i64 * 3)]
 
 
 class Result(C.Structure):
@@ -203,7 +204,7 @@ def lib():
     L.proxsdp_hip_rccl_unique_id.argtypes = [C.c_void_p]
     L.proxsdp_hip_rccl_comm_init.argtypes = [i32, C.c_void_p, i32, i32, C.POINTER(C.c_void_p)]
     L.proxsdp_hip_rccl_comm_destroy.argtypes = [C.c_void_p]
-    if L.proxsdp_hip_abi_version() != 6:
+    if L.proxsdp_hip_abi_version() != 7:
         raise ProxSDPHipError(-1, "ABI version mismatch")
     _lib = L
     return L
@@ -506,7 +507,8 @@ def reconstruct(Z, lam, n, repeat=0, mfma=-1):
 
 
 def full_eig_kernel(packed, n, sign=1, repeat=1):
-    """full_eig! of one packed block on device-resident data: (X+ packed, ms per call, rank, products per call)"""
+    """full_eig! of one packed block on device-resident data: (X+ packed, ms per call, rank, products per call).
+    sign: 0 rocSOLVER dsyevd, 1 sign-function projection (default sign_start_row), 100 + k: sign_start_row = k"""
     L = lib()
     xin = _f(packed)
     out = np.zeros(n * (n + 1) // 2)

@@ -1208,10 +1208,10 @@ def test_sdplib_full_eig_fallback_config(fname, iters, golden_dir):
     # an explicit full_eig_decomp = true never goes to the Lanczos engine, whatever full_eig_lanczos
     # says in auto mode (the Lanczos-served full_eig! is for the IMPLICIT regime only, see
     # test_implicit_full_eig_regime_served_by_lanczos).  full_eig_sign: 0 = rocSOLVER dsyevd + rank-r+
-    # reconstruction, 1 / auto = the sign-function projection (57 fp64 MFMA products, no eigenpairs);
+    # reconstruction, 1 / auto = the sign-function projection (fp64 MFMA products, no eigenpairs; sign_start_row = 0: 57);
     # both reproduce the oracle's LAPACK trace.
-    for fel, sign in ((0, 0), (-1, 0), (0, 1), (-1, -1)):
-        opt = Optimizer(max_iter=iters, full_eig_decomp=1, full_eig_lanczos=fel, full_eig_sign=sign)
+    for fel, sign, row in ((0, 0, -1), (-1, 0, -1), (0, 1, 0), (0, 1, -1), (-1, -1, -1)):
+        opt = Optimizer(max_iter=iters, full_eig_decomp=1, full_eig_lanczos=fel, full_eig_sign=sign, sign_start_row=row)
         sol = opt.optimize(pr, trace_capacity=iters)
         assert sol.status == ref.status == 3 and sol.iter == ref.iter == iters
         G, T = _trace_cols(ref.trace), sol.trace[:, [1, 2, 3, 4, 7, 11]]
@@ -1220,7 +1220,14 @@ def test_sdplib_full_eig_fallback_config(fname, iters, golden_dir):
         assert sol.stats["full_eigs"] == iters
         assert sol.stats["lanczos_matvecs"] == 0 and sol.stats["full_eigs_lanczos"] == 0
         assert sol.stats["full_eigs_sign"] == (iters if sign != 0 else 0)
-        assert sol.stats["sign_products"] == (57 * iters if sign != 0 else 0)
+        # the full table: 57 products per call; the shortened schedule (default): 34 when its test passes
+        # (start row 8), 63 when it fails and the skipped rows are run after all
+        short = sol.stats["sign_short_pass"] + sol.stats["sign_short_fail"]
+        if sign == 0: assert sol.stats["sign_products"] == 0 and short == 0
+        elif row == 0: assert sol.stats["sign_products"] == 57 * iters and short == 0
+        else:
+            assert short == iters and sol.stats["sign_short_pass"] >= iters // 2
+            assert 29 * iters <= sol.stats["sign_products"] <= 57 * iters
         assert sol.final_rank == ref.final_rank
 
 
@@ -1242,7 +1249,9 @@ def test_sign_function_projection_of_several_blocks_side_by_side():
         T = sol.trace[:, [1, 2, 3, 4, 7, 11]]
         assert np.array_equal(T[:, 5], G[:, 5])
         assert np.allclose(T, G, rtol=1e-6, atol=1e-8 * np.abs(G).max())
-        assert sol.stats["full_eigs_sign"] == 4 * 60 and sol.stats["sign_products"] == 57 * 4 * 60
+        assert sol.stats["full_eigs_sign"] == 4 * 60
+        assert sol.stats["sign_short_pass"] + sol.stats["sign_short_fail"] == 4 * 60      # shortened schedule, tested
+        assert sol.stats["sign_short_pass"] >= 2 * 60 and sol.stats["sign_products"] < 57 * 4 * 60
         assert sol.final_rank == ref.final_rank
 
 
@@ -1322,7 +1331,7 @@ def _spectrum_cases(n, rng):
 @pytest.mark.parametrize("n", [33, 64, 100, 257, 501, 1000])
 def test_sign_function_projection_against_lapack(n):
     """full_eig! by the matrix sign function (sign_project.hip.hpp; psd_project mode 4): X+ = (X + X sign X)/2
-    from 57 fp64 MFMA products, no eigenpairs.  Against LAPACK's projection: every |eigenvalue| >= 1e-10 ||X||
+    from fp64 MFMA products (34 .. 63, see the shortened-schedule test below), no eigenpairs.  Against LAPACK's projection: every |eigenvalue| >= 1e-10 ||X||
     is resolved, smaller ones cost at most their own size; the count of positive eigenvalues comes from
     tr S and tr S^2.  Cases: generic, low-rank positive part, a 25 % null space, repeated eigenvalues with
     tiny ones next to zero, definite matrices, the zero matrix; sides that are not multiples of 32 / 64."""
@@ -1344,6 +1353,46 @@ def test_sign_function_projection_against_lapack(n):
             assert info["rank"] == int((lam > 1e-7).sum()), name       # the exact null space counts as zero
         dense, _ = B.psd_project(svec(X), n, 1, mode=1)
         assert np.abs(out - dense).max() / sc <= 1e-9
+
+
+@pytest.mark.parametrize("n", [100, 501, 1000])
+def test_shortened_sign_schedule_is_tested_and_completed_when_the_test_fails(n):
+    """options.sign_start_row: the sign iteration starts at row 8 of its coefficient table (34 products instead of
+    57), which resolves |eigenvalues| >= 1.1e-5 s (s = the spectral scale (sum lambda^4)^(1/4)); the result is then
+    TESTED (sum t^2 (1 - t^2) over the eigenvalues t of the computed sign matrix) and the skipped rows are run only
+    when the test fails.  Spectra: (a) nothing below 1e-3 s -> 34 products; (b) a symmetric PAIR +-1e-7 s (every
+    odd trace functional cancels on it) and (c) a single +3e-10 s: below what row 8 resolves, above the 1e-10 s the
+    full table resolves -> the test must fail, the run is completed (63 products) and the result is as accurate as
+    the full table's; (d) +-3e-12 s and an exact null direction: below what ANY schedule resolves -> the test passes,
+    the error stays below 1e-10 s.  Every case against LAPACK and against the full table (sign_start_row = 0)."""
+    rng = np.random.default_rng(100 + n)
+    Qm, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    base = rng.standard_normal(n) * 3.0
+    base[np.abs(base) < 0.1] = 0.5                                   # nothing small by accident
+    s0 = float((base ** 4).sum() ** 0.25)
+    cases = {"clear": (base.copy(), True)}
+    lam = base.copy(); lam[0], lam[1] = 1e-7 * s0, -1e-7 * s0
+    cases["pair_1e-7"] = (lam, False)
+    lam = base.copy(); lam[0] = 3e-10 * s0
+    cases["single_3e-10"] = (lam, False)
+    lam = base.copy(); lam[0], lam[1], lam[2] = 3e-12 * s0, -3e-12 * s0, 0.0
+    cases["harmless"] = (lam, True)
+    for name, (lam, passes) in cases.items():
+        X = (Qm * lam) @ Qm.T
+        X = (X + X.T) / 2
+        w, V = np.linalg.eigh(X)
+        ref = svec((V * np.maximum(w, 0.0)) @ V.T)
+        sc = float((w ** 4).sum() ** 0.25)
+        full, _, rk_full, p_full = B.full_eig_kernel(svec(X), n, sign=100, repeat=1)
+        short, _, rk_short, p_short = B.full_eig_kernel(svec(X), n, sign=108, repeat=1)
+        print(f"n={n} {name}: products full {p_full} short {p_short} | err full {np.abs(full - ref).max() / sc:.2e} "
+              f"short {np.abs(short - ref).max() / sc:.2e}")
+        assert p_full == 57
+        assert p_short == (34 if passes else 63), name
+        assert np.abs(full - ref).max() <= 1e-10 * sc, name
+        assert np.abs(short - ref).max() <= 1e-10 * sc, name
+        if name != "harmless":
+            assert rk_short == rk_full == int((w > 0).sum()), name
 
 
 @pytest.mark.parametrize("n,seed", [(420, 1), (1000, 0)])
