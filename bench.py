@@ -294,7 +294,8 @@ def main():
 
     if solo and not args.no_time_to_tol:
         # full_eig! regime at the metric's size (what the reference falls into with default options once
-        # target_rank > 16): sign-function projection (57 fp64 MFMA products) vs rocSOLVER dsyevd, 12 iterations each
+        # target_rank > 16): sign-function projection (34 fp64 MFMA products when its shortened schedule passes its test, 64 when
+        # not; 57 with sign_start_row = 0) vs rocSOLVER dsyevd, 12 iterations each
         def fe_leg(sign):
             o3 = Optimizer(max_iter=12, device_id=dev_id, full_eig_decomp=1, full_eig_sign=sign, profile_symv_every=1)
             s3 = o3.optimize(pr, trace_capacity=12)
@@ -506,7 +507,8 @@ def bench_randsdp(args, torch, dist, rank, world, dev_id, backend):
 def bench_sdplib(args, torch, dist, rank, world, dev_id, backend):
     """BASELINE config 5: SDPLIB maxG51 / gpp500-1 (test/base_sdplib.jl model) on the FULL-RANK
     fallback eig path, full_eig_decomp = true: every iteration is full_eig! (prox_operators.jl:111-126) =
-    by default the sign-function projection (57 fp64 MFMA products, sign_project.hip.hpp); beside it the
+    by default the sign-function projection (34 fp64 MFMA products per call when the shortened schedule passes its
+    test -- options.sign_start_row --, sign_project.hip.hpp); beside it the
     dense eigensolver (rocSOLVER dsyevd) + rank-r+ reconstruction (full_eig_sign = 0).
     Single PSD block: replicas for N > 1.  value = iterations/s of maxG51; gpp500-1 beside it."""
     from proxsdp_jl_amd import problems, replicas
@@ -543,6 +545,7 @@ def bench_sdplib(args, torch, dist, rank, world, dev_id, backend):
             ach = flops / (eig_ms * 1e-3) / 1e12 if eig_ms > 0 else None
             out.update({"projection": "matrix sign function, fp64 MFMA products (full_eig_sign auto)",
                         "projection_ms_per_step": eig_ms, "products_per_projection": nprod,
+                        "shortened_schedule_passed": int(st["sign_short_pass"]), "shortened_schedule_failed": int(st["sign_short_fail"]),
                         "avg_product_launch_ms": eig_ms / nprod if nprod else None,
                         "projection_share": eig_ms / (1e3 * t / K),
                         "dsyevd_equivalent_TFLOPs": (10.0 / 3.0) * n ** 3 / (eig_ms * 1e-3) / 1e12 if eig_ms > 0 else None,

@@ -1221,7 +1221,7 @@ def test_sdplib_full_eig_fallback_config(fname, iters, golden_dir):
         assert sol.stats["lanczos_matvecs"] == 0 and sol.stats["full_eigs_lanczos"] == 0
         assert sol.stats["full_eigs_sign"] == (iters if sign != 0 else 0)
         # the full table: 57 products per call; the shortened schedule (default): 34 when its test passes
-        # (start row 8), 63 when it fails and the skipped rows are run after all
+        # (start row 8), 64 when it fails and the skipped rows are run after all
         short = sol.stats["sign_short_pass"] + sol.stats["sign_short_fail"]
         if sign == 0: assert sol.stats["sign_products"] == 0 and short == 0
         elif row == 0: assert sol.stats["sign_products"] == 57 * iters and short == 0
@@ -1331,7 +1331,7 @@ def _spectrum_cases(n, rng):
 @pytest.mark.parametrize("n", [33, 64, 100, 257, 501, 1000])
 def test_sign_function_projection_against_lapack(n):
     """full_eig! by the matrix sign function (sign_project.hip.hpp; psd_project mode 4): X+ = (X + X sign X)/2
-    from fp64 MFMA products (34 .. 63, see the shortened-schedule test below), no eigenpairs.  Against LAPACK's projection: every |eigenvalue| >= 1e-10 ||X||
+    from fp64 MFMA products (34 .. 64, see the shortened-schedule test below), no eigenpairs.  Against LAPACK's projection: every |eigenvalue| >= 1e-10 ||X||
     is resolved, smaller ones cost at most their own size; the count of positive eigenvalues comes from
     tr S and tr S^2.  Cases: generic, low-rank positive part, a 25 % null space, repeated eigenvalues with
     tiny ones next to zero, definite matrices, the zero matrix; sides that are not multiples of 32 / 64."""
@@ -1362,7 +1362,7 @@ def test_shortened_sign_schedule_is_tested_and_completed_when_the_test_fails(n):
     TESTED (sum t^2 (1 - t^2) over the eigenvalues t of the computed sign matrix) and the skipped rows are run only
     when the test fails.  Spectra: (a) nothing below 1e-3 s -> 34 products; (b) a symmetric PAIR +-1e-7 s (every
     odd trace functional cancels on it) and (c) a single +3e-10 s: below what row 8 resolves, above the 1e-10 s the
-    full table resolves -> the test must fail, the run is completed (63 products) and the result is as accurate as
+    full table resolves -> the test must fail, the run is completed (64 products: the final product, enqueued ahead of the test, runs twice) and the result is as accurate as
     the full table's; (d) +-3e-12 s and an exact null direction: below what ANY schedule resolves -> the test passes,
     the error stays below 1e-10 s.  Every case against LAPACK and against the full table (sign_start_row = 0)."""
     rng = np.random.default_rng(100 + n)
@@ -1388,7 +1388,7 @@ def test_shortened_sign_schedule_is_tested_and_completed_when_the_test_fails(n):
         print(f"n={n} {name}: products full {p_full} short {p_short} | err full {np.abs(full - ref).max() / sc:.2e} "
               f"short {np.abs(short - ref).max() / sc:.2e}")
         assert p_full == 57
-        assert p_short == (34 if passes else 63), name
+        assert p_short == (34 if passes else 64), name
         assert np.abs(full - ref).max() <= 1e-10 * sc, name
         assert np.abs(short - ref).max() <= 1e-10 * sc, name
         if name != "harmless":
