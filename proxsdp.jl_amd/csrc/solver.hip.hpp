@@ -302,6 +302,7 @@ public:
             if (W.stream) (void)hipStreamDestroy(W.stream);
             if (W.ev_mid) (void)hipEventDestroy(W.ev_mid);
             if (W.ev_early) (void)hipEventDestroy(W.ev_early);
+            if (W.sg_ev) (void)hipEventDestroy(W.sg_ev);
             if (W.side) (void)hipStreamDestroy(W.side);
         }
         if (ev_main) (void)hipEventDestroy(ev_main);

@@ -1,6 +1,8 @@
 """Round-3 probe: the solve to tolerance of the metric instance (rank-64 knob) with the K x K eigensolve split from
-krylovdim 64 (default) and from 24 (host_eig_merge = 1), after the read-backs of the Lanczos record and of the
-iteration's scalars became stores into pinned host memory (no copy command on the critical path)."""
+krylovdim 64 (default) and from 24 (host_eig_merge = 1).  Used for two experiments: (1) read-backs of the Lanczos
+record and of the iteration's scalars as kernel stores into pinned host memory instead of copy commands -- measured
+neutral (A/B on one box: 7.27 / 7.10 s against 7.16 / 7.13 s), not kept; (2) the restart rotation's upload from
+PINNED staging buffers instead of a pageable vector -- kept (7.34 / 7.47 -> 7.16 / 7.13 s)."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from proxsdp_jl_amd import problems as P
