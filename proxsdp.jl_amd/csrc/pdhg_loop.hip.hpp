@@ -500,14 +500,23 @@ inline int Solver::linesearch() {
                            (long long)P.n, part.p + PSTRIDE, 1);
         hipLaunchKernelGGL(dev::k_combine, dim3(1), dim3(dev::TPB), 0, stream,
                            part.p, PSTRIDE, PSTRIDE, 2, 0u, scal.p);
-        scal.download(hscal.data(), 2, stream);
-        PX_HIP(hipStreamSynchronize(stream));
+        // the residual / gap reductions of THIS candidate ride behind its trial (pure reductions over the candidate's
+        // y and M'y): when it is the accepted one -- the common case -- residual_and_gap finds its nine scalars in the
+        // same read-back and the iteration has one synchronisation less; a rejected candidate's are ignored
+        enqueue_residual(primal_step, beta * primal_step);
+        if (hscal_pin.p == nullptr) hscal_pin.alloc(16);
+        PX_HIP(hipMemcpyAsync(hscal_pin.p, scal.p, 11 * sizeof(double), hipMemcpyDeviceToHost, stream));
+        wait_stream();
+        std::copy(hscal_pin.p, hscal_pin.p + 11, hscal.begin());
+        residual_ready = true;
         const double y_norm = std::sqrt(hscal[0]), Mty_norm = std::sqrt(hscal[1]);
         if (debug && iter <= 5 && trials <= 6)
             std::fprintf(stderr, "[dbg] it %lld trial %d tau %.6e theta %.6e y_norm %.6e Mty_norm %.6e\n",
                          iter, trials, primal_step, theta, y_norm, Mty_norm);
         if (std::sqrt(beta) * primal_step * Mty_norm <= opt.delta * y_norm) break;
         primal_step *= opt.linsearch_decay;
+        residual_ready = false;                  // (also when the loop ends on its trial limit: the reference then
+                                                 //  continues with the DECAYED step and the last candidate's y)
     }
     primal_step_old = primal_step;
     dual_step = beta * primal_step;
@@ -534,25 +543,34 @@ inline void Solver::dual_step_plain() {
 
 // compute_residual! + compute_gap! (residuals.jl:2-71), then the *_old rotation
 // (:65-68) as index flips instead of four vector copies
-inline void Solver::residual_and_gap() {
+inline void Solver::enqueue_residual(double pstep, double dstep) {
     const int gq = std::min(PSTRIDE, grid_for(std::max<int64_t>(P.Q, 1)));
     const int gx = std::min(PSTRIDE, grid_for(P.n));
     const double xold_coef = (iter == 1 && opt.advanced_initialization) ? 0.0 : 1.0;   // x_old = 0 at k = 1
     hipLaunchKernelGGL(dev::k_residual_x, dim3(gx), dim3(dev::TPB), 0, stream,
                        xbuf[1 - xc].p, xbuf[xc].p, xold_coef, Mtybuf[1 - mtyc].p, Mtybuf[mtyc].p, c_d.p,
-                       primal_step, (long long)P.n, part.p + 2 * PSTRIDE);
+                       pstep, (long long)P.n, part.p + 2 * PSTRIDE);
     // k_residual_x writes 3 quantities with stride gridDim; re-stride into the common layout
     // by launching with exactly PSTRIDE-strided output: handled by passing gridDim == gx and
     // combining with stride gx (see k_combine call below).
     hipLaunchKernelGGL(dev::k_residual_y, dim3(gq), dim3(dev::TPB), 0, stream,
                        ybuf[1 - yc].p, ybuf[yc].p, Mxbuf[1 - mxc].p, Mxbuf[mxc].p, bh_d.p, (int)P.p, (int)P.Q,
-                       dual_step, part.p + 5 * PSTRIDE);
+                       dstep, part.p + 5 * PSTRIDE);
     hipLaunchKernelGGL(dev::k_combine, dim3(1), dim3(dev::TPB), 0, stream,
                        part.p + 2 * PSTRIDE, gx, gx, 3, 0x3u, scal.p + 2);
     hipLaunchKernelGGL(dev::k_combine, dim3(1), dim3(dev::TPB), 0, stream,
                        part.p + 5 * PSTRIDE, gq, gq, 6, 0xFu, scal.p + 5);
-    PX_HIP(hipMemcpyAsync(hscal.data() + 2, scal.p + 2, 9 * sizeof(double), hipMemcpyDeviceToHost, stream));
-    PX_HIP(hipStreamSynchronize(stream));
+}
+
+inline void Solver::residual_and_gap() {
+    if (!residual_ready) {
+        enqueue_residual(primal_step, dual_step);
+        if (hscal_pin.p == nullptr) hscal_pin.alloc(16);
+        PX_HIP(hipMemcpyAsync(hscal_pin.p + 2, scal.p + 2, 9 * sizeof(double), hipMemcpyDeviceToHost, stream));
+        wait_stream();
+        std::copy(hscal_pin.p + 2, hscal_pin.p + 11, hscal.begin() + 2);
+    }
+    residual_ready = false;
     const double* s = hscal.data() + 2;
     if (debug && iter <= 5)
         std::fprintf(stderr, "[dbg] it %lld res: %.6e %.6e cx %.6e | %.6e %.6e eq %.6e in %.6e by %.6e hy %.6e\n",

@@ -559,6 +559,9 @@ private:
     void dense_ev_end();
     void dense_ev_harvest();
     std::vector<double> hbscal;
+    PinnedBuf hscal_pin;            // read-back of the general path's scalars (linesearch norms | residual / gap sums)
+    bool residual_ready = false;    // the accepted linesearch candidate's residual scalars are already in hscal
+    void enqueue_residual(double pstep, double dstep);
 };
 
 // ------------------------------------------------------------------ setup
