@@ -285,7 +285,12 @@ typedef struct proxsdp_options {
                                   * after 32 passes in a row, down after a failure); 0 = the full table, no test
                                   * (round-2 behaviour); k > 0 = always start at row k (capped where the test stops
                                   * resolving 1e-10) */
-    int32_t reserved_i[4];       /* zero */
+    int32_t general_batch;       /* models without a support set (full-vector passes, sparse M): linesearch candidates,
+                                  * residual and gap in one batch of launches and ONE read-back per iteration (up to 3
+                                  * candidates evaluated side by side, the first the reference's loop would accept wins;
+                                  * per candidate the same arithmetic): -1 auto = 1 = on, 0 = one trial per
+                                  * synchronisation (round-2 path) */
+    int32_t reserved_i[3];       /* zero */
     double  reserved_d[2];       /* zero */
 } proxsdp_options;
 

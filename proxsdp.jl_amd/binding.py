@@ -110,7 +110,7 @@ def _opt_fields():
     a("full_eig_lanczos_verify", i32); a("full_eig_lanczos_posres", f64); a("full_eig_lanczos_kdim10", i32)
     a("sign_small_tile_max", i32); a("host_eig_threads", i32); a("block_threads", i32)
     a("host_eig_merge", i32); a("block_batch", i32); a("rocsolver_warmup", i32); a("debug_fail_iteration", i32); a("host_wait_spin", i32)
-    a("sign_start_row", i32); a("reserved_i", i32 * 4); a("reserved_d", f64 * 2)
+    a("sign_start_row", i32); a("general_batch", i32); a("reserved_i", i32 * 3); a("reserved_d", f64 * 2)
     return F
 
 

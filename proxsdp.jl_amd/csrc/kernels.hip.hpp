@@ -1834,6 +1834,75 @@ k_residual_xy_batch(const double* __restrict__ xnew, const int* __restrict__ sup
                         part + 5 * (long long)pstride, pstride, cstride, gq, sm, roww);
 }
 
+// The same batch on the GENERAL path (no support set: full-vector passes).  Mty_c = M' y_c for every candidate
+// + |Mty_c - Mty_old|^2 partials: per candidate the arithmetic of k_spmv_csc_norm (addback form).
+__global__ void __launch_bounds__(TPB)
+k_spmv_csc_norm_batch(const int* __restrict__ colptr, const int* __restrict__ row, const double* __restrict__ val,
+                      const double* __restrict__ ycand, long long ystride, double* __restrict__ Mtycand, long long mstride,
+                      const double* __restrict__ Mty_old, long long ncols, double* __restrict__ part, long long cstride) {
+    __shared__ double sm[NWAVE];
+    const int c = blockIdx.y;
+    const double* y = ycand + (long long)c * ystride;
+    double* out = Mtycand + (long long)c * mstride;
+    double ss = 0.0;
+    long long j = (long long)blockIdx.x * TPB + threadIdx.x;
+    const long long stride = (long long)gridDim.x * TPB;
+    for (; j < ncols; j += stride) {
+        double acc = 0.0;
+        const int k0 = colptr[j], k1 = colptr[j + 1];
+        for (int k = k0; k < k1; ++k) acc += val[k] * y[row[k]];
+        const double o = Mty_old[j];
+        const double d = acc - o;
+        out[j] = d + o;                        // pdhg.jl:560,574
+        ss += d * d;
+    }
+    const double tot = block_sum(ss, sm);
+    if (threadIdx.x == 0) part[(long long)c * cstride + blockIdx.x] = tot;
+}
+// x part of compute_residual! + c.x over the whole vector, per candidate (the arithmetic of k_residual_x);
+// part[c][q][wg], q = 0: max |dPx|  1: max |Px_old|  2: sum c*x
+__device__ __forceinline__ void
+residual_x_full_body(const double* __restrict__ x, const double* __restrict__ xold, double xold_coef,
+                     const double* __restrict__ Mtycand, long long mstride, const double* __restrict__ Mty_old,
+                     const double* __restrict__ cv, long long N, const TrialBatch& tb, double* __restrict__ part,
+                     int pstride, long long cstride, int gx, double* __restrict__ sm) {
+    if ((int)blockIdx.x >= gx) return;
+    const int c = blockIdx.y;
+    const double tau = tb.tau[c];
+    const double* Mty = Mtycand + (long long)c * mstride;
+    double m0 = 0.0, m1 = 0.0, s2 = 0.0;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < N; i += (long long)gx * TPB) {
+        const double xi = x[i];
+        const double pold = xold_coef * xold[i] - tau * Mty_old[i];
+        const double pnew = xi - tau * Mty[i];
+        m0 = fmax(m0, fabs(pnew - pold));
+        m1 = fmax(m1, fabs(pold));
+        s2 += cv[i] * xi;
+    }
+    const double r0 = block_max(m0, sm), r1 = block_max(m1, sm), r2 = block_sum(s2, sm);
+    if (threadIdx.x == 0) {
+        double* pp = part + (long long)c * cstride;
+        pp[blockIdx.x] = r0; pp[pstride + blockIdx.x] = r1; pp[2 * pstride + blockIdx.x] = r2;
+    }
+}
+// grid (max(gx, gq), nc, 2): z = 0 the x part over the whole vector, z = 1 the y part
+__global__ void __launch_bounds__(TPB)
+k_residual_xy_full_batch(const double* __restrict__ x, const double* __restrict__ xold, double xold_coef,
+                         const double* __restrict__ Mtycand, long long mstride, const double* __restrict__ Mty_old,
+                         const double* __restrict__ cv, long long N, int gx,
+                         const double* __restrict__ ycand, long long ystride, const double* __restrict__ yold,
+                         const double* __restrict__ Mx, const double* __restrict__ Mx_old,
+                         const double* __restrict__ bh, int p, int Q, int gq,
+                         TrialBatch tb, double* __restrict__ part, int pstride, long long cstride) {
+    __shared__ double sm[NWAVE];
+    if (blockIdx.z == 0)
+        residual_x_full_body(x, xold, xold_coef, Mtycand, mstride, Mty_old, cv, N, tb,
+                             part + 2 * (long long)pstride, pstride, cstride, gx, sm);
+    else
+        residual_y_body(ycand, ystride, yold, Mx, Mx_old, bh, p, Q, tb,
+                        part + 5 * (long long)pstride, pstride, cstride, gq, sm, nullptr);
+}
+
 // non-PSD tail of x (SOC + free variables): x_new = x_trial copied to the other buffer,
 // with the off-support residual terms (as in the fused reconstruction)
 __global__ void __launch_bounds__(TPB)

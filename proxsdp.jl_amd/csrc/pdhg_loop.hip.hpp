@@ -504,7 +504,7 @@ inline int Solver::linesearch() {
         // y and M'y): when it is the accepted one -- the common case -- residual_and_gap finds its nine scalars in the
         // same read-back and the iteration has one synchronisation less; a rejected candidate's are ignored
         enqueue_residual(primal_step, beta * primal_step);
-        if (hscal_pin.p == nullptr) hscal_pin.alloc(16);
+        if (hscal_pin.p == nullptr) hscal_pin.alloc(64);
         PX_HIP(hipMemcpyAsync(hscal_pin.p, scal.p, 11 * sizeof(double), hipMemcpyDeviceToHost, stream));
         wait_stream();
         std::copy(hscal_pin.p, hscal_pin.p + 11, hscal.begin());
@@ -565,7 +565,7 @@ inline void Solver::enqueue_residual(double pstep, double dstep) {
 inline void Solver::residual_and_gap() {
     if (!residual_ready) {
         enqueue_residual(primal_step, dual_step);
-        if (hscal_pin.p == nullptr) hscal_pin.alloc(16);
+        if (hscal_pin.p == nullptr) hscal_pin.alloc(64);
         PX_HIP(hipMemcpyAsync(hscal_pin.p + 2, scal.p + 2, 9 * sizeof(double), hipMemcpyDeviceToHost, stream));
         wait_stream();
         std::copy(hscal_pin.p + 2, hscal_pin.p + 11, hscal.begin() + 2);
@@ -1231,6 +1231,127 @@ inline int Solver::linesearch_residual_support() {
     return trials;
 }
 
+// linesearch! + compute_residual! + compute_gap! on the GENERAL path (no support set, sparse M): the structure of
+// linesearch_residual_support with full-vector kernels -- up to 3 consecutive candidates per batch, ONE read-back,
+// the first candidate the reference's loop would have accepted wins.  Per candidate the arithmetic is that of
+// linesearch() / residual_and_gap() (same kernels' bodies, same partial layout and combine order): identical scalars.
+inline int Solver::linesearch_residual_general() {
+    constexpr int NC = 3;
+    const int gq = std::min(PSTRIDE, grid_for(std::max<int64_t>(P.Q, 1)));
+    const int gx = std::min(PSTRIDE, grid_for(P.n));
+    const long long cstride = 11LL * PSTRIDE;
+    const long long ystride = std::max<int64_t>(P.Q, 1), mstride = P.n;
+    const double xold_coef = (iter == 1 && opt.advanced_initialization) ? 0.0 : 1.0;
+    if (Mtycand_d.n < (size_t)NC * P.n) {
+        Mtycand_d.alloc((size_t)NC * P.n);
+        ycand_d.alloc((size_t)4 * std::max<int64_t>(P.Q, 1));
+        bpart.alloc((size_t)4 * 11 * PSTRIDE); bpart.zero(stream);
+        bscal.alloc(64); bscal.zero(stream);
+        hbscal.assign(64, 0.0);
+        if (hscal_pin.p == nullptr) hscal_pin.alloc(64);
+    }
+    primal_step = primal_step * std::sqrt(1.0 + theta);
+    int trials = 0;
+    bool accepted = false;
+    const double* s_acc = nullptr;
+    auto residual_batch = [&](const dev::TrialBatch& tb, int nc, int c0) {
+        hipLaunchKernelGGL(dev::k_residual_xy_full_batch, dim3(std::max(gx, gq), nc, 2), dim3(dev::TPB), 0, stream,
+                           xbuf[1 - xc].p, xbuf[xc].p, xold_coef, Mtycand_d.p + (size_t)c0 * mstride, mstride, Mtybuf[mtyc].p,
+                           c_d.p, (long long)P.n, gx,
+                           ycand_d.p + (size_t)c0 * ystride, ystride, ybuf[yc].p, Mxbuf[1 - mxc].p, Mxbuf[mxc].p,
+                           bh_d.p, (int)P.p, (int)P.Q, gq, tb, bpart.p, PSTRIDE, cstride);
+    };
+    auto read_back = [&](int nc) {
+        unsigned long long ismax = 0;
+        for (int c = 0; c < nc; ++c) ismax |= 0x1ECull << (11 * c);      // bits 2,3,5,6,7,8 of every candidate
+        hipLaunchKernelGGL(dev::k_combine_multi, dim3(nc * 11), dim3(dev::TPB), 0, stream,
+                           (const double*)bpart.p, PSTRIDE, std::max(gq, gx), ismax, bscal.p, nc * 11,
+                           (const double*)nullptr, 0, 0, (double*)nullptr);
+        PX_HIP(hipMemcpyAsync(hscal_pin.p, bscal.p, NC * 11 * sizeof(double), hipMemcpyDeviceToHost, stream));
+        wait_stream();
+        std::copy(hscal_pin.p, hscal_pin.p + NC * 11, hbscal.begin());
+    };
+    while (!accepted && trials < opt.max_linsearch_steps) {
+        dev::TrialBatch tb{};
+        double tau_c = primal_step;
+        int nc = 0;
+        for (; nc < NC && trials + nc < opt.max_linsearch_steps; ++nc) {
+            tb.tau[nc] = tau_c;
+            tb.theta[nc] = tau_c / primal_step_old;
+            tb.bt[nc] = beta * tau_c;
+            tb.sigma[nc] = beta * tau_c;
+            tau_c *= opt.linsearch_decay;
+        }
+        tb.nc = nc;
+        hipLaunchKernelGGL(dev::k_dual_trial_batch, dim3(gq, nc), dim3(dev::TPB), 0, stream,
+                           ybuf[yc].p, Mxbuf[1 - mxc].p, Mxbuf[mxc].p, bh_d.p, (int)P.p, (int)P.Q, tb,
+                           ycand_d.p, ystride, bpart.p, cstride, (const double*)nullptr);
+        hipLaunchKernelGGL(dev::k_spmv_csc_norm_batch, dim3(gx, nc), dim3(dev::TPB), 0, stream,
+                           csc_ptr.p, csc_row.p, csc_val.p, ycand_d.p, ystride, Mtycand_d.p, mstride, Mtybuf[mtyc].p,
+                           (long long)P.n, bpart.p + PSTRIDE, cstride);
+        residual_batch(tb, nc, 0);
+        read_back(nc);
+        for (int c = 0; c < nc; ++c) {
+            ++trials;
+            const double* sc = hbscal.data() + 11 * c;
+            primal_step = tb.tau[c];
+            theta = tb.theta[c];
+            const double y_norm = std::sqrt(sc[0]), Mty_norm = std::sqrt(sc[1]);
+            if (debug && iter <= 5 && trials <= 6)
+                std::fprintf(stderr, "[dbg] it %lld trial %d tau %.6e theta %.6e y_norm %.6e Mty_norm %.6e\n",
+                             iter, trials, primal_step, theta, y_norm, Mty_norm);
+            const bool ok = std::sqrt(beta) * primal_step * Mty_norm <= opt.delta * y_norm;
+            const bool last = trials >= opt.max_linsearch_steps;
+            if (ok || last) {
+                accepted = true;
+                s_acc = sc;
+                if (!ok) {
+                    // reference quirk (pdhg.jl:545-569): trial limit reached -> the step is decayed once more while the
+                    // last trial's y / Mty are kept; the residual scalars are re-evaluated with THAT step (rare path)
+                    primal_step *= opt.linsearch_decay;
+                    dev::TrialBatch t1{};
+                    t1.nc = 1; t1.tau[0] = primal_step; t1.theta[0] = theta; t1.bt[0] = beta * primal_step;
+                    t1.sigma[0] = beta * primal_step;
+                    residual_batch(t1, 1, c);
+                    read_back(1);
+                    // (candidate c's two norms, slots 0 and 1, are not needed any more)
+                    s_acc = hbscal.data();
+                }
+                hipLaunchKernelGGL(dev::k_copy2, dim3(grid_for((long long)P.Q + P.n)), dim3(dev::TPB), 0, stream,
+                                   ybuf[1 - yc].p, (const double*)(ycand_d.p + (size_t)c * ystride), (long long)P.Q,
+                                   Mtybuf[1 - mtyc].p, (const double*)(Mtycand_d.p + (size_t)c * mstride), (long long)P.n);
+                break;
+            }
+            primal_step = tb.tau[c] * opt.linsearch_decay;
+        }
+    }
+    primal_step_old = primal_step;
+    dual_step = beta * primal_step;
+    st.linesearch_trials += trials;
+    // ---- residuals and gap from the accepted candidate's scalars (residual_and_gap)
+    const double* s = s_acc + 2;
+    if (debug && iter <= 5)
+        std::fprintf(stderr, "[dbg] it %lld res: %.6e %.6e cx %.6e | %.6e %.6e eq %.6e in %.6e by %.6e hy %.6e\n",
+                     iter, s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], s[8]);
+    const double pres = std::sqrt(g_n) * s[0] / std::max({s[1], g_norm_b, g_norm_h, 1.0});
+    const double dres = std::sqrt(g_Q) * s[3] / std::max({s[4], g_norm_c, 1.0});
+    h_pres.at(iter) = pres;
+    h_dres.at(iter) = dres;
+    h_comb.at(iter) = std::max(pres, dres);
+    if (P.p > 0) equa_feasibility = s[5] / (1.0 + g_norm_b);
+    if (P.m > 0) ineq_feasibility = s[6] / (1.0 + g_norm_h);
+    h_feas.at(iter) = std::max(equa_feasibility, ineq_feasibility);
+    const double po = s[2];
+    double d_o = 0.0;
+    if (P.p > 0) d_o -= s[7];
+    if (P.m > 0) d_o -= s[8];
+    h_pobj.at(iter) = po;
+    h_dobj.at(iter) = d_o;
+    h_gap.at(iter) = std::fabs(po - d_o) / (1.0 + std::fabs(po) + std::fabs(d_o));
+    xc = 1 - xc; mtyc = 1 - mtyc; yc = 1 - yc; mxc = 1 - mxc;
+    return trials;
+}
+
 // ---- hooks for the kernel-level test entry points
 inline void Solver::test_project(int idx, double* xp, int tr) {
     target_rank.assign(1, tr); current_rank.assign(1, 0); min_eig.assign(1, 0.0);
@@ -1480,12 +1601,17 @@ inline void Solver::run() {
             last_trials = linesearch_residual_support();
             st.t_linesearch += now_s() - tl0;
         } else {
+            if (opt.line_search_flag && !P.dense() && !sharded() && opt.general_batch != 0) {
+                last_trials = linesearch_residual_general();       // trials + residual + gap in one batch and one read-back
+                st.t_linesearch += now_s() - tl0;
+            } else {
             if (opt.line_search_flag) last_trials = P.dense() ? linesearch_dense() : linesearch();
             else { dual_step_plain(); last_trials = 1; }
             const double tl1 = now_s();
             residual_and_gap();
             st.t_linesearch += tl1 - tl0;
             st.t_residual += now_s() - tl1;
+            }
         }
         {   // algorithmic bytes of this iteration
             const double t = (double)last_trials;

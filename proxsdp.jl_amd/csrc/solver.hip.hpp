@@ -510,6 +510,7 @@ private:
     bool batch_eligible(int idx, bool fuse) const;
     void setup_support();
     int  linesearch_residual_support();
+    int  linesearch_residual_general();
     void setup_dense();
     int  linesearch_dense();
     void dense_mv(const double* x, double* y, bool scaled);

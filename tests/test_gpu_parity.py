@@ -1499,6 +1499,36 @@ def test_mimo_dense_vector_path_against_oracle():
     assert sol.stats["lanczos_matvecs"] > 0
 
 
+@pytest.mark.parametrize("case", ["mimo", "mixed_cones", "gpp124-2", "maxcut_dense_passes", "trial_limit"])
+def test_general_path_batched_linesearch_is_bit_identical_to_one_trial_per_synchronisation(case, golden_dir):
+    """options.general_batch: on models without a support set (full-vector passes) up to three linesearch candidates,
+    their residual and gap reductions are evaluated in one batch of launches with ONE read-back per iteration; per
+    candidate the arithmetic is that of the one-trial-at-a-time path (general_batch = 0), so every trace column --
+    trial counts included -- must be IDENTICAL, not close.  Cases: MIMO (box rows on every entry), a mixed-cone
+    model (SOC + PSD + LP rows), SDPLIB gpp124-2 with full_eig! every iteration (all-ones row: full support),
+    Max-Cut forced onto the dense passes, and max_linsearch_steps = 2 (the reference's trial-limit quirk:
+    the step is decayed once more and the residual re-evaluated with it)."""
+    kw, iters = {}, 120
+    if case == "mimo":
+        pr = P.mimo(60, seed=2)
+    elif case == "mixed_cones":
+        pr = mixed_cones(3)
+    elif case == "gpp124-2":
+        pr = P.sdplib(golden_dir / "sdplib" / "gpp124-2.dat-s"); kw = dict(full_eig_decomp=1)
+    elif case == "maxcut_dense_passes":
+        pr = P.maxcut(150, seed=5); kw = dict(support_path=0)
+    else:
+        pr = P.mimo(40, seed=7); kw = dict(max_linsearch_steps=2)
+    a = Optimizer(max_iter=iters, general_batch=0, **kw).optimize(pr, trace_capacity=iters)
+    b = Optimizer(max_iter=iters, **kw).optimize(pr, trace_capacity=iters)
+    assert a.status == b.status and a.iter == b.iter
+    cols = [c for c in range(a.trace.shape[1]) if c != 12]            # (12 = elapsed seconds)
+    assert np.array_equal(a.trace[:, cols], b.trace[:, cols])
+    assert a.objval == b.objval and np.array_equal(a.primal, b.primal) and np.array_equal(a.dual_eq, b.dual_eq)
+    if case == "trial_limit":
+        assert a.trace[:, 11].max() == 2
+
+
 def test_maxcut_n1000_reaches_tolerance():
     """BASELINE config 1 (Max-Cut ER n=1000, single PSD cone): converges to the solver's
     own tolerances; the solution is feasible and PSD; weak duality holds."""
