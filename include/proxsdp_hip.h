@@ -37,6 +37,8 @@
 extern "C" {
 #endif
 
+/* 7 (round 3): proxsdp_options gained sign_start_row and general_batch (taken from reserved_i), proxsdp_stats gained
+ * sign_short_pass / sign_short_fail (taken from reserved): same struct sizes and offsets as version 6 */
 #define PROXSDP_HIP_ABI_VERSION 7
 
 /* error codes (negative return values) */
