@@ -283,8 +283,8 @@ typedef struct proxsdp_options {
                                   * further down the table, TESTS the result (sum t^2 (1 - t^2) over the eigenvalues t of
                                   * the computed sign matrix, from two Frobenius norms) and continues with the rows it
                                   * skipped only when the test fails -- same error bound either way.
-                                  * -1 auto: adaptive per block (starts at row 8: 35 products instead of 57; moves up
-                                  * after 32 passes in a row, down after a failure); 0 = the full table, no test
+                                  * -1 auto: adaptive per block (starts at row 8: 34 products instead of 57; a failure
+                                  * sends the next 8 projections two rows down, a second one soon after lowers the row for good); 0 = the full table, no test
                                   * (round-2 behaviour); k > 0 = always start at row k (capped where the test stops
                                   * resolving 1e-10) */
     int32_t general_batch;       /* models without a support set (full-vector passes, sparse M): linesearch candidates,
