@@ -13,7 +13,9 @@ in the build container, results committed as numbers only):
   solve_maxcut_n2000.json   Max-Cut ER n=2000, seed 0, solved to tol 1e-4 with reference default options
                             (hours of CPU: past target rank 16 every iteration is a LAPACK full_eig!)
 
-Run from the repo root:  python tests/golden/make_golden_large.py [trace4000] [solve1000] [trace4000r63] [solve2000]
+  solve_maxG51_full_eig.json  BASELINE config 5: SDPLIB maxG51 with full_eig_decomp = true solved to tol 1e-4 (round 3)
+
+Run from the repo root:  python tests/golden/make_golden_large.py [trace4000] [solve1000] [trace4000r63] [solve2000] [solvemaxg51]
 The inputs are regenerated from the seed by the tests through the same generator
 (proxsdp_jl_amd.problems.maxcut)."""
 import json
@@ -110,8 +112,27 @@ def solve2000():
     print("solve2000", r.status, r.iter, r.objval, r.dual_objval, r.gap, time.time() - t0)
 
 
+def solve_maxg51():
+    """BASELINE config 5 by the oracle: SDPLIB maxG51 (n = 1000) with full_eig_decomp = true (every projection is LAPACK's
+    full_eig!), tol 1e-4: status, iterations, objective, dual objective, gap, final rank + every 50th trace row."""
+    pr = P.sdplib(OUT / "sdplib" / "maxG51.dat-s")
+    o = Options()
+    o.full_eig_decomp = True
+    o.time_limit = 6 * 3600.0
+    t0 = time.time()
+    r = oracle.solve(pr, o, trace=True)
+    rows = rows_of(r)
+    (OUT / "solve_maxG51_full_eig.json").write_text(json.dumps(dict(
+        instance="maxG51", full_eig_decomp=True, tol=1e-4, status=r.status, iter=r.iter, objval=r.objval,
+        dual_objval=r.dual_objval, gap=r.gap, final_rank=int(r.final_rank), full_eigs=int(r.stats["full_eigs"]),
+        rows_every_50=rows[49::50], last_row=rows[-1], wall_s=time.time() - t0)))
+    print("solve_maxg51", r.status, r.iter, r.objval, r.dual_objval, r.gap, time.time() - t0)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["trace4000", "solve1000"]
+    if "solvemaxg51" in which:
+        solve_maxg51()
     if "trace4000" in which:
         trace4000()
     if "solve1000" in which:

@@ -616,6 +616,36 @@ def test_maxcut_n1000_objective_matches_oracle_solve(golden_dir):
     assert abs(sol.iter - gold["iter"]) <= 0.25 * gold["iter"]
 
 
+@pytest.mark.parametrize("row", [-1, 0])
+def test_config5_maxG51_solved_to_tolerance_takes_the_oracles_iterations(row, golden_dir):
+    """BASELINE config 5 at its own size, solved by BOTH sides: SDPLIB maxG51 (n = 1000) with full_eig_decomp = true,
+    tol 1e-4.  The oracle (LAPACK full_eig! every iteration; ~15 min of CPU, tests/golden/make_golden_large.py
+    solvemaxg51) and the library's sign-function projection -- on its shortened, tested schedule (default) and on the
+    full table (sign_start_row = 0) -- must stop at the SAME iteration with the same objective, and every 50th trace
+    row along the way must agree: a projection error of 1e-10 of the spectral scale per iteration does not move a
+    1933-iteration trajectory off LAPACK's."""
+    gold = json.loads((golden_dir / "solve_maxG51_full_eig.json").read_text())
+    pr = P.sdplib(golden_dir / "sdplib" / "maxG51.dat-s")
+    opt = Optimizer(full_eig_decomp=1, sign_start_row=row)
+    sol = opt.optimize(pr, trace_capacity=gold["iter"] + 10)
+    print("gpu", sol.status, sol.iter, sol.objval, "oracle", gold["status"], gold["iter"], gold["objval"],
+          "short pass/fail", sol.stats["sign_short_pass"], sol.stats["sign_short_fail"])
+    assert sol.status == gold["status"] == 1
+    assert sol.iter == gold["iter"]
+    assert abs(sol.objval - gold["objval"]) <= 1e-8 * abs(gold["objval"])
+    assert abs(sol.dual_objval - gold["dual_objval"]) <= 1e-8 * abs(gold["dual_objval"])
+    assert sol.final_rank == gold["final_rank"]
+    G = np.array(gold["rows_every_50"])
+    T = sol.trace[49::50, :12][:len(G)]
+    assert np.array_equal(T[:, [0, 10, 11]], G[:, [0, 10, 11]])                 # iteration, target rank, linesearch trials
+    assert np.allclose(T[:, 1:10], G[:, 1:10], rtol=1e-6, atol=1e-9 * np.abs(G[:, 1:3]).max())
+    assert sol.stats["full_eigs_sign"] == sol.iter
+    if row == 0:
+        assert sol.stats["sign_products"] == 57 * sol.iter
+    else:
+        assert sol.stats["sign_short_pass"] >= 0.98 * sol.iter
+
+
 def test_maxcut_n2000_solve_matches_oracle_through_the_implicit_full_eig_regime(golden_dir):
     """Max-Cut ER n = 2000 solved to tol 1e-4 with REFERENCE DEFAULT options by the oracle
     (tests/golden/make_golden_large.py solve2000: 7098 iterations, 30 min of CPU; from iteration 6369 on target_rank
