@@ -616,6 +616,33 @@ def test_maxcut_n1000_objective_matches_oracle_solve(golden_dir):
     assert abs(sol.iter - gold["iter"]) <= 0.25 * gold["iter"]
 
 
+def test_config4_mimo_8x512_solved_to_tolerance_against_the_oracle_solve(golden_dir):
+    """BASELINE config 4 at its own shape, solved by BOTH sides: eight MIMO detection SDPs (n = 512: PSD side 513,
+    box rows on every entry) as one block-diagonal model, reference default options, tol 1e-4.  The oracle's solve
+    (35 s of CPU; tests/golden/solve_mimo_n512_x8.json, generated by the script in its `generator` field) against the
+    library's batched multi-block Lanczos on the general vector path: same status and iteration count, the same
+    linesearch trial counts, traces to 1e-6 up to where the degenerate iterates (repeated eigenvalues, DESIGN.md
+    section 6) let rounding through, objective within the solver's tolerance."""
+    gold = json.loads((golden_dir / "solve_mimo_n512_x8.json").read_text())
+    pr = P.block_diag_problems([P.mimo(512, seed=s_) for s_ in range(8)], name="mimo-x8")
+    sol = Optimizer().optimize(pr, trace_capacity=gold["iter"] + 20)
+    G = np.array(gold["rows"])
+    T = sol.trace[:, :12]
+    print("gpu", sol.status, sol.iter, sol.objval, sol.stats["lanczos_matvecs"], "oracle", gold["status"], gold["iter"],
+          gold["objval"], gold["matvecs"])
+    assert sol.status == gold["status"] == 1
+    assert abs(sol.iter - gold["iter"]) <= 0.25 * gold["iter"]
+    assert abs(sol.objval - gold["objval"]) <= 1e-4 * (1 + abs(gold["objval"]))
+    assert sol.stats["batched_block_steps"] > 0
+    m = min(len(T), len(G))
+    close = np.all(np.isclose(T[:m, 1:8], G[:m, 1:8], rtol=1e-6, atol=1e-9), axis=1) & (T[:m, 11] == G[:m, 11])
+    first_off = int(np.argmin(close)) if not close.all() else m
+    print("traces agree (1e-6, trial counts) for the first", first_off, "of", m, "iterations")
+    assert first_off >= 20
+    if sol.iter == gold["iter"]:
+        assert abs(sol.stats["lanczos_matvecs"] - gold["matvecs"]) <= 0.05 * gold["matvecs"]
+
+
 @pytest.mark.parametrize("row", [-1, 0])
 def test_config5_maxG51_solved_to_tolerance_takes_the_oracles_iterations(row, golden_dir):
     """BASELINE config 5 at its own size, solved by BOTH sides: SDPLIB maxG51 (n = 1000) with full_eig_decomp = true,
