@@ -1229,6 +1229,32 @@ def test_randsdp_dense_matrix_entry_matches_sparse_and_oracle():
     assert np.allclose(s_d.trace[:60, [1, 2, 3, 4, 7, 11]], G[:60], rtol=1e-7, atol=1e-10)
 
 
+def test_randsdp_config3_cpu_comparable_size_matches_oracle_trace(golden_dir):
+    """BASELINE config 3 at the size SURVEY.md section 8 calls CPU-comparable: randSDP n = 500, m = 1000 (dense A:
+    1000 x 125 250 doubles = 1 GB), seed 0, reference default options.  The oracle's first 200 iterations
+    (tests/golden/make_golden_randsdp500.py) against the library on its dense-A path (M_dense, streamed twice per
+    iteration) and on the CSC path fed the same numbers: identical linesearch trials and Lanczos mat-vec counts,
+    traces to 1e-7 over the first 60 iterations and to 1e-4 over all 200."""
+    gold = json.loads((golden_dir / "trace_randsdp_n500_m1000.json").read_text())
+    G = np.array(gold["rows"]); gm = np.array(gold["matvecs"])
+    iters = len(G)
+    for dense in (True, False):
+        pr = P.randsdp(gold["n"], gold["m"], seed=gold["seed"], dense=dense)
+        sol = Optimizer(max_iter=iters).optimize(pr, trace_capacity=iters)
+        T = sol.trace[:, :12]
+        assert sol.iter == iters
+        assert np.array_equal(T[:, 11], G[:, 11]), "linesearch trials"
+        assert np.array_equal(T[:, 10], G[:, 10]), "target rank"
+        same = sol.trace[:, 13] == gm
+        print("dense" if dense else "csc", "mat-vec counts equal in", int(same.sum()), "of", iters)
+        assert same.mean() >= 0.95
+        sc = np.abs(G[:, 1:8]).max(axis=0)
+        assert np.allclose(T[:60, 1:8], G[:60, 1:8], rtol=1e-7, atol=1e-10 * sc)
+        assert np.allclose(T[:, 1:8], G[:, 1:8], rtol=1e-4, atol=1e-6 * sc)
+        if dense:
+            assert sol.stats["dense_passes"] >= 2 * iters
+
+
 def test_randsdp_dense_matrix_on_device_lanczos_size():
     """M_dense as a DEVICE pointer (generated on the GPU, as the 64 GB BASELINE size must be),
     n = 150 so the Lanczos path runs; checked against the CSC path fed the same numbers and
