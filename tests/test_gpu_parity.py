@@ -711,6 +711,30 @@ def test_config5_maxG51_solved_to_tolerance_takes_the_oracles_iterations(row, go
         assert sol.stats["sign_short_pass"] >= 0.98 * sol.iter
 
 
+@pytest.mark.parametrize("name", ["mcp250-1", "mcp500-1", "maxG11"])
+def test_sdplib_full_eig_solves_take_the_oracles_iterations(name, golden_dir):
+    """The regime of BASELINE config 5 (full_eig_decomp = true: every projection is full_eig!) on three more SDPLIB
+    instances (Max-Cut family; the gpp instances need > 100 000 full_eig! iterations), solved to tol 1e-4 by the oracle (LAPACK; tests/golden/make_golden_full_eig.py) and by the library's
+    sign-function projection on its shortened, tested schedule: same status, the same iteration count, objective to
+    1e-7 relative, every 50th trace row to 1e-5."""
+    gold = json.loads((golden_dir / "solve_sdplib_full_eig.json").read_text())
+    if name not in gold:
+        pytest.skip(f"{name} not in the committed fixture")
+    g = gold[name]
+    pr = P.sdplib(golden_dir / "sdplib" / f"{name}.dat-s")
+    sol = Optimizer(full_eig_decomp=1, time_limit=600.0).optimize(pr, trace_capacity=g["iter"] + 10)
+    print(name, "gpu", sol.status, sol.iter, sol.objval, "oracle", g["status"], g["iter"], g["objval"],
+          "short pass/fail", sol.stats["sign_short_pass"], sol.stats["sign_short_fail"])
+    assert sol.status == g["status"]
+    assert sol.iter == g["iter"]
+    assert abs(sol.objval - g["objval"]) <= 1e-7 * (1 + abs(g["objval"]))
+    G = np.array(g["rows_every_50"])
+    if len(G):
+        T = sol.trace[49::50, :12][:len(G)]
+        assert np.array_equal(T[:, [0, 10, 11]], G[:, [0, 10, 11]])
+        assert np.allclose(T[:, 1:10], G[:, 1:10], rtol=1e-5, atol=1e-8 * np.abs(G[:, 1:3]).max())
+
+
 def test_maxcut_n2000_solve_matches_oracle_through_the_implicit_full_eig_regime(golden_dir):
     """Max-Cut ER n = 2000 solved to tol 1e-4 with REFERENCE DEFAULT options by the oracle
     (tests/golden/make_golden_large.py solve2000: 7098 iterations, 30 min of CPU; from iteration 6369 on target_rank
