@@ -14,6 +14,10 @@ The problem is uploaded before the loop starts (inputs resident in HBM).
 N > 1: the single-PSD-block path does not shard (SURVEY.md section 8e,
 DESIGN.md section 7) -> N independent replicas (seed = rank), no data-path
 collective, scaling "weak"; value = total iterations of all ranks / max time.
+`python bench.py --gpus N` with no launcher in the environment starts the N
+ranks itself (torch.distributed.run, rendezvous on 127.0.0.1); under a launcher
+WORLD_SIZE must equal --gpus, anything else is an error.  `--workload mimo
+--gpus N` is the block-sharded solve with the library's own RCCL collectives.
 
 The timed window is PINNED at the metric's regime, target rank round(sqrt n) = 63
 (library-only knob initial_target_rank; Lanczos path kept by
@@ -34,7 +38,9 @@ the HBM-bound kernel, with an n = 16000 HBM-resident leg), "time_to_tol"
 64) and "..._warm_start", each with "objective_rel_diff_vs_tight" against the pinned
 optimum of the instance (tests/golden/maxcut_n4000_tight.json), and
 "config_maxcut_n1000" (BASELINE config 2 on both sides, incl. solve to tol
-against the committed oracle solve).  cpu_baseline.parity_on_the_sample compares
+against the committed oracle solve), and compact legs of BASELINE configs 3 / 4 / 5
+("config_randsdp", "config_mimo_x8", "config_sdplib": what `--workload ...` runs,
+shorter windows, each with its roofline and cpu_baseline or the reason it has none).  cpu_baseline.parity_on_the_sample compares
 the oracle's sample iterations with the headline solve's own first iterations.
 """
 import argparse
@@ -108,12 +114,27 @@ def main():
     ap.add_argument("--rand-m", type=int, default=4000)
     ap.add_argument("--blocks", type=int, default=8)
     ap.add_argument("--mimo-n", type=int, default=512)
+    ap.add_argument("--no-config-legs", action="store_true",
+                    help="skip the compact legs of BASELINE configs 3 / 4 / 5 (config_randsdp, config_mimo_x8, config_sdplib) "
+                         "that ride in the default line")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU, the same
+        # command line the driver would use for N > 1) and hand over to them
+        return spawn_ranks(args.gpus)
 
     import torch
     from proxsdp_jl_amd import binding, problems, replicas
     from proxsdp_jl_amd.optimizer import Optimizer
     rank, local_rank, world = replicas.rank_info()
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE = %d: launch with `python bench.py --gpus N` (spawns the ranks "
+                         "itself) or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world))
+    if os.environ.get("PROXSDP_BENCH_DRYRUN") == "1":
+        return dry_run(args, replicas, rank, world)
     dist = None
     backend = os.environ.get("PROXSDP_BENCH_BACKEND", "nccl")       # "gloo" only for 1-GPU validation runs
     ndev = max(1, torch.cuda.device_count())
@@ -126,12 +147,14 @@ def main():
 
     if binding.device_count() <= 0:
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    if args.workload == "mimo":
-        return bench_mimo(args, torch, dist, rank, world, dev_id, backend)
-    if args.workload == "randsdp":
-        return bench_randsdp(args, torch, dist, rank, world, dev_id, backend)
-    if args.workload == "sdplib":
-        return bench_sdplib(args, torch, dist, rank, world, dev_id, backend)
+    if args.workload != "maxcut":
+        leg = {"mimo": bench_mimo, "randsdp": bench_randsdp, "sdplib": bench_sdplib}[args.workload]
+        line = leg(args, torch, dist, rank, world, dev_id, backend)
+        if rank == 0:
+            print(json.dumps(line))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     n = args.n
     K, W0 = args.steps, args.warmup
     W = W0 + max(0, args.settle)                    # settle + warm-up iterations, all untimed
@@ -367,10 +390,75 @@ def main():
                 "cpu_oracle_committed": {"status": gj["status"], "iterations": gj["iter"], "objective": gj["objval"],
                                          "time_s_build_container_8_cores": gj["wall_s"]},
                 "objective_rel_diff": abs(g3o.objective_value() - gj["objval"]) / (1 + abs(gj["objval"]))}
+    if solo and not args.no_config_legs:
+        # BASELINE configs 3 / 4 / 5, compact: the same legs `--workload randsdp|mimo|sdplib` run, shorter windows, each with
+        # its own roofline and cpu_baseline (or the reason it has none)
+        t_legs = time.time()
+        cpu_s = min(args.cpu_seconds, 8.0)
+        try:
+            out["config_sdplib"] = compact(bench_sdplib(sub_args(args, steps=60, warmup=10, no_rocsolver_leg=True, cpu_seconds=cpu_s),
+                                                        torch, None, 0, 1, dev_id, backend))
+            out["config_mimo_x8"] = compact(bench_mimo(sub_args(args, steps=40, warmup=10, cpu_seconds=cpu_s, support_path=-1),
+                                                       torch, None, 0, 1, dev_id, backend))
+            free_b, _ = torch.cuda.mem_get_info(dev_id)
+            need = 8.0 * args.rand_m * (args.rand_n * (args.rand_n + 1) // 2) * 1.12
+            if free_b > need:
+                out["config_randsdp"] = compact(bench_randsdp(sub_args(args, steps=10, warmup=3), torch, None, 0, 1, dev_id, backend))
+            else:
+                out["config_randsdp"] = {"skipped": "needs %.0f GB of free HBM, %.0f GB free" % (need / 1e9, free_b / 1e9)}
+        except Exception as e:                                  # a side leg must not take the headline line with it
+            out["config_legs_error"] = "%s: %s" % (type(e).__name__, e)
+        out["config_legs_wall_s"] = time.time() - t_legs
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def compact(line):
+    """a side leg's line without the fields that only repeat the enclosing line"""
+    for k in ("higher_is_better", "vs_baseline", "scaling", "n_gpus"):
+        line.pop(k, None)
+    return line
+
+
+def spawn_ranks(n):
+    """re-execute this command under torch.distributed.run with one rank per GPU (rendezvous on 127.0.0.1)"""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        raise SystemExit("bench.py --gpus %d: the ranks exited with code %d" % (n, rc))
+
+
+def dry_run(args, replicas, rank, world):
+    """PROXSDP_BENCH_DRYRUN=1: the rank plumbing of a run WITHOUT the solve (CPU test of `--gpus N`: process group,
+    barrier, MAX-over-ranks time, SUM of units, rank 0 prints) -- never a measurement, and it says so."""
+    dist = None
+    if world > 1:
+        dist = replicas.init(os.environ.get("PROXSDP_BENCH_BACKEND", "nccl"), rank, world)
+        dist.barrier()
+    steps, secs = replicas.aggregate(dist, args.steps, 1.0 + rank)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "metric": "none (dry run: no solve)", "value": None, "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "units_all_ranks": steps, "max_seconds": secs, "workload": args.workload}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def sub_args(args, **kw):
+    a = argparse.Namespace(**vars(args))
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
 
 
 def extra_opts(args):
@@ -468,12 +556,13 @@ def bench_randsdp(args, torch, dist, rank, world, dev_id, backend):
         raise SystemExit(f"solve stopped after {len(tr)} iterations (< warmup+steps): status {sol.status}")
     t_steps = float(tr[W + K - 1, 12] - (tr[W - 1, 12] if W > 0 else 0.0))
     total_steps, t_steps = replicas.aggregate(dist, K, t_steps, device="cuda" if dist is not None else "cpu")
+    line = None
     if rank == 0:
         st = sol.stats
         N = n * (n + 1) // 2
         bytes_pass = 8.0 * m * N
         pass_ms = st["dense_ms"] / max(1, st["dense_passes"])
-        print(json.dumps({
+        line = ({
             "metric": "PDHG iterations/sec, randSDP n=%d m=%d (dense A, %.1f GB)" % (n, m, bytes_pass / 1e9),
             "value": total_steps / t_steps, "unit": "iterations/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": 1e3 * t_steps / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -499,9 +588,10 @@ def bench_randsdp(args, torch, dist, rank, world, dev_id, backend):
             "cpu_baseline_note": "none at this size: the 64 GB coefficient matrix exists only in HBM (the oracle would need it "
                                  "in host memory and ~2 min per pass); the n=500, m=1000 instance is compared with the oracle "
                                  "in tests/test_gpu_parity.py::test_randsdp_config_against_oracle",
-            "generate_s": t_gen, "solve_wall_s": wall, "init_s": st["init_time"], "exit_s": st["exit_time"]}))
-    if dist is not None:
-        dist.destroy_process_group()
+            "generate_s": t_gen, "solve_wall_s": wall, "init_s": st["init_time"], "exit_s": st["exit_time"]})
+    del pr, opt, sol
+    torch.cuda.empty_cache()
+    return line
 
 
 def bench_sdplib(args, torch, dist, rank, world, dev_id, backend):
@@ -589,8 +679,9 @@ def bench_sdplib(args, torch, dist, rank, world, dev_id, backend):
                          "(LAPACK through SciPy for full_eig!), %.1f s of CPU work" % (int(ref.iter), ref.stats["loop_time"]),
                "wall_s": time.time() - tc}
     if rank == 0:
-        print(json.dumps({
+        return ({
             "cpu_baseline": cpu,
+            "cpu_baseline_note": None if cpu is not None else "N > 1 or --no-cpu",
             "metric": "PDHG iterations/sec, SDPLIB maxG51 (n=1000) on the full-rank fallback eig path (full_eig_decomp=true)",
             "value": total_steps / t_steps, "unit": "iterations/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": 1e3 * t_steps / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -598,9 +689,8 @@ def bench_sdplib(args, torch, dist, rank, world, dev_id, backend):
             "config": {"workload": "SDPLIB maxG51 / gpp500-1, reference harness model (one merged PSD block), "
                                    "full_eig_decomp=true", "parallelism": "replicas x%d" % world},
             "roofline": a["roofline"], "maxG51": a, "gpp500-1": b,
-            "rocsolver_path": {"maxG51": a0, "gpp500-1": b0}}))
-    if dist is not None:
-        dist.destroy_process_group()
+            "rocsolver_path": {"maxG51": a0, "gpp500-1": b0}})
+    return None
 
 
 def bench_mimo(args, torch, dist, rank, world, dev_id, backend):
@@ -673,10 +763,11 @@ def bench_mimo(args, torch, dist, rank, world, dev_id, backend):
                    "kind": "port", "sample": "NumPy/SciPy oracle restatement (not Julia), iterations 1-%d of the same %d-block model, "
                                              "%.1f s of CPU work" % (int(ref.iter), args.blocks, ref.stats["loop_time"]),
                    "wall_s": time.time() - tc}
-        print(json.dumps({
+        return ({
             "roofline": roof, "cpu_baseline": cpu,
             "cpu_baseline_note": None if cpu is not None else "N > 1 or --no-cpu",
             "lanczos_matvecs_per_step": st["lanczos_matvecs"] / max(1, int(sol.iter)),
+            "lanczos_restarts_per_step": st["lanczos_restarts"] / max(1, int(sol.iter)),
             "batched_block_steps": int(st["batched_block_steps"]),
             "metric": "PDHG iterations/sec, MIMO detection SDP n=%d x %d blocks (one block-diagonal model)" % (args.mimo_n, args.blocks),
             "value": K / t_steps, "unit": "iterations/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -686,9 +777,8 @@ def bench_mimo(args, torch, dist, rank, world, dev_id, backend):
                                    % (args.blocks, side, model.n, model.A.shape[0] + model.G.shape[0], world),
                        "parallelism": "block-sharded, scalar all-reduce per iteration" if world > 1 else "single GPU, equal-side blocks batched per launch (grid.z = block)",
                        "status_after_window": int(sol.status), "objective": float(sol.objval)},
-            "solve_wall_s": wall}))
-    if dist is not None:
-        dist.destroy_process_group()
+            "solve_wall_s": wall})
+    return None
 
 
 if __name__ == "__main__":

@@ -508,4 +508,21 @@ int proxsdp_host_preprocess(const proxsdp_problem* prob, int64_t* order, int64_t
     });
 }
 
+#ifdef PX_TIMELINE
+// measurement builds only (tools/timeline/): copy of the step kernels' stamp table
+int proxsdp_hip_debug_timeline(unsigned long long* out, int64_t count, int32_t clear) {
+    return guarded([&]() -> int {
+        const size_t total = sizeof(proxsdp::dev::g_tl) / sizeof(unsigned long long);
+        if (out && count > 0)
+            PX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(proxsdp::dev::g_tl), std::min<size_t>(total, (size_t)count) * sizeof(unsigned long long)));
+        if (clear) {
+            void* p = nullptr;
+            PX_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(proxsdp::dev::g_tl)));
+            PX_HIP(hipMemset(p, 0, sizeof(proxsdp::dev::g_tl)));
+        }
+        return (int)std::min<size_t>(total, (size_t)1 << 30);
+    });
+}
+#endif
+
 }  // extern "C"

@@ -29,6 +29,27 @@ constexpr int CPW = TILE / NWAVE;   // tile columns per wave (16)
 constexpr double INV_SQRT2 = 0.70710678118654752440;
 constexpr double SQRT2 = 1.41421356237309504880;
 
+// ---- intra-kernel timeline of the Lanczos step kernels (measurement builds only: -DPX_TIMELINE, tools/timeline/).
+// Thread 0 of every workgroup stamps the 100 MHz device-wide clock (s_memrealtime) at fixed points of the step
+// kernels: g_tl[kind][step k][workgroup][slot], kind 0 = k_fop_finish / k_symv_finish, 1 = k_lz_orth.
+// The product library is built WITHOUT the macro: PX_TL / PX_TL_DRAIN expand to nothing.
+#ifdef PX_TIMELINE
+constexpr int TL_WG = 160, TL_SLOTS = 8, TL_K = 260;
+__device__ unsigned long long g_tl[2][TL_K][TL_WG][TL_SLOTS];
+#define PX_TL(kind, k, slot)                                                                                   \
+    do {                                                                                                       \
+        if (threadIdx.x == 0 && (int)blockIdx.x < ::proxsdp::dev::TL_WG && (k) >= 0 && (k) < ::proxsdp::dev::TL_K) { \
+            asm volatile("" ::: "memory");                                                                     \
+            ::proxsdp::dev::g_tl[kind][k][blockIdx.x][slot] = wall_clock64();                                    \
+            asm volatile("" ::: "memory");                                                                     \
+        }                                                                                                      \
+    } while (0)
+#define PX_TL_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define PX_TL(kind, k, slot) do { } while (0)
+#define PX_TL_DRAIN() do { } while (0)
+#endif
+
 struct LanczosCtl {                 // device-resident control block of one PSD block
     int stop;                       // set when beta <= tol (invariant subspace)
     int kstop;                      // basis size at which it stopped
@@ -428,6 +449,7 @@ lz_orth_body(const double* __restrict__ Ppart, int nt, int npad, const double* _
              const double* __restrict__ alphas, const double* __restrict__ betas,
              const double* __restrict__ Apart, int napart, int first, const double* __restrict__ arrow, int keep,
              const FopArgs& fo) {
+    PX_TL(1, k, 0);
     const int stop = ctl->stop;                      // tested after the loads below are in flight
     constexpr int NC = 16 * NCH;
     constexpr int NCP = 16 * (NCHP > 0 ? NCHP : 1);
@@ -479,6 +501,9 @@ lz_orth_body(const double* __restrict__ Ppart, int nt, int npad, const double* _
         if constexpr (NCHP > 1) lam_l1 = fo.lam[lane + WAVE];
     }
     if (stop) return;
+    PX_TL(1, k, 1);
+    PX_TL_DRAIN();
+    PX_TL(1, k, 2);
     const double binv = first ? 1.0 : 1.0 / be_km;
     // ---- reductions
     if constexpr (NCHP == 0) {
@@ -517,6 +542,7 @@ lz_orth_body(const double* __restrict__ Ppart, int nt, int npad, const double* _
     }
     if (!first && (int)threadIdx.x < 4 * NC) s_h[threadIdx.x] = ((int)threadIdx.x < k) ? hred_j : 0.0;
     __syncthreads();
+    PX_TL(1, k, 3);
     // ---- coefficients: s_q[j], j < k, over V_{k-1}; s_q[k] = coefficient of v_k
     double alpha, wi;
     if constexpr (NCHP == 0) {
@@ -559,6 +585,7 @@ lz_orth_body(const double* __restrict__ Ppart, int nt, int npad, const double* _
     }
     if (j == k) s_q[k] = ck;
     __syncthreads();
+    PX_TL(1, k, 4);
     // ---- w' = w - V q   (each wave its own columns, from registers)
     double d0 = 0.0, d1 = 0.0;
 #pragma unroll
@@ -579,6 +606,7 @@ lz_orth_body(const double* __restrict__ Ppart, int nt, int npad, const double* _
     }
     s_acc[wv][lane] = dsub;                           // (all reads of s_acc for wi precede the barrier above)
     __syncthreads();
+    PX_TL(1, k, 5);
     const double wp = wi - ((s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane]));
     if (wv == 0) {
         wbuf[i] = wp;
@@ -596,6 +624,7 @@ lz_orth_body(const double* __restrict__ Ppart, int nt, int npad, const double* _
         const int jc = wv + 4 * (16 * ch + lane);
         if (lane < 16 && jc <= k) hpart_out[(long long)jc * pld + blockIdx.x] = hs;
     }
+    PX_TL(1, k, 6);
 }
 template <int NCH, int NCHP>
 __global__ void __launch_bounds__(TPB)
@@ -632,6 +661,7 @@ __device__ __forceinline__ void lz_finish_body(const double* __restrict__ wbuf, 
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int kk = k + 1;
     const int i = g * LZ_ROWS + lane;
+    PX_TL(0, k + 1, 0);
     // ---- all loads
     const int stop = ctl->stop;
     const int gl = min(lane, pld - 1);
@@ -647,6 +677,9 @@ __device__ __forceinline__ void lz_finish_body(const double* __restrict__ wbuf, 
     const double h1k = h1[k];
     const double carry = use_carry ? ctl->carry : 0.0;
     if (stop) return;
+    PX_TL(0, k + 1, 1);
+    PX_TL_DRAIN();
+    PX_TL(0, k + 1, 2);
     // ---- h2 = sums of the partial dots, |w'|^2
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -669,6 +702,7 @@ __device__ __forceinline__ void lz_finish_body(const double* __restrict__ wbuf, 
         if (lane == 0) s_h[4 * NC] = hn;
     }
     __syncthreads();
+    PX_TL(0, k + 1, 3);
     // ---- beta, v_{k+1} = (w' - V h2) / beta
     double hh = 0.0;
     for (int j = lane; j < kk; j += WAVE) hh += s_h[j] * s_h[j];
@@ -695,10 +729,12 @@ __device__ __forceinline__ void lz_finish_body(const double* __restrict__ wbuf, 
     }
     if (beta <= tol) return;
     __syncthreads();
+    PX_TL(0, k + 1, 4);
     if (wv == 0) {
         const double wi = w0 - ((s_d[lane] + s_d[LZ_ROWS + lane]) + (s_d[2 * LZ_ROWS + lane] + s_d[3 * LZ_ROWS + lane]));
         V[(long long)(k + 1) * ldv + i] = wi / beta;          // rows >= n stay zero
     }
+    PX_TL(0, k + 1, 5);
     (void)s_beta;
 }
 
@@ -835,11 +871,12 @@ __device__ __forceinline__ void fop_body(const double* __restrict__ v, const dou
                                          int npad, const double* __restrict__ esv, double* __restrict__ tpart, int pld,
                                          double* __restrict__ ebuf, double* __restrict__ apart, int g,
                                          double* __restrict__ s_e /* NWAVE*64 */, const LanczosCtl* __restrict__ ctl,
-                                         const EllOverflow& ov) {
+                                         const EllOverflow& ov, int tlk = -1 /* timeline builds: step index */) {
     constexpr int NCP = 16 * NCHP;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = g * LZ_ROWS + lane;
+    PX_TL(0, tlk, 0);
     const int stop = (ctl != nullptr) ? ctl->stop : 0;   // tested once the first loads are in flight
     const double vi = v[i];
     double vrp[NCP];
@@ -854,6 +891,7 @@ __device__ __forceinline__ void fop_body(const double* __restrict__ v, const dou
         sx0[u] = (wv + u * NWAVE < ell_w) ? ell_sidx[(long long)k * npad + i] : -1;
     }
     if (stop) return;
+    PX_TL(0, tlk, 1);
     double e = 0.0;
     for (int k0 = wv; k0 < ell_w; k0 += 4 * NWAVE) {
         int col[4], sx[4];
@@ -872,6 +910,7 @@ __device__ __forceinline__ void fop_body(const double* __restrict__ v, const dou
             if (sx[u] >= 0) e += ((col[u] == i) ? ev[u] : ev[u] * INV_SQRT2) * xv[u];
     }
     s_e[wv * LZ_ROWS + lane] = e;
+    PX_TL(0, tlk, 2);
     if (ov.wr_ptr != nullptr) {
         const int q0 = ov.wr_ptr[g], q1 = ov.wr_ptr[g + 1];
         if (q1 > q0) {                                   // uniform over the workgroup; rare
@@ -904,12 +943,14 @@ __device__ __forceinline__ void fop_body(const double* __restrict__ v, const dou
         if (lane < 16 && cc < rp) tpart[(long long)cc * pld + g] = ts;
     }
     __syncthreads();
+    PX_TL(0, tlk, 3);
     if (wv == 0) {
         const double ei = (s_e[lane] + s_e[LZ_ROWS + lane]) + (s_e[2 * LZ_ROWS + lane] + s_e[3 * LZ_ROWS + lane]);
         ebuf[i] = ei;
         const double a = wave_sum(vi * ei);
         if (lane == 0) apart[g] = a;
     }
+    PX_TL(0, tlk, 4);
 }
 // first mat-vec of a cycle (on the normalised v_k); grid = nt
 template <int NCHP>
@@ -939,7 +980,7 @@ k_fop_finish(const double* __restrict__ wbuf, double* __restrict__ V, int ldv, i
                             s_a, s_b, &s_beta, hred);
     } else {
         fop_body<NCHP>(wbuf, Vp, ldv, rp, ell_col, ell_sidx, ell_w, npad, esv, tpart, pld, ebuf, apart,
-                       (int)blockIdx.x - nt, s_b, ctl, ov);
+                       (int)blockIdx.x - nt, s_b, ctl, ov, k + 1);
     }
 }
 

@@ -41,6 +41,37 @@ def test_two_rank_replica_aggregation():
     assert c0 != c1                           # different instances per replica
 
 
+def _run_bench(extra_env, *argv):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=env, cwd=root,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+
+
+def test_bench_gpus_flag_spawns_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher in the environment must reach two ranks (the flag was
+    parsed and ignored).  Dry run = the rank plumbing without the solve (no device here), gloo backend."""
+    import json
+    r = _run_bench({"PROXSDP_BENCH_DRYRUN": "1", "PROXSDP_BENCH_BACKEND": "gloo"}, "--gpus", "2", "--steps", "7")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                      # rank 0 prints ONE line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["dry_run"] is True
+    assert line["units_all_ranks"] == 14.0                # SUM over ranks
+    assert line["max_seconds"] == 2.0                     # MAX over ranks (rank r reports 1 + r)
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    r = _run_bench({"PROXSDP_BENCH_DRYRUN": "1", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"}, "--gpus", "2")
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+    r = _run_bench({"PROXSDP_BENCH_DRYRUN": "1"}, "--gpus", "1", "--steps", "3")
+    assert r.returncode == 0 and '"n_gpus": 1' in r.stdout
+
+
 def test_block_assignment():
     assert replicas.assign_blocks(8, 8) == list(range(8))
     assert replicas.assign_blocks(8, 2) == [0, 1, 0, 1, 0, 1, 0, 1]
