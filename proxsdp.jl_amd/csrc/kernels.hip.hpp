@@ -347,9 +347,30 @@ constexpr int MAXK = 260;           // capacity of the Krylov basis (krylovdim +
 constexpr int LZ_ROWS = TILE;       // rows per workgroup in the Lanczos vector kernels
 constexpr int NRM_SLOT = MAXK - 1;  // slot of a partial-dots row that carries |w'|^2
 
-// Partial dots live column-major over workgroups: hpart[j * pld + g] (pld = number of
-// workgroups rounded up to 64, padding stays zero), so that the consumer reads the
-// partials of one basis column with ONE coalesced load per wave.
+// Partial dots live PRODUCER-major: workgroup g writes its record hpart[g * KLD + j] (column j of the basis),
+// its |w'|^2 share at hpart[pld * KLD + g] (pld = number of workgroups rounded up to 64, padding records stay
+// zero); likewise tpart[g * RLD + c] for the operator form's Vp'v partials.  The consumer maps LANE <-> COLUMN:
+// wave wv holds the records g = wv, wv + 4, ... (one coalesced load per record, no cross-lane traffic), adds them in
+// registers and the four waves meet once in LDS.  (Round 3 kept the partials column-major and reduced 16 columns at
+// a time over the lanes with the mat-vec's fold network: by the step timeline, profiles/r04_step_timeline.md, that
+// network was 1.7 us of the closing workgroups' 5.6 us.)  The ORDER of the additions is that network's balanced
+// tree -- partner g^8, then g^4, g^2, g^1, g^16, g^32 -- restated on the new layout (tree_in_wave / tree_across), so
+// every sum has the bits it had before: the committed iteration counts and rank schedules do not move.
+//   g = wv + 4u:  g^8 <-> u^2, g^4 <-> u^1 (inside the wave);  g^2, g^1 <-> the other waves;  g^16 <-> u^4, g^32 <-> u^8
+__device__ __forceinline__ void tree_in_wave(const double (&p)[16], double (&q)[4]) {   // levels g^8, g^4: 16 records -> 4 groups
+#pragma unroll
+    for (int a = 0; a < 4; ++a) q[a] = (p[4 * a] + p[4 * a + 2]) + (p[4 * a + 1] + p[4 * a + 3]);
+}
+// s[(wave * 4 + group) * stride + column]: levels g^2, g^1 (waves), then g^16, g^32 (groups)
+__device__ __forceinline__ double tree_across(const double* __restrict__ s, int stride, int col) {
+    double a[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        a[q] = (s[(0 * 4 + q) * stride + col] + s[(2 * 4 + q) * stride + col]) + (s[(1 * 4 + q) * stride + col] + s[(3 * 4 + q) * stride + col]);
+    return (a[0] + a[1]) + (a[2] + a[3]);
+}
+constexpr int KLD = 256;            // >= krylovdim + 1
+constexpr int RLD = 128;            // >= rank of the previous projection's factors (<= 127)
 
 // start of a projection: V[:,0] = start vector, control block cleared (one launch instead of a
 // device-to-device copy plus a memset in the solve stream)
@@ -453,7 +474,7 @@ lz_orth_body(const double* __restrict__ Ppart, int nt, int npad, const double* _
     const int stop = ctl->stop;                      // tested after the loads below are in flight
     constexpr int NC = 16 * NCH;
     constexpr int NCP = 16 * (NCHP > 0 ? NCHP : 1);
-    __shared__ double s_t[4 * NCP];
+    __shared__ double s_t[NWAVE * 4 * 4 * NCP];      // per-wave group sums of the producers' Vp'v records, [wave][group][column]
     __shared__ double s_u[4 * NCP];
     __shared__ double s_h[4 * NC];
     __shared__ double s_q[4 * NC];
@@ -465,7 +486,8 @@ lz_orth_body(const double* __restrict__ Ppart, int nt, int npad, const double* _
     // ---- all loads
     double pv[16];                                   // mat-vec partial slots wv, wv+4, ...
     double av[8];                                    // per-tile shares of w' P~ w'
-    double vrp[NCP], tp[NCP], eb = 0.0, ap = 0.0;    // operator form: Vp columns, Vp'v partials, (E v)_i, v'Ev partials
+    constexpr int NLP = (NCHP > 0 ? NCHP : 1);       // 64-column chunks of the Vp'v records (lane <-> column)
+    double vrp[NCP], tp[16][NLP], eb = 0.0, ap = 0.0; // operator form: Vp columns, Vp'v partials, (E v)_i, v'Ev partials
     if constexpr (NCHP == 0) {
 #pragma unroll
         for (int u = 0; u < 16; ++u) pv[u] = Ppart[(long long)min(wv + u * NWAVE, nt - 1) * npad + i];
@@ -477,14 +499,28 @@ lz_orth_body(const double* __restrict__ Ppart, int nt, int npad, const double* _
         for (int c = 0; c < NCP; ++c) {
             const int cc = min(wv + 4 * c, max(fo.rp - 1, 0));
             vrp[c] = fo.Vp[(long long)cc * ldv + i];
-            tp[c] = fo.tpart[(long long)cc * pld + gl0];
+        }
+        // Vp'v partials: records of the producers wv, wv + 4, ... (lane <-> column)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const long long rec = (long long)min(wv + NWAVE * u, pld - 1) * RLD;
+#pragma unroll
+            for (int ch = 0; ch < NLP; ++ch) tp[u][ch] = (ch == 0 || 64 * ch < fo.rp) ? fo.tpart[rec + 64 * ch + lane] : 0.0;
         }
         eb = fo.ebuf[i];
         ap = fo.apart[gl0];
     }
-    double vr[NC];                                   // basis columns of this wave (column k included)
+    double vr[NC];                                   // basis columns of this wave (column k included): groups of four,
+#pragma unroll                                       // groups beyond column k are not loaded
+    for (int c0 = 0; c0 < NC; c0 += 4) {
+        if (wv + 4 * c0 <= k) {
 #pragma unroll
-    for (int c = 0; c < NC; ++c) vr[c] = V[(long long)min(wv + 4 * c, k) * ldv + i];
+            for (int c = c0; c < c0 + 4; ++c) vr[c] = V[(long long)min(wv + 4 * c, k) * ldv + i];
+        } else {
+#pragma unroll
+            for (int c = c0; c < c0 + 4; ++c) vr[c] = 0.0;
+        }
+    }
     // h2 of step k-1, already reduced by the closing workgroup 0 of the previous launch
     const double hred_j = hred[min((int)threadIdx.x, MAXK - 1)];
     // coefficient data of the prediction (thread j <-> basis column j; lane-indexed copies for
@@ -520,20 +556,19 @@ lz_orth_body(const double* __restrict__ Ppart, int nt, int npad, const double* _
         a = wave_sum(a);
         if (lane == 0) s_red[wv] = a;
     } else {
-        // t = Vp' v (sum of the workgroup partials), v'Ev
+        // t = Vp' v: this wave's share of the producers' records, fixed order; the four waves meet in s_t
 #pragma unroll
-        for (int c = 0; c < NCP; ++c) {
-            const int cc = wv + 4 * c;
-            if (lane >= pld || cc >= fo.rp) tp[c] = 0.0;
-            else for (int g = lane + WAVE; g < pld; g += WAVE) tp[c] += fo.tpart[(long long)cc * pld + g];   // n > 4096
-        }
+        for (int ch = 0; ch < NLP; ++ch) {
+            double pr[16], q4[4];
 #pragma unroll
-        for (int ch = 0; ch < NCHP; ++ch) {
-            double t[16];
+            for (int u = 0; u < 16; ++u) {
+                pr[u] = tp[u][ch];
+                if (64 * ch < fo.rp)
+                    for (int g = wv + NWAVE * u + WAVE; g < pld; g += WAVE) pr[u] += fo.tpart[(long long)g * RLD + 64 * ch + lane];   // n > 4096
+            }
+            tree_in_wave(pr, q4);
 #pragma unroll
-            for (int c = 0; c < 16; ++c) t[c] = tp[16 * ch + c];
-            const double ts = fold16_all(t, lane);
-            if (lane < 16) s_t[wv + 4 * (16 * ch + lane)] = ts;          // zero for c >= rp
+            for (int a = 0; a < 4; ++a) s_t[(wv * 4 + a) * (64 * NLP) + 64 * ch + lane] = q4[a];
         }
         if (lane >= pld) ap = 0.0;
         else for (int g = lane + WAVE; g < pld; g += WAVE) ap += fo.apart[g];
@@ -550,12 +585,14 @@ lz_orth_body(const double* __restrict__ Ppart, int nt, int npad, const double* _
         wi = ((s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane])) * (INV_SQRT2 * binv);
     } else {
         // v'Av = t' Lam t + v'Ev;   u = Lam t for the row-wise rebuild below
-        double tl = (lane < fo.rp) ? lam_l0 * s_t[lane] * s_t[lane] : 0.0;
-        if constexpr (NCHP > 1) if (lane + WAVE < fo.rp) tl += lam_l1 * s_t[lane + WAVE] * s_t[lane + WAVE];
+        auto tsum = [&](int c) { return tree_across(s_t, 64 * NLP, c); };   // t_c from the waves' group sums (c < 64 NLP)
+        double tl = 0.0;
+        if (lane < fo.rp) { const double t0 = tsum(lane); tl = lam_l0 * t0 * t0; }
+        if constexpr (NCHP > 1) if (lane + WAVE < fo.rp) { const double t1 = tsum(lane + WAVE); tl += lam_l1 * t1 * t1; }
         tl = wave_sum(tl);
         alpha = (tl + s_red[0]) * binv * binv;
         wi = eb * binv;                              // + Vp u / beta, folded into the exchange below
-        if (j < 4 * NCP) s_u[j] = (j < fo.rp) ? lam_j * s_t[j] : 0.0;
+        if (j < 4 * NCP) s_u[j] = (j < fo.rp) ? lam_j * tsum(j) : 0.0;
     }
     double ck = alpha;
     if (first) {
@@ -584,15 +621,20 @@ lz_orth_body(const double* __restrict__ Ppart, int nt, int npad, const double* _
         }
     }
     if (j == k) s_q[k] = ck;
+    else if (j > k && j < 4 * NC) s_q[j] = 0.0;       // (and `first` with j in [keep, k): set below)
+    if (first && j >= keep && j < k) s_q[j] = 0.0;
     __syncthreads();
     PX_TL(1, k, 4);
-    // ---- w' = w - V q   (each wave its own columns, from registers)
+    // ---- w' = w - V q   (each wave its own columns, from registers; s_q is zero beyond column k, so no test per term:
+    // the LDS reads are issued together)
+    double qv[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) qv[c] = s_q[wv + 4 * c];
     double d0 = 0.0, d1 = 0.0;
 #pragma unroll
     for (int c = 0; c < NC; c += 2) {
-        const int j0 = wv + 4 * c, j1 = j0 + 4;
-        if (j0 <= k) d0 += vr[c] * s_q[j0];
-        if (j1 <= k) d1 += vr[c + 1] * s_q[j1];
+        d0 += vr[c] * qv[c];
+        d1 += vr[c + 1] * qv[c + 1];
     }
     double dsub = d0 + d1;
     if constexpr (NCHP > 0) {                         // (A v)_i = e_i + sum_c Vp[i,c] u_c
@@ -611,7 +653,7 @@ lz_orth_body(const double* __restrict__ Ppart, int nt, int npad, const double* _
     if (wv == 0) {
         wbuf[i] = wp;
         const double r = wave_sum(wp * wp);
-        if (lane == 0) hpart_out[(long long)NRM_SLOT * pld + blockIdx.x] = r;
+        if (lane == 0) hpart_out[(long long)pld * KLD + blockIdx.x] = r;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) hsum_out[k] = ck;
     // ---- measured pass: V_k' w'
@@ -622,7 +664,7 @@ lz_orth_body(const double* __restrict__ Ppart, int nt, int npad, const double* _
         for (int c = 0; c < 16; ++c) t[c] = (wv + 4 * (16 * ch + c) <= k) ? vr[16 * ch + c] * wp : 0.0;
         const double hs = fold16_all(t, lane);
         const int jc = wv + 4 * (16 * ch + lane);
-        if (lane < 16 && jc <= k) hpart_out[(long long)jc * pld + blockIdx.x] = hs;
+        if (lane < 16 && jc <= k) hpart_out[(long long)blockIdx.x * KLD + jc] = hs;
     }
     PX_TL(1, k, 6);
 }
@@ -657,6 +699,7 @@ __device__ __forceinline__ void lz_finish_body(const double* __restrict__ wbuf, 
                                                double* __restrict__ s_h, double* __restrict__ s_d,
                                                double* __restrict__ s_beta, double* __restrict__ hred) {
     constexpr int NC = 16 * NCH;
+    __shared__ double s_p[NWAVE * 4 * 64 * NCH];         // per-wave group sums of the producers' records, [wave][group][column]
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int kk = k + 1;
@@ -664,15 +707,28 @@ __device__ __forceinline__ void lz_finish_body(const double* __restrict__ wbuf, 
     PX_TL(0, k + 1, 0);
     // ---- all loads
     const int stop = ctl->stop;
-    const int gl = min(lane, pld - 1);
-    double hp[NC], vr[NC];
+    // partial dots: records of the producers wv, wv + 4, ... (16 of them cover pld = 64), lane <-> column
+    double hp[16][NCH];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const int j = min(wv + 4 * c, MAXK - 2);
-        hp[c] = hpart_in[(long long)j * pld + gl];
-        vr[c] = V[(long long)min(wv + 4 * c, k) * ldv + i];
+    for (int u = 0; u < 16; ++u) {
+        const long long rec = (long long)min(wv + NWAVE * u, pld - 1) * KLD;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+            hp[u][ch] = (ch == 0 || 64 * ch < kk) ? hpart_in[rec + 64 * ch + lane] : 0.0;   // (uniform test: whole chunks beyond k are skipped)
     }
-    double hn = hpart_in[(long long)NRM_SLOT * pld + gl];
+    // the wave's basis columns j = wv + 4c: groups of four, groups beyond column k are not loaded
+    double vr[NC];
+#pragma unroll
+    for (int c0 = 0; c0 < NC; c0 += 4) {
+        if (wv + 4 * c0 <= k) {
+#pragma unroll
+            for (int c = c0; c < c0 + 4; ++c) vr[c] = V[(long long)min(wv + 4 * c, k) * ldv + i];
+        } else {
+#pragma unroll
+            for (int c = c0; c < c0 + 4; ++c) vr[c] = 0.0;
+        }
+    }
+    double hn = hpart_in[(long long)pld * KLD + min(lane, pld - 1)];
     const double w0 = wbuf[i];
     const double h1k = h1[k];
     const double carry = use_carry ? ctl->carry : 0.0;
@@ -682,24 +738,29 @@ __device__ __forceinline__ void lz_finish_body(const double* __restrict__ wbuf, 
     PX_TL(0, k + 1, 2);
     // ---- h2 = sums of the partial dots, |w'|^2
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const int j = wv + 4 * c;
-        if (lane >= pld || j >= kk) hp[c] = 0.0;
-        else for (int q = lane + WAVE; q < pld; q += WAVE) hp[c] += hpart_in[(long long)j * pld + q];   // n > 4096
-    }
-#pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-        double t[16];
+        double pr[16], q4[4];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) t[c] = hp[16 * ch + c];
-        const double hs = fold16_all(t, lane);
-        if (lane < 16) s_h[wv + 4 * (16 * ch + lane)] = hs;              // zero for j >= kk
+        for (int u = 0; u < 16; ++u) {
+            pr[u] = hp[u][ch];                                        // records >= the producer count are zero
+            if (64 * ch < kk)
+                for (int q = wv + NWAVE * u + WAVE; q < pld; q += WAVE) pr[u] += hpart_in[(long long)q * KLD + 64 * ch + lane];   // n > 4096
+        }
+        tree_in_wave(pr, q4);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) s_p[(wv * 4 + a) * (64 * NCH) + 64 * ch + lane] = q4[a];
     }
     if (wv == 0) {
         if (lane >= pld) hn = 0.0;
-        else for (int q = lane + WAVE; q < pld; q += WAVE) hn += hpart_in[(long long)NRM_SLOT * pld + q];
+        else for (int q = lane + WAVE; q < pld; q += WAVE) hn += hpart_in[(long long)pld * KLD + q];
         hn = wave_sum(hn);
         if (lane == 0) s_h[4 * NC] = hn;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 64 * NCH) {
+        const int j = threadIdx.x;
+        const double hj = tree_across(s_p, 64 * NCH, j);
+        s_h[j] = (j < kk) ? hj : 0.0;
     }
     __syncthreads();
     PX_TL(0, k + 1, 3);
@@ -708,16 +769,21 @@ __device__ __forceinline__ void lz_finish_body(const double* __restrict__ wbuf, 
     for (int j = lane; j < kk; j += WAVE) hh += s_h[j] * s_h[j];
     hh = wave_sum(hh);                                   // every wave: same value, same order
     const double beta = sqrt(fmax(s_h[4 * NC] - hh, 0.0));
+    // V h2 row sums: s_h is zero from column kk on (and skipped column groups hold zeros), so the products need no
+    // test -- a uniform branch around every term made the LDS reads of s_h wait for one another (1.3 us of the closing
+    // workgroups' time in profiles/r04_step_timeline.md)
+    double hq[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) hq[c] = s_h[wv + 4 * c];
     double d0 = 0.0, d1 = 0.0;
 #pragma unroll
     for (int c = 0; c < NC; c += 2) {
-        const int j0 = wv + 4 * c, j1 = j0 + 4;
-        if (j0 < kk) d0 += vr[c] * s_h[j0];
-        if (j1 < kk) d1 += vr[c + 1] * s_h[j1];
+        d0 += vr[c] * hq[c];
+        d1 += vr[c + 1] * hq[c + 1];
     }
     s_d[wv * LZ_ROWS + lane] = d0 + d1;
     // the reduced h2 for the prediction of the next step (k_lz_orth reads k values instead of
-    // re-reducing 64 partials per column)
+    // re-reducing the partials)
     if (g == 0 && (int)threadIdx.x < kk) hred[threadIdx.x] = s_h[threadIdx.x];
     if (g == 0 && threadIdx.x == 0) {
         alphas[k] = h1k + s_h[k] - carry;
@@ -940,7 +1006,7 @@ __device__ __forceinline__ void fop_body(const double* __restrict__ v, const dou
         for (int c = 0; c < 16; ++c) t[c] = vrp[16 * ch + c] * vi;
         const double ts = fold16_all(t, lane);
         const int cc = wv + 4 * (16 * ch + lane);
-        if (lane < 16 && cc < rp) tpart[(long long)cc * pld + g] = ts;
+        if (lane < 16 && cc < rp) tpart[(long long)g * RLD + cc] = ts;
     }
     __syncthreads();
     PX_TL(0, tlk, 3);
