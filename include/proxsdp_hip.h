@@ -139,7 +139,11 @@ typedef struct proxsdp_problem {
      * collectives itself on its own stream -- ncclAllReduce(sum) / ncclAllReduce(max) of the packed scalar record
      * and ncclAllReduce(sum) of the coupling buffer -- with no host callback and no host copy of the vectors;
      * reduce_fn / reduce_vec_fn may then be NULL (they are ignored).  librccl.so is loaded at run time
-     * (dlopen): the library does not link it, and a process that never passes a communicator never loads it. */
+     * (dlopen): the library does not link it, and a process that never passes a communicator never loads it.
+     * Every host wait behind one of these collectives is bounded (PROXSDP_HIP_COLLECTIVE_TIMEOUT_S seconds, default
+     * 300): a rank whose peer left the solve aborts its communicator (ncclCommAbort) and returns PROXSDP_E_INTERNAL
+     * instead of waiting for ever; a rank that fails for its own reasons aborts its communicator on the way out.  An
+     * aborted communicator must be destroyed by the caller, not reused. */
     void* nccl_comm;
     int64_t reserved3;
 } proxsdp_problem;
@@ -272,7 +276,9 @@ typedef struct proxsdp_options {
     int32_t rocsolver_warmup;    /* 1 = load rocSOLVER's code objects from a background thread at start-up (default 0) */
     int32_t debug_fail_iteration;/* k > 0: FAULT INJECTION for tests -- this process throws inside the PSD projection of
                                   * iteration k (a block-sharded solve must then abort on EVERY shard after that
-                                  * iteration's scalar reduce instead of leaving the peers in a collective); 0 = never */
+                                  * iteration's scalar reduce instead of leaving the peers in a collective); 0 = never.
+                                  * Honoured only when PROXSDP_HIP_FAULT_INJECTION=1 is set in the environment as well
+                                  * (otherwise PROXSDP_E_INVALID): a test switch, not a user option */
     int32_t host_wait_spin;      /* how the solver thread waits for the GPU at its per-cycle / per-iteration read-backs:
                                   * 1 = poll hipStreamQuery (no sleep: the wake-up of a blocked wait costs tens of
                                   * microseconds per synchronisation and leaves the core cold for the K x K eigensolve

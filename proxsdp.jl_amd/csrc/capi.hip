@@ -157,7 +157,14 @@ int proxsdp_hip_solve(const proxsdp_problem* prob, const proxsdp_options* opt, p
         res->status_string[0] = 0;
         if (o.trace_capacity > 0 && !res->trace) o.trace_capacity = 0;
         proxsdp::Solver S(*prob, o, *res);
-        S.run();
+        try {
+            S.run();
+        } catch (...) {
+            // native RCCL path: this rank leaves the solve -- stop its own pending collectives so that its stream drains;
+            // the peers' waits are bounded (Solver::wait_collective) and fail the same way
+            if (S.nccl && !S.nccl_aborted) S.abort_comm();
+            throw;
+        }
         return 0;
     });
 }

@@ -329,7 +329,9 @@ struct Rank1Merge {
                 const double* w0 = wbuf.data(); const double* w1 = w0 + kk; const double* w2 = w1 + kk; const double* w3 = w2 + kk;
                 int r = 0;
 #if defined(__x86_64__)
-                for (; r + 8 <= nr; r += 8)
+                // (the panel kernel needs AVX2 + FMA: checked once at run time, the scalar loop below serves any other host)
+                static const bool have_fma = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+                for (; have_fma && r + 8 <= nr; r += 8)
                     rank1_panel_8x4(Qf.data(), K, qcol.data(), kk, r0 + r, w0, w1, w2, w3, u[0] ? u[0] + r : nullptr,
                                     u[1] ? u[1] + r : nullptr, u[2] ? u[2] + r : nullptr, u[3] ? u[3] + r : nullptr);
 #endif

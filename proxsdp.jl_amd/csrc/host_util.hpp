@@ -472,16 +472,20 @@ public:
     void disarm() { armed_.store(false, std::memory_order_release); }
     // fn(i) for every i in [0, n), on the helpers and the calling thread; returns when all are done.
     // fn must not throw (callers catch inside and report through their own state).
+    // The job index is handed out through ONE 64-bit word [generation | next index] by compare-and-swap: a helper
+    // that was descheduled inside the previous generation's loop cannot take an index of this one by accident (with a
+    // separate generation counter and index counter it could: a stale fetch_add executed a job twice and let run()
+    // return early -- ADVICE r3), and the job description it reads is the one published with that word.
     template <typename F>
     void run(int n, F&& fn) {
         if (n <= 0) return;
         std::function<void(int)> f = fn;
-        job_ = &f;
-        njobs_ = n;
+        job_.store(&f, std::memory_order_relaxed);
+        njobs_.store(n, std::memory_order_relaxed);
         done_.store(0, std::memory_order_relaxed);
-        next_.store(0, std::memory_order_release);
-        gen_.fetch_add(1, std::memory_order_acq_rel);
-        work();
+        const uint64_t g = ++gen_;
+        ticket_.store(g << 32, std::memory_order_release);
+        work(g);
         while (done_.load(std::memory_order_acquire) < n) {
 #if defined(__x86_64__)
             _mm_pause();
@@ -489,16 +493,19 @@ public:
         }
     }
 private:
-    void work() {
+    void work(uint64_t g) {
         for (;;) {
-            const int i = next_.fetch_add(1, std::memory_order_acq_rel);
-            if (i >= njobs_) break;
-            (*job_)(i);
+            uint64_t t = ticket_.load(std::memory_order_acquire);
+            if ((t >> 32) != g) return;                                  // another generation's word: not ours to touch
+            const int i = (int)(t & 0xffffffffu);
+            if (i >= njobs_.load(std::memory_order_relaxed)) return;
+            if (!ticket_.compare_exchange_weak(t, t + 1, std::memory_order_acq_rel, std::memory_order_acquire)) continue;
+            (*job_.load(std::memory_order_relaxed))(i);                  // (run() cannot return before done_ counts this job)
             done_.fetch_add(1, std::memory_order_acq_rel);
         }
     }
     void loop() {
-        long long seen = 0;
+        uint64_t seen = 0;
         for (;;) {
             {
                 std::unique_lock<std::mutex> lk(mu_);
@@ -506,8 +513,8 @@ private:
                 if (stop_.load()) return;
             }
             while (armed_.load(std::memory_order_acquire) && !stop_.load(std::memory_order_relaxed)) {
-                const long long g = gen_.load(std::memory_order_acquire);
-                if (g != seen) { seen = g; work(); }
+                const uint64_t g = ticket_.load(std::memory_order_acquire) >> 32;
+                if (g != seen) { seen = g; work(g); }
                 else {
 #if defined(__x86_64__)
                     _mm_pause();
@@ -520,10 +527,10 @@ private:
     std::mutex mu_;
     std::condition_variable cv_;
     std::atomic<bool> armed_{false}, stop_{false};
-    std::atomic<long long> gen_{0};
-    std::atomic<int> next_{1 << 30}, done_{0};
-    int njobs_ = 0;
-    const std::function<void(int)>* job_ = nullptr;
+    uint64_t gen_ = 0;                                   // (only the thread that calls run() touches it)
+    std::atomic<uint64_t> ticket_{0};                    // [generation : 32 | next job index : 32]
+    std::atomic<int> done_{0}, njobs_{0};
+    std::atomic<const std::function<void(int)>*> job_{nullptr};
 };
 
 // ------------------------------------------------------------------ split + rank-one merge (host_eig_merge.hpp)

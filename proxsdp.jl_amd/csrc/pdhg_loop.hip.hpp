@@ -1389,6 +1389,14 @@ inline void Solver::run() {
         throw std::domain_error("approx_norm=false with a dense A or a block-sharded solve is not implemented");
     if (P.n <= 0) throw std::invalid_argument("problem has no variables");
     if (opt.convergence_window <= 0) throw std::invalid_argument("convergence_window must be positive");
+    // (the reference's `for i in 1:max_linsearch_steps` simply runs no trial then and keeps stale norms; the batched
+    // candidates here need at least one)
+    if (opt.line_search_flag && opt.max_linsearch_steps < 1) throw std::invalid_argument("max_linsearch_steps must be >= 1");
+    // fault injection is a TEST switch: it only works in a process that asks for it by environment as well
+    if (opt.debug_fail_iteration > 0) {
+        const char* e = std::getenv("PROXSDP_HIP_FAULT_INJECTION");
+        if (!(e && e[0] == '1')) throw std::invalid_argument("debug_fail_iteration needs PROXSDP_HIP_FAULT_INJECTION=1 in the environment (test switch)");
+    }
     theta = opt.initial_theta; adapt_level = opt.initial_adapt_level; beta = opt.initial_beta;
     const int window = opt.convergence_window;
     const size_t nb = P.blocks.size();

@@ -24,6 +24,7 @@ struct Rccl {
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;     // optional: releases THIS rank's pending collectives
     std::string load_error;
 
     static Rccl& get() {
@@ -65,6 +66,7 @@ private:
                          sym(CommUserRank, "ncclCommUserRank") && sym(AllReduce, "ncclAllReduce") &&
                          sym(AllGather, "ncclAllGather") && sym(GetErrorString, "ncclGetErrorString");
         if (!all) handle = nullptr;       // (left loaded; the table is unusable)
+        else CommAbort = reinterpret_cast<decltype(CommAbort)>(dlsym(handle, "ncclCommAbort"));
     }
 };
 

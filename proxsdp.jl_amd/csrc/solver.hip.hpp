@@ -388,6 +388,7 @@ public:
     // wait for the solver's (or the calling block thread's) stream at a read-back on the critical path
     void wait_stream() {
         hipStream_t s = stream;
+        if (nccl) { wait_collective(s); return; }
         if (opt.host_wait_spin == 0) { PX_HIP(hipStreamSynchronize(s)); return; }
         for (;;) {
             const hipError_t e = hipStreamQuery(s);
@@ -398,6 +399,39 @@ public:
 #endif
         }
     }
+    // Native RCCL path: every host wait that may sit behind a collective is BOUNDED (a peer that left the
+    // solve -- an exception between two collectives, a dead process -- used to leave this rank in
+    // hipStreamSynchronize for ever).  After PROXSDP_HIP_COLLECTIVE_TIMEOUT_S seconds (default 300) without progress
+    // this rank aborts its communicator (ncclCommAbort: its own pending collective kernels stop) and fails the solve.
+    double collective_timeout_s = -1.0;
+    void wait_collective(hipStream_t s) {
+        if (collective_timeout_s < 0.0) {
+            const char* e = std::getenv("PROXSDP_HIP_COLLECTIVE_TIMEOUT_S");
+            collective_timeout_s = (e && std::atof(e) > 0.0) ? std::atof(e) : 300.0;
+        }
+        const double t0 = now_s();
+        for (unsigned spins = 0;; ++spins) {
+            const hipError_t e = hipStreamQuery(s);
+            if (e == hipSuccess) return;
+            if (e != hipErrorNotReady) PX_HIP(e);
+            if ((spins & 0xfff) == 0xfff && now_s() - t0 > collective_timeout_s) {
+                abort_comm();
+                throw std::runtime_error("block-sharded solve: a collective did not complete within " +
+                                         std::to_string((int)collective_timeout_s) + " s (did another shard leave the solve?)");
+            }
+#if defined(__x86_64__)
+            _mm_pause();
+#endif
+        }
+    }
+    // local abort of the native communicator (it is unusable afterwards; the caller destroys it)
+    void abort_comm() {
+        if (!nccl) return;
+        Rccl& rc = Rccl::get();
+        if (rc.ok() && rc.CommAbort) (void)rc.CommAbort(nccl);
+        nccl_aborted = true;
+    }
+    bool nccl_aborted = false;
     void wait_event(hipEvent_t ev) {
         if (opt.host_wait_spin == 0) { PX_HIP(hipEventSynchronize(ev)); return; }
         for (;;) {
@@ -417,7 +451,7 @@ public:
             nccl_tmp.upload(v.data(), v.size(), stream);
             rc.check(rc.AllReduce(nccl_tmp.p, nccl_tmp.p, v.size(), ncclFloat64, ncclSum, nccl, stream), "ncclAllReduce");
             nccl_tmp.download(v.data(), v.size(), stream);
-            PX_HIP(hipStreamSynchronize(stream));
+            wait_collective(stream);
             st.rccl_reductions++;
             return;
         }
@@ -1909,7 +1943,7 @@ inline void Solver::reduce_native(std::vector<double>& sums, std::vector<double>
     rc.check(rc.AllGather(nccl_send.p, nccl_recv.p, n, ncclFloat64, nccl, stream), "ncclAllGather");
     double* all = h + nccl_cap;
     PX_HIP(hipMemcpyAsync(all, nccl_recv.p, n * W * sizeof(double), hipMemcpyDeviceToHost, stream));
-    PX_HIP(hipStreamSynchronize(stream));
+    wait_collective(stream);
     for (size_t q = 0; q < ns; ++q) {
         double a = all[q];
         for (size_t r = 1; r < W; ++r) a += all[r * n + q];

@@ -563,7 +563,6 @@ def test_captured_iterate_projection_fixtures(golden_dir):
             assert info["min_eig"] == pytest.approx(mineig, rel=1e-9, abs=1e-10 * np.linalg.norm(x_in))
             assert info["converged"] == int(conv)
     print(kinds)
-    assert kinds["sdplib_mcp124-1__it53"] == "degenerate" or True      # (may also come out tight by luck)
     assert sum(v == "tight" for v in kinds.values()) >= 5
 
 
@@ -613,20 +612,56 @@ def test_maxcut_n1000_objective_matches_oracle_solve(golden_dir):
     assert sol.status == gold["status"] == 1
     assert abs(opt.objective_value() - gold["objval"]) <= 1e-4 * (1 + abs(gold["objval"]))
     assert sol.gap <= 1e-4 and sol.primal_feasible_user_tol
-    assert abs(sol.iter - gold["iter"]) <= 0.25 * gold["iter"]
+    assert sol.iter == gold["iter"]                      # 5921 = 5921 (measured every round since the oracle solve was committed)
+
+
+def _first_departure(T, G, gm, mv, rtol):
+    """first row where the library's trace leaves the oracle's: objective / gap / residual columns beyond rtol, another
+    number of linesearch trials, another target rank or another Lanczos mat-vec count"""
+    m = min(len(T), len(G))
+    sc = np.abs(G[:m, 1:8]).max(axis=0)
+    ok = (np.all(np.abs(T[:m, 1:8] - G[:m, 1:8]) <= rtol * np.abs(G[:m, 1:8]) + 1e-3 * rtol * sc, axis=1)
+          & (T[:m, 11] == G[:m, 11]) & (T[:m, 10] == G[:m, 10]) & (mv[:m] == gm[:m]))
+    return int(np.argmin(ok)) if not ok.all() else m
+
+
+def test_sdplib_500_instances_follow_the_oracle_trace_until_the_degenerate_iterates(golden_dir):
+    """SDPLIB mcp500-1 and gpp500-1 with REFERENCE DEFAULT options (Krylov path) against the oracle's first 400 iterations
+    (tests/golden/trace_sdplib500.json, make_golden_sdplib500_trace.py) -- ADVICE r3: say WHERE the two sides part instead
+    of comparing the end states of two 5000-iteration solves.
+    Measured (round 4, tools/gpurun_ab.py): on mcp500-1 library and oracle agree to 1e-13 (objectives) with identical
+    linesearch trials and Lanczos mat-vec counts for the first 125 iterations; at iteration 126 the truncated projection
+    meets a (near-)repeated eigenvalue at the truncation edge (any orthonormal basis of that
+    eigenspace is a valid KrylovKit answer, the two sides return different ones), the mat-vec counts differ and the
+    trajectories are 1e-3 apart 70 iterations later.  From there on EVERY build is its own trajectory (round 3's and
+    round 4's library, bit-identical to each other, and the oracle): end states are compared only through the solver's
+    own criteria and the literature optimum (next test)."""
+    gold = json.loads((golden_dir / "trace_sdplib500.json").read_text())
+    measured = {"mcp500-1": 125, "gpp500-1": None}
+    for name in ("mcp500-1", "gpp500-1"):
+        g = gold[name]
+        G = np.array(g["rows"]); gm = np.array(g["matvecs"])
+        pr = P.sdplib(golden_dir / "sdplib" / f"{name}.dat-s")
+        sol = Optimizer(max_iter=len(G)).optimize(pr, trace_capacity=len(G))
+        T = sol.trace[:, :12]
+        first = _first_departure(T, G, gm, sol.trace[:, 13], 1e-9)
+        loose = _first_departure(T, G, gm * 0, sol.trace[:, 13] * 0, 1e-6)
+        print(name, "trace + trial counts + mat-vec counts equal to 1e-9 for the first", first, "iterations; to 1e-6 without the mat-vec counts:", loose)
+        assert first >= 100, (name, first)
+        if measured[name] is not None:
+            assert first >= measured[name] - 5
 
 
 def test_sdplib_500_instances_solved_to_tolerance_against_the_oracle_solves(golden_dir):
     """SDPLIB mcp500-1 and gpp500-1 with REFERENCE DEFAULT options (Krylov path), solved to tol 1e-4 by the oracle
-    (tests/golden/make_golden_sdplib500.py: 42 and 9 min of CPU) and by the library.
-    mcp500-1: same status, iterations within 25 % (measured 5086 vs 5182), objective within the solver's own gap
-    measure, the first rank update at the same iteration.
-    gpp500-1 is the instance on which the two sides do NOT end at the same point: the reference's
-    stop rule does not test dual feasibility, primal and dual objective cross on the way down, and the oracle's
-    trajectory ends at such a crossing (iteration 4403, objective 26.89, 6 % above the optimum) while the library's
-    goes on to the literature optimum 25.3205 (7385 iterations).  Asserted: both OPTIMAL by the rule, the first rank
-    update at the same iteration, the library at the literature optimum -- and the oracle's recorded end state, so
-    that the discrepancy stays visible."""
+    (tests/golden/make_golden_sdplib500.py: 42 and 9 min of CPU) and by the library.  Both trajectories leave the
+    oracle's after ~125 iterations (previous test), so the end states are compared through what the solver itself
+    promises: status OPTIMAL by the reference's rule on both sides, the first rank update at the same iteration, the
+    objective inside the stop rule's slack around the literature optimum (mcp500-1 598.15: the rule stops both sides
+    ~1e-3 relative short of it -- oracle 597.13 after 5182 iterations, library 597.15 after 5086; gpp500-1 25.3205: the
+    library reaches it after 7385 iterations, the ORACLE stops at 26.89 after 4403 because the reference's rule does
+    not test dual feasibility and fires where primal and dual objective cross on the way down -- DESIGN.md section 6;
+    recorded, not asserted: it is the oracle's end state, not a property of the library)."""
     gold = json.loads((golden_dir / "solve_sdplib500.json").read_text())
 
     def schedule(sol):
@@ -640,18 +675,17 @@ def test_sdplib_500_instances_solved_to_tolerance_against_the_oracle_solves(gold
     sol = Optimizer().optimize(pr, trace_capacity=20000)
     print("mcp500-1 gpu", sol.status, sol.iter, sol.objval, schedule(sol), "oracle", g["status"], g["iter"], g["objval"], g["rank_schedule"])
     assert sol.status == g["status"] == 1
-    assert abs(sol.iter - g["iter"]) <= 0.25 * g["iter"]
-    assert abs(sol.objval - g["objval"]) <= 1e-4 * (1 + abs(g["objval"]) + abs(g["dual_objval"]))
+    assert sol.gap <= 1e-4 and sol.primal_feasible_user_tol
     assert schedule(sol)[:2] == g["rank_schedule"][:2]
-    assert abs(abs(sol.objval) - 598.15) <= 3.5e-3 * 598.15
+    assert abs(abs(sol.objval) - 598.15) <= 3.5e-3 * 598.15 and abs(abs(g["objval"]) - 598.15) <= 3.5e-3 * 598.15
     g = gold["gpp500-1"]
     pr = P.sdplib(golden_dir / "sdplib" / "gpp500-1.dat-s")
     sol = Optimizer().optimize(pr, trace_capacity=20000)
     print("gpp500-1 gpu", sol.status, sol.iter, sol.objval, schedule(sol), "oracle", g["status"], g["iter"], g["objval"], g["rank_schedule"])
     assert sol.status == g["status"] == 1
+    assert sol.gap <= 1e-4 and sol.primal_feasible_user_tol
     assert schedule(sol)[:2] == g["rank_schedule"][:2]
     assert abs(sol.objval - 25.3205) <= 1e-3 * 25.3205                      # the literature optimum
-    assert g["objval"] > 26.5 and g["iter"] < sol.iter                      # the oracle's trajectory stopped at an objective crossing
 
 
 def test_config4_mimo_8x512_solved_to_tolerance_against_the_oracle_solve(golden_dir):
@@ -669,7 +703,7 @@ def test_config4_mimo_8x512_solved_to_tolerance_against_the_oracle_solve(golden_
     print("gpu", sol.status, sol.iter, sol.objval, sol.stats["lanczos_matvecs"], "oracle", gold["status"], gold["iter"],
           gold["objval"], gold["matvecs"])
     assert sol.status == gold["status"] == 1
-    assert abs(sol.iter - gold["iter"]) <= 0.25 * gold["iter"]
+    assert sol.iter == gold["iter"]                      # 76 = 76
     assert abs(sol.objval - gold["objval"]) <= 1e-4 * (1 + abs(gold["objval"]))
     assert sol.stats["batched_block_steps"] > 0
     m = min(len(T), len(G))
@@ -677,8 +711,7 @@ def test_config4_mimo_8x512_solved_to_tolerance_against_the_oracle_solve(golden_
     first_off = int(np.argmin(close)) if not close.all() else m
     print("traces agree (1e-6, trial counts) for the first", first_off, "of", m, "iterations")
     assert first_off >= 20
-    if sol.iter == gold["iter"]:
-        assert abs(sol.stats["lanczos_matvecs"] - gold["matvecs"]) <= 0.05 * gold["matvecs"]
+    assert abs(sol.stats["lanczos_matvecs"] - gold["matvecs"]) <= 0.05 * gold["matvecs"]
 
 
 @pytest.mark.parametrize("row", [-1, 0])
@@ -1271,7 +1304,7 @@ def test_randsdp_config3_cpu_comparable_size_matches_oracle_trace(golden_dir):
         assert np.array_equal(T[:, 10], G[:, 10]), "target rank"
         same = sol.trace[:, 13] == gm
         print("dense" if dense else "csc", "mat-vec counts equal in", int(same.sum()), "of", iters)
-        assert same.mean() >= 0.95
+        assert same.all(), np.nonzero(~same)[0]            # 200 of 200 (measured on both paths)
         sc = np.abs(G[:, 1:8]).max(axis=0)
         assert np.allclose(T[:60, 1:8], G[:60, 1:8], rtol=1e-7, atol=1e-10 * sc)
         assert np.allclose(T[:, 1:8], G[:, 1:8], rtol=1e-4, atol=1e-6 * sc)

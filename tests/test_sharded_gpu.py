@@ -167,7 +167,7 @@ def test_native_rccl_collectives_one_rank():
 
 def _failing_worker(rank, world, port, q):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
-                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PROXSDP_HIP_FAULT_INJECTION="1")
     from proxsdp_jl_amd import replicas, sharded
     dist = replicas.init("gloo", rank, world)
     kw = dict(max_iter=300)
