@@ -38,8 +38,11 @@ extern "C" {
 #endif
 
 /* 7 (round 3): proxsdp_options gained sign_start_row and general_batch (taken from reserved_i), proxsdp_stats gained
- * sign_short_pass / sign_short_fail (taken from reserved): same struct sizes and offsets as version 6 */
-#define PROXSDP_HIP_ABI_VERSION 7
+ * sign_short_pass / sign_short_fail (taken from reserved): same struct sizes and offsets as version 6
+ * 8 (round 4): proxsdp_options gained full_eig_lanczos_certify (from reserved_i) and full_eig_lanczos_tol (from
+ * reserved_d), proxsdp_stats full_eigs_lanczos_certified / _cert_failed / cert_matvecs (the last reserved slots):
+ * same struct sizes and offsets; debug_fail_iteration now needs PROXSDP_HIP_FAULT_INJECTION=1 */
+#define PROXSDP_HIP_ABI_VERSION 8
 
 /* error codes (negative return values) */
 #define PROXSDP_E_INVALID  (-1)   /* invalid argument / inconsistent problem data */
@@ -298,8 +301,18 @@ typedef struct proxsdp_options {
                                   * candidates evaluated side by side, the first the reference's loop would accept wins;
                                   * per candidate the same arithmetic): -1 auto = 1 = on, 0 = one trial per
                                   * synchronisation (round-2 path) */
-    int32_t reserved_i[3];       /* zero */
-    double  reserved_d[2];       /* zero */
+    int32_t full_eig_lanczos_certify; /* PER-CALL certificate of a Lanczos-served full_eig! (single-vector Lanczos shows one
+                                  * eigenvector per distinct eigenvalue the start vector sees: a repeated positive eigenvalue
+                                  * or a deficient start vector would drop positive pairs from X+): after convergence a
+                                  * second, independent vector is orthogonalised against the returned Ritz vectors and run
+                                  * through m steps of the same recurrence with them locked (Lanczos on the deflated
+                                  * operator); its largest Ritz value must be <= full_eig_lanczos_posres x the spectral
+                                  * scale, otherwise the dense engine projects that input.  -1 auto = 10 steps, 0 = off,
+                                  * m >= 2 = m steps.  The periodic dense check (full_eig_lanczos_verify) stays behind it. */
+    int32_t reserved_i[2];       /* zero */
+    double  full_eig_lanczos_tol;/* convergence of the POSITIVE Ritz pairs of that engine: residual <= tol x the spectral
+                                  * scale; 0 (default) = krylovkit_tol as an absolute residual (KrylovKit's rule) */
+    double  reserved_d[1];       /* zero */
 } proxsdp_options;
 
 #define PROXSDP_TRACE_COLS 14
@@ -360,7 +373,10 @@ typedef struct proxsdp_stats {
     double  host_eig_overlap_time;   /* s: the part of those eigensolves done while the GPU was running the cycle */
     int64_t sign_short_pass;         /* sign-function projections whose shortened schedule passed its test (sign_start_row) */
     int64_t sign_short_fail;         /* ... that failed it and continued with the skipped rows */
-    int64_t reserved[3];
+    int64_t full_eigs_lanczos_certified;  /* Lanczos-served full_eig! calls whose certificate run passed (full_eig_lanczos_certify) */
+    int64_t full_eigs_lanczos_cert_failed;/* ... whose certificate found a positive direction outside the returned pairs: the
+                                           * dense engine projected that input instead */
+    int64_t cert_matvecs;                 /* mat-vecs of those certificate runs (included in lanczos_matvecs) */
 } proxsdp_stats;
 
 /* Result (structs.jl:60-81).  Arrays are caller-allocated with the stated

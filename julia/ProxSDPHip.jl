@@ -113,7 +113,9 @@ struct Stats                     # proxsdp_stats
     host_eig_overlap_time::Float64
     sign_short_pass::Int64
     sign_short_fail::Int64
-    reserved::NTuple{3,Int64}
+    full_eigs_lanczos_certified::Int64
+    full_eigs_lanczos_cert_failed::Int64
+    cert_matvecs::Int64
 end
 
 mutable struct CResult           # proxsdp_result

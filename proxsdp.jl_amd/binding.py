@@ -110,7 +110,8 @@ def _opt_fields():
     a("full_eig_lanczos_verify", i32); a("full_eig_lanczos_posres", f64); a("full_eig_lanczos_kdim10", i32)
     a("sign_small_tile_max", i32); a("host_eig_threads", i32); a("block_threads", i32)
     a("host_eig_merge", i32); a("block_batch", i32); a("rocsolver_warmup", i32); a("debug_fail_iteration", i32); a("host_wait_spin", i32)
-    a("sign_start_row", i32); a("general_batch", i32); a("reserved_i", i32 * 3); a("reserved_d", f64 * 2)
+    a("sign_start_row", i32); a("general_batch", i32); a("full_eig_lanczos_certify", i32); a("reserved_i", i32 * 2)
+    a("full_eig_lanczos_tol", f64); a("reserved_d", f64 * 1)
     return F
 
 
@@ -136,7 +137,7 @@ class Stats(C.Structure):
                 ("batched_block_steps", i64), ("rccl_reductions", i64),
                 ("batched_profiled_blocks", i64), ("host_eig_merges", i64),
                 ("host_eig_overlap_time", f64), ("sign_short_pass", i64), ("sign_short_fail", i64),
-                ("reserved", i64 * 3)]
+                ("full_eigs_lanczos_certified", i64), ("full_eigs_lanczos_cert_failed", i64), ("cert_matvecs", i64)]
 
 
 class Result(C.Structure):
@@ -204,7 +205,7 @@ def lib():
     L.proxsdp_hip_rccl_unique_id.argtypes = [C.c_void_p]
     L.proxsdp_hip_rccl_comm_init.argtypes = [i32, C.c_void_p, i32, i32, C.POINTER(C.c_void_p)]
     L.proxsdp_hip_rccl_comm_destroy.argtypes = [C.c_void_p]
-    if L.proxsdp_hip_abi_version() != 7:
+    if L.proxsdp_hip_abi_version() != 8:
         raise ProxSDPHipError(-1, "ABI version mismatch")
     _lib = L
     return L

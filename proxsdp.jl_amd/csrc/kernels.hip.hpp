@@ -804,6 +804,38 @@ __device__ __forceinline__ void lz_finish_body(const double* __restrict__ wbuf, 
     (void)s_beta;
 }
 
+// measured pass alone: partial dots V[:, 0..k]' w and |w|^2 into a partial-dot buffer (the records lz_finish_body reads),
+// control block cleared.  Used to ORTHOGONALISE A FRESH VECTOR against a set of basis columns (k_lz_measure followed by
+// k_lz_finish gives V[:, k+1] = (w - V V'w) / |.|): the start of the certificate run of a Lanczos-served full_eig!
+// (Solver::lanczos_certificate).  k = -1: no columns, only |w|^2.
+template <int NCH>
+__global__ void __launch_bounds__(TPB)
+k_lz_measure(const double* __restrict__ wbuf, const double* __restrict__ V, int ldv, int k,
+             double* __restrict__ hpart_out, int pld, LanczosCtl* __restrict__ ctl) {
+    constexpr int NC = 16 * NCH;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i = blockIdx.x * LZ_ROWS + lane;
+    const double wp = wbuf[i];
+    double vr[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) vr[c] = (wv + 4 * c <= k) ? V[(long long)(wv + 4 * c) * ldv + i] : 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->stop = 0; ctl->kstop = 0; ctl->carry = 0.0; }
+    if (wv == 0) {
+        const double r = wave_sum(wp * wp);
+        if (lane == 0) hpart_out[(long long)pld * KLD + blockIdx.x] = r;
+    }
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        double t[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) t[c] = vr[16 * ch + c] * wp;
+        const double hs = fold16_all(t, lane);
+        const int jc = wv + 4 * (16 * ch + lane);
+        if (lane < 16 && jc <= k) hpart_out[(long long)blockIdx.x * KLD + jc] = hs;
+    }
+}
+
 template <int NCH>
 __global__ void __launch_bounds__(TPB)
 k_lz_finish(const double* __restrict__ wbuf, int n, double* __restrict__ V, int ldv, int k,

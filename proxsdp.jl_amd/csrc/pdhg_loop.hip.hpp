@@ -359,6 +359,24 @@ inline bool Solver::full_eig_by_lanczos(int idx, const double* xp, double* xo, b
         // moves by a few; a collapse means the Krylov space was fooled (e.g. decoupled coordinates
         // resolved long before the small positive pairs): let the dense solver decide
         if (npos + 2 + W.last_npos / 8 < W.last_npos) break;
+        // per-call certificate (Solver::lanczos_certificate): nothing positive may be left outside the returned pairs
+        const int cert_m = opt.full_eig_lanczos_certify < 0 ? 10 : opt.full_eig_lanczos_certify;
+        if (cert_m >= 2) {
+            double theta = 0.0, cscale = 0.0;
+            if (lanczos_certificate(W, xp, npos, cert_m, theta, cscale)) {
+                const double posres = opt.full_eig_lanczos_posres > 0.0 ? opt.full_eig_lanczos_posres : 1e-7;
+                if (!(theta <= posres * cscale)) {
+                    // a positive direction the run did not see: the dense engine projects this input (intact: the
+                    // reconstruction has not run yet); three failures leave the block to the dense engine for good
+                    W.lst.full_eigs_lanczos_cert_failed++;
+                    if (++W.fel_cert_fails >= 3) W.fel_disabled = true;
+                    if (debug) std::fprintf(stderr, "[proxsdp] certificate failed: block %d iteration %lld theta %.3e scale %.3e npos %d\n",
+                                            idx, (long long)iter, theta, cscale, npos);
+                    break;
+                }
+                W.lst.full_eigs_lanczos_certified++;
+            }
+        }
         int rank = 0;
         for (int i = 0; i < npos; ++i) if (W.vals[i] > opt.tol_psd) ++rank;
         // (values are descending: the positive ones are the first npos)

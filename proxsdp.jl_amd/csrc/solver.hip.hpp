@@ -164,6 +164,7 @@ struct EigWork {
     int64_t N = 0;
     DevBuf<double> V, Z;            // npad x cap each (V: Krylov basis, Z: rotation target / Ritz vectors)
     DevBuf<double> w, Ppart, hpart1, hpart2, hsum1, hred, U, lam, resid, Apart, arrow;
+    DevBuf<double> resid2;           // second, independent start vector: certificate run of a Lanczos-served full_eig!
     int napart = 0;
     PinnedBuf arrow_host;
     const double* arrow_p = nullptr;   // where the kernels read the arrow part: behind U after a restart upload
@@ -204,6 +205,7 @@ struct EigWork {
     LzRun lzrun;                                   // host state of the run in progress (buffers reused across projections)
     long long fel_served = 0;                      // full_eig! calls of this block served by the Lanczos engine
     bool fel_disabled = false;                     // ... switched off after a failed verification (full_eig_lanczos_verify)
+    int fel_cert_fails = 0;                        // failed certificates of this block (full_eig_lanczos_certify)
     // persistent Lanczos cycle kernel (lanczos_cycle.hip.hpp): granule buffers, epoch counter, error word
     DevBuf<double> xg1, xg2, warm_part;
     DevBuf<unsigned> xf1, xf2;
@@ -316,6 +318,8 @@ public:
     void setup_device();
     void alloc_eigwork(EigWork& W, int n, int max_nev);
     void lanczos(EigWork& W, const double* xp, int nev, bool positive_part = false);
+    void lz_launch_step(EigWork& W, const double* xp, int k, int kfirst, double step_tol, bool& presymv);
+    bool lanczos_certificate(EigWork& W, const double* xp, int npos, int msteps, double& theta_max, double& scale);
     void lanczos_batch(const std::vector<int>& blocks, const double* xbase, const std::vector<int>& nevs);
     // batched rotations: U of every block staged in ONE pinned buffer, one upload, one launch (grid.z = block)
     double dbg_batch[5] = {0, 0, 0, 0, 0};         // debug: enqueue | wait | restart logic | flush seconds, cycles
@@ -1078,7 +1082,12 @@ inline bool Solver::lz_after_cycle(EigWork& W, LzRun& R, bool speculated) {
     }
     int converged = 0;
     if (!R.arpack) {
-        while (converged < K && std::fabs(f[converged]) <= tol) ++converged;
+        // (positive-part mode, the library's own algorithm: optionally a residual RELATIVE to the spectral scale,
+        // options.full_eig_lanczos_tol; KrylovKit's rule -- absolute krylovkit_tol -- everywhere else)
+        double tol_c = tol;
+        if (R.positive_part && opt.full_eig_lanczos_tol > 0.0)
+            tol_c = std::max(tol, opt.full_eig_lanczos_tol * std::max(std::fabs(D[0]), std::fabs(D[K - 1])));
+        while (converged < K && std::fabs(f[converged]) <= tol_c) ++converged;
     } else {
         const double eps23 = std::pow(2.220446049250313e-16 / 2.0, 2.0 / 3.0);
         int want = std::min(nev, K);
@@ -1290,6 +1299,132 @@ inline bool Solver::lz_split_first(EigWork& W, LzRun& R, int k1) {
     return ok;
 }
 
+// the launches of Lanczos step k of a cycle that started at basis column kfirst: the mat-vec (on the exact v_k at the
+// start of a cycle, otherwise fused with the closing of step k-1 and run on the uncorrected w') and the
+// recurrence / re-orthogonalisation kernel
+inline void Solver::lz_launch_step(EigWork& W, const double* xp, int k, int kfirst, double step_tol, bool& presymv) {
+            if (k == kfirst) {
+                if (!presymv) launch_symv(W, xp, W.V.p + (size_t)k * W.npad, true);   // v_k is ready (start)
+                else { W.lst.symv_launches++; W.lst.symv_bytes += 8.0 * (double)W.N + 16.0 * (double)W.n; }
+                presymv = false;               // after a restart the mat-vec of v_keep is already in Ppart
+            } else {
+                // close step k-1 and run the mat-vec of step k in one launch
+                launch_symv_finish(W, xp, k - 1, step_tol, k - 1 > kfirst);
+            }
+            // recurrence, predicted correction and the measured full pass in one launch;
+            // the partial-dot buffers alternate by step parity (read k-1, write k)
+            double* hp[2] = {W.hpart1.p, W.hpart2.p};
+            dev::FopArgs fo{};
+            if (W.use_fop) {
+                fo.Vp = W.F.p + (size_t)W.F_first * W.npad; fo.lam = W.Flam.p; fo.rp = W.F_r;
+                fo.tpart = W.tpart.p; fo.ebuf = W.ebuf.p; fo.apart = W.apartf.p;
+            }
+            const int nch = (k + 1 <= 64) ? 1 : (k + 1 <= 128) ? 2 : (k + 1 <= 192) ? 3 : 4;
+            const int nchp = !W.use_fop ? 0 : (W.F_r <= 64 ? 1 : 2);
+            const bool prof_o = opt.profile_symv_every > 0 && (W.lst.symv_launches % opt.profile_symv_every) == 1;
+            size_t oslot = 0;
+            if (prof_o) {
+                if (W.evo.used == W.evo.e0.size()) {
+                    hipEvent_t a, b;
+                    PX_HIP(hipEventCreate(&a)); PX_HIP(hipEventCreate(&b));
+                    W.evo.e0.push_back(a); W.evo.e1.push_back(b);
+                }
+                oslot = W.evo.used++;
+            }
+            auto launch_orth = [&](auto kern) {
+                launch_prof(prof_o, prof_o ? W.evo.e0[oslot] : nullptr, prof_o ? W.evo.e1[oslot] : nullptr, kern,
+                                   dim3(W.nt), stream,
+                                   (const double*)W.Ppart.p, W.nt, W.npad, (const double*)W.V.p, W.npad, k, W.w.p,
+                                   (const double*)W.hred.p, hp[k & 1], W.pld, W.hsum1.p,
+                                   (const dev::LanczosCtl*)W.ctl_p, (const double*)W.alphas_p, (const double*)W.betas_p,
+                                   (const double*)W.Apart.p, W.napart, k == kfirst ? 1 : 0, (const double*)W.arrow_p,
+                                   kfirst, fo);
+            };
+            switch (nch * 3 + nchp) {
+                case 3: launch_orth(dev::k_lz_orth<1, 0>); break;
+                case 4: launch_orth(dev::k_lz_orth<1, 1>); break;
+                case 5: launch_orth(dev::k_lz_orth<1, 2>); break;
+                case 6: launch_orth(dev::k_lz_orth<2, 0>); break;
+                case 7: launch_orth(dev::k_lz_orth<2, 1>); break;
+                case 8: launch_orth(dev::k_lz_orth<2, 2>); break;
+                case 9: launch_orth(dev::k_lz_orth<3, 0>); break;
+                case 10: launch_orth(dev::k_lz_orth<3, 1>); break;
+                case 11: launch_orth(dev::k_lz_orth<3, 2>); break;
+                case 12: launch_orth(dev::k_lz_orth<4, 0>); break;
+                case 13: launch_orth(dev::k_lz_orth<4, 1>); break;
+                default: launch_orth(dev::k_lz_orth<4, 2>); break;
+            }
+}
+
+// Certificate of a Lanczos-served full_eig! (options.full_eig_lanczos_certify).  Single-vector Lanczos
+// returns one eigenvector per DISTINCT eigenvalue the start vector has a component along: a repeated positive eigenvalue or
+// a deficient start vector silently drops positive eigenpairs from X+.  After the run has converged with npos positive
+// pairs (Ritz vectors in W.Z, values in W.vals) a SECOND, independent pseudo-random vector is orthogonalised against them
+// and run through `msteps` steps of the same recurrence with the Ritz vectors as the locked part of the basis (a thick
+// restart whose coupling row is zero): Lanczos on the operator deflated by the returned pairs.  Everything that is left
+// must be <= 0; the largest Ritz value of the msteps x msteps tridiagonal is a LOWER bound of the largest remaining
+// eigenvalue and converges to an isolated one within a few steps.  Returns false when the check could not run (workspace
+// too small, non-finite coefficients); theta_max / scale are what the caller tests.
+inline bool Solver::lanczos_certificate(EigWork& W, const double* xp, int npos, int msteps, double& theta_max, double& scale) {
+    if (npos + msteps + 1 > W.cap || npos + msteps + 1 > dev::KLD || msteps < 2) return false;
+    if (W.resid2.n == 0) {
+        std::vector<double> r2(W.npad, 0.0);
+        start_vector(W.n, (uint64_t)opt.eigsolver_resid_seed ^ 0x9e3779b97f4a7c15ull, 3, r2.data());   // (normalised)
+        W.resid2.alloc(W.npad);
+        W.resid2.upload(r2.data(), W.npad, stream);
+        PX_HIP(hipStreamSynchronize(stream));                       // (r2 goes out of scope)
+    }
+    std::swap(W.V.p, W.Z.p);                                        // the basis buffer holds the Ritz vectors in columns [0, npos)
+    auto nch_of = [](int cols) { return cols <= 64 ? 1 : cols <= 128 ? 2 : cols <= 192 ? 3 : 4; };
+    if (npos == 0) {
+        hipLaunchKernelGGL(dev::k_lz_begin, dim3(ceil_div(W.npad, dev::TPB)), dim3(dev::TPB), 0, stream,
+                           W.V.p, (const double*)W.resid2.p, W.npad, W.ctl_p);
+    } else {
+        // v_npos = (r - Z Z'r) / |.|: measured dots, then the ordinary step closing
+        PX_HIP(hipMemcpyAsync(W.w.p, W.resid2.p, (size_t)W.npad * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        const int kc = npos - 1, nch = nch_of(npos);
+        auto km = nch == 1 ? dev::k_lz_measure<1> : nch == 2 ? dev::k_lz_measure<2> : nch == 3 ? dev::k_lz_measure<3> : dev::k_lz_measure<4>;
+        hipLaunchKernelGGL(km, dim3(W.nt), dim3(dev::TPB), 0, stream, (const double*)W.w.p, (const double*)W.V.p, W.npad, kc,
+                           lz_hpart(W, kc), W.pld, W.ctl_p);
+        auto kf = nch == 1 ? dev::k_lz_finish<1> : nch == 2 ? dev::k_lz_finish<2> : nch == 3 ? dev::k_lz_finish<3> : dev::k_lz_finish<4>;
+        hipLaunchKernelGGL(kf, dim3(W.nt), dim3(dev::TPB), 0, stream, (const double*)W.w.p, W.n, W.V.p, W.npad, kc,
+                           (const double*)lz_hpart(W, kc), W.pld, (const double*)W.hsum1.p, W.alphas_p, W.betas_p, W.ctl_p, 0.0, 0, W.hred.p);
+    }
+    // locked part: coupling row f = 0, Ritz values D (the prediction of k_lz_orth multiplies the measured junk by them)
+    for (int j = 0; j < npos; ++j) { W.arrow_host.p[j] = 0.0; W.arrow_host.p[dev::MAXK + j] = W.vals[j]; }
+    if (npos > 0) {
+        PX_HIP(hipMemcpyAsync(W.arrow.p, W.arrow_host.p, (size_t)npos * sizeof(double), hipMemcpyHostToDevice, stream));
+        PX_HIP(hipMemcpyAsync(W.arrow.p + dev::MAXK, W.arrow_host.p + dev::MAXK, (size_t)npos * sizeof(double), hipMemcpyHostToDevice, stream));
+    }
+    W.arrow_p = W.arrow.p;
+    const int kend = npos + msteps;
+    bool presymv = false;
+    for (int k = npos; k < kend; ++k) lz_launch_step(W, xp, k, npos, 0.0, presymv);
+    {
+        const int nch = nch_of(kend);
+        auto kf = nch == 1 ? dev::k_lz_finish<1> : nch == 2 ? dev::k_lz_finish<2> : nch == 3 ? dev::k_lz_finish<3> : dev::k_lz_finish<4>;
+        hipLaunchKernelGGL(kf, dim3(W.nt), dim3(dev::TPB), 0, stream, (const double*)W.w.p, W.n, W.V.p, W.npad, kend - 1,
+                           (const double*)lz_hpart(W, kend - 1), W.pld, (const double*)W.hsum1.p, W.alphas_p, W.betas_p, W.ctl_p, 0.0,
+                           (kend - 1 > npos) ? 1 : 0, W.hred.p);
+    }
+    PX_HIP(hipMemcpyAsync(W.rec_host, W.rec.p, EigWork::REC_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, stream));
+    wait_stream();
+    std::swap(W.V.p, W.Z.p);
+    W.lst.lanczos_matvecs += msteps; W.mv_iter += msteps; W.lst.cert_matvecs += msteps;
+    const double* al = W.rec_host + npos;
+    const double* be = W.rec_host + dev::MAXK + npos;
+    std::vector<double> T((size_t)msteps * msteps, 0.0), d(msteps, 0.0);
+    for (int j = 0; j < msteps; ++j) {
+        if (!(al[j] == al[j]) || !(be[j] == be[j])) return false;
+        T[(size_t)j * msteps + j] = al[j];
+        if (j + 1 < msteps) T[(size_t)j * msteps + j + 1] = T[(size_t)(j + 1) * msteps + j] = be[j];
+    }
+    if (symeig_dense(msteps, T.data(), d.data(), true) != 0) return false;
+    theta_max = d[msteps - 1];
+    scale = std::max({std::fabs(d[0]), std::fabs(theta_max), npos > 0 ? std::fabs(W.vals[0]) : 0.0});
+    return true;
+}
+
 inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive_part) {
     if (opt.krylovkit_eager && opt.eigsolver != 1 && !positive_part) { lanczos_eager(W, xp, nev); return; }
     LzRun& R = W.lzrun;
@@ -1342,57 +1477,7 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive
             PX_HIP(hipMemcpyAsync(W.cy_err_host.p, W.cy_err.p, sizeof(int), hipMemcpyDeviceToHost, stream));
         } else {
         for (int k = kfirst; k < krylovdim; ++k) {
-            if (k == kfirst) {
-                if (!R.presymv) launch_symv(W, xp, W.V.p + (size_t)k * W.npad, true);   // v_k is ready (start)
-                else { W.lst.symv_launches++; W.lst.symv_bytes += 8.0 * (double)W.N + 16.0 * (double)W.n; }
-                R.presymv = false;             // after a restart the mat-vec of v_keep is already in Ppart
-            } else {
-                // close step k-1 and run the mat-vec of step k in one launch
-                launch_symv_finish(W, xp, k - 1, step_tol, k - 1 > kfirst);
-            }
-            // recurrence, predicted correction and the measured full pass in one launch;
-            // the partial-dot buffers alternate by step parity (read k-1, write k)
-            double* hp[2] = {W.hpart1.p, W.hpart2.p};
-            dev::FopArgs fo{};
-            if (W.use_fop) {
-                fo.Vp = W.F.p + (size_t)W.F_first * W.npad; fo.lam = W.Flam.p; fo.rp = W.F_r;
-                fo.tpart = W.tpart.p; fo.ebuf = W.ebuf.p; fo.apart = W.apartf.p;
-            }
-            const int nch = (k + 1 <= 64) ? 1 : (k + 1 <= 128) ? 2 : (k + 1 <= 192) ? 3 : 4;
-            const int nchp = !W.use_fop ? 0 : (W.F_r <= 64 ? 1 : 2);
-            const bool prof_o = opt.profile_symv_every > 0 && (W.lst.symv_launches % opt.profile_symv_every) == 1;
-            size_t oslot = 0;
-            if (prof_o) {
-                if (W.evo.used == W.evo.e0.size()) {
-                    hipEvent_t a, b;
-                    PX_HIP(hipEventCreate(&a)); PX_HIP(hipEventCreate(&b));
-                    W.evo.e0.push_back(a); W.evo.e1.push_back(b);
-                }
-                oslot = W.evo.used++;
-            }
-            auto launch_orth = [&](auto kern) {
-                launch_prof(prof_o, prof_o ? W.evo.e0[oslot] : nullptr, prof_o ? W.evo.e1[oslot] : nullptr, kern,
-                                   dim3(W.nt), stream,
-                                   (const double*)W.Ppart.p, W.nt, W.npad, (const double*)W.V.p, W.npad, k, W.w.p,
-                                   (const double*)W.hred.p, hp[k & 1], W.pld, W.hsum1.p,
-                                   (const dev::LanczosCtl*)W.ctl_p, (const double*)W.alphas_p, (const double*)W.betas_p,
-                                   (const double*)W.Apart.p, W.napart, k == kfirst ? 1 : 0, (const double*)W.arrow_p,
-                                   kfirst, fo);
-            };
-            switch (nch * 3 + nchp) {
-                case 3: launch_orth(dev::k_lz_orth<1, 0>); break;
-                case 4: launch_orth(dev::k_lz_orth<1, 1>); break;
-                case 5: launch_orth(dev::k_lz_orth<1, 2>); break;
-                case 6: launch_orth(dev::k_lz_orth<2, 0>); break;
-                case 7: launch_orth(dev::k_lz_orth<2, 1>); break;
-                case 8: launch_orth(dev::k_lz_orth<2, 2>); break;
-                case 9: launch_orth(dev::k_lz_orth<3, 0>); break;
-                case 10: launch_orth(dev::k_lz_orth<3, 1>); break;
-                case 11: launch_orth(dev::k_lz_orth<3, 2>); break;
-                case 12: launch_orth(dev::k_lz_orth<4, 0>); break;
-                case 13: launch_orth(dev::k_lz_orth<4, 1>); break;
-                default: launch_orth(dev::k_lz_orth<4, 2>); break;
-            }
+            lz_launch_step(W, xp, k, kfirst, step_tol, R.presymv);
             if (split_cycle && k == k1) {
                 // alphas / betas up to step k1 - 1 are final: copy them out on the side stream while the cycle runs on
                 PX_HIP(hipEventRecord(W.ev_mid, stream));
@@ -1906,22 +1991,31 @@ inline void Solver::run_blocks(const std::vector<int>& blocks, const std::functi
     merge_block_stats();
 }
 inline void Solver::merge_block_stats() {
+    // per-block counters (filled on the blocks' own threads) into the solver's; one line per field
+#define PX_MERGE(f) st.f += a.f
     for (EigWork& W : eig) {
         proxsdp_stats& a = W.lst;
-        st.lanczos_matvecs += a.lanczos_matvecs; st.lanczos_restarts += a.lanczos_restarts;
-        st.lanczos_calls += a.lanczos_calls; st.full_eigs += a.full_eigs;
-        st.krylov_fallbacks += a.krylov_fallbacks; st.symv_launches += a.symv_launches;
-        st.symv_profiled += a.symv_profiled; st.symv_profiled_ms += a.symv_profiled_ms;
-        st.orth_profiled += a.orth_profiled; st.orth_profiled_ms += a.orth_profiled_ms;
-        st.full_eig_solver_ms += a.full_eig_solver_ms; st.full_eig_recon_ms += a.full_eig_recon_ms;
-        st.full_eigs_lanczos += a.full_eigs_lanczos; st.full_eigs_sign += a.full_eigs_sign; st.sign_products += a.sign_products; st.sign_short_pass += a.sign_short_pass; st.sign_short_fail += a.sign_short_fail; st.sign_engine_projections += a.sign_engine_projections; st.sign_engine_rejected += a.sign_engine_rejected; st.sign_engine_checks += a.sign_engine_checks; st.sign_engine_mismatches += a.sign_engine_mismatches; st.full_eigs_lanczos_checks += a.full_eigs_lanczos_checks; st.full_eigs_lanczos_mismatches += a.full_eigs_lanczos_mismatches; st.batched_block_steps += a.batched_block_steps; st.host_eig_merges += a.host_eig_merges; st.host_eig_overlap_time += a.host_eig_overlap_time; st.warm_starts += a.warm_starts; st.device_eigs += a.device_eigs; st.mfma_reconstructions += a.mfma_reconstructions; st.cycle_launches += a.cycle_launches;
-        st.cycle_steps += a.cycle_steps; st.cycle_ms += a.cycle_ms;
-        st.symv_bytes += a.symv_bytes; st.host_eig_time += a.host_eig_time; st.host_eigs += a.host_eigs;
-        st.fop_projections += a.fop_projections;
+        PX_MERGE(lanczos_matvecs); PX_MERGE(lanczos_restarts); PX_MERGE(lanczos_calls);
+        PX_MERGE(full_eigs); PX_MERGE(krylov_fallbacks);
+        PX_MERGE(symv_launches); PX_MERGE(symv_bytes);
+        PX_MERGE(symv_profiled); PX_MERGE(symv_profiled_ms);
+        PX_MERGE(orth_profiled); PX_MERGE(orth_profiled_ms);
+        PX_MERGE(full_eig_solver_ms); PX_MERGE(full_eig_recon_ms);
+        PX_MERGE(full_eigs_lanczos); PX_MERGE(full_eigs_lanczos_checks); PX_MERGE(full_eigs_lanczos_mismatches);
+        PX_MERGE(full_eigs_lanczos_certified); PX_MERGE(full_eigs_lanczos_cert_failed); PX_MERGE(cert_matvecs);
+        PX_MERGE(full_eigs_sign); PX_MERGE(sign_products); PX_MERGE(sign_short_pass); PX_MERGE(sign_short_fail);
+        PX_MERGE(sign_engine_projections); PX_MERGE(sign_engine_rejected);
+        PX_MERGE(sign_engine_checks); PX_MERGE(sign_engine_mismatches);
+        PX_MERGE(batched_block_steps);
+        PX_MERGE(host_eigs); PX_MERGE(host_eig_time); PX_MERGE(host_eig_merges); PX_MERGE(host_eig_overlap_time);
+        PX_MERGE(warm_starts); PX_MERGE(device_eigs); PX_MERGE(mfma_reconstructions);
+        PX_MERGE(cycle_launches); PX_MERGE(cycle_steps); PX_MERGE(cycle_ms);
+        PX_MERGE(fop_projections);
         a = proxsdp_stats{};
         lz_matvec_iter += W.mv_iter; recon_r_iter += W.recon_r;
         W.mv_iter = 0; W.recon_r = 0;
     }
+#undef PX_MERGE
 }
 
 // scalar reduce of a block-sharded solve over RCCL: every rank's packed record [sums | maxs] is all-gathered on the

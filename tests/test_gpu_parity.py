@@ -629,15 +629,16 @@ def test_sdplib_500_instances_follow_the_oracle_trace_until_the_degenerate_itera
     """SDPLIB mcp500-1 and gpp500-1 with REFERENCE DEFAULT options (Krylov path) against the oracle's first 400 iterations
     (tests/golden/trace_sdplib500.json, make_golden_sdplib500_trace.py) -- ADVICE r3: say WHERE the two sides part instead
     of comparing the end states of two 5000-iteration solves.
-    Measured (round 4, tools/gpurun_ab.py): on mcp500-1 library and oracle agree to 1e-13 (objectives) with identical
-    linesearch trials and Lanczos mat-vec counts for the first 125 iterations; at iteration 126 the truncated projection
+    Measured (round 4, tools/gpurun_ab.py): on mcp500-1 library and oracle agree to 1e-13 (objectives; all seven trace
+    columns to 1e-9 for 117 iterations) with identical linesearch trials and Lanczos mat-vec counts for the first 125
+    iterations; at iteration 126 the truncated projection
     meets a (near-)repeated eigenvalue at the truncation edge (any orthonormal basis of that
     eigenspace is a valid KrylovKit answer, the two sides return different ones), the mat-vec counts differ and the
     trajectories are 1e-3 apart 70 iterations later.  From there on EVERY build is its own trajectory (round 3's and
     round 4's library, bit-identical to each other, and the oracle): end states are compared only through the solver's
     own criteria and the literature optimum (next test)."""
     gold = json.loads((golden_dir / "trace_sdplib500.json").read_text())
-    measured = {"mcp500-1": 125, "gpp500-1": None}
+    measured = {"mcp500-1": 117, "gpp500-1": None}
     for name in ("mcp500-1", "gpp500-1"):
         g = gold[name]
         G = np.array(g["rows"]); gm = np.array(g["matvecs"])
@@ -792,6 +793,9 @@ def test_maxcut_n2000_solve_matches_oracle_through_the_implicit_full_eig_regime(
     assert sol.iter == gold["iter"]
     assert sol.stats["full_eigs"] == gold["full_eigs"] and sol.stats["full_eigs_lanczos"] >= gold["full_eigs"] - 5
     assert sol.stats["full_eigs_lanczos_mismatches"] == 0
+    # every Lanczos-served call carried its certificate (deflated 10-step run): none failed
+    assert sol.stats["full_eigs_lanczos_cert_failed"] == 0
+    assert sol.stats["full_eigs_lanczos_certified"] == sol.stats["full_eigs_lanczos"]
     assert abs(opt.objective_value() - gold["objval"]) <= 1e-6 * (1 + abs(gold["objval"]))
     assert sol.final_rank == gold["final_rank"]
 
@@ -1630,13 +1634,60 @@ def test_lanczos_served_full_eig_is_verified_against_the_dense_engine(n):
     # the hazard, unverified: two positive eigenpairs are lost
     o = B.default_options()
     B.set_option(o, "full_eig_lanczos_verify", 0)
+    B.set_option(o, "full_eig_lanczos_certify", 0)   # (the per-call certificate has its own test below)
     raw, info0 = B.psd_project(svec(X), n, len(top), mode=2, options=o, resid=deficient)
     assert info0["fell_back"] == 0 and info0["rank"] == len(top) - 2
     assert abs(np.abs(raw - ref).max() - 7.0) <= 1e-9
-    # verified (the default): the dense engine's projection is returned
-    out, info = B.psd_project(svec(X), n, len(top), mode=2, resid=deficient)
+    # verified by the dense engine (first call of a block): its projection is returned
+    o = B.default_options()
+    B.set_option(o, "full_eig_lanczos_certify", 0)
+    out, info = B.psd_project(svec(X), n, len(top), mode=2, options=o, resid=deficient)
     assert info["fell_back"] == 1 and info["rank"] == len(top) and info["min_eig"] == 0.0
     assert np.abs(out - ref).max() <= 1e-9 * 9.0
+
+
+def test_lanczos_served_full_eig_is_certified_on_every_call():
+    """the dense check of the previous test runs on the first call and every 256th after it; the
+    CERTIFICATE (options.full_eig_lanczos_certify, default on) runs on EVERY call: a second, independent vector is
+    orthogonalised against the returned Ritz vectors and pushed through 10 steps of the same recurrence with them locked
+    -- Lanczos on the deflated operator -- and its largest Ritz value must not be positive.  Exact hazards: an eigenvalue
+    5 of MULTIPLICITY 3 on coordinates the start vector sees only one of (a single-vector Krylov space contains one
+    eigenvector per distinct eigenvalue: two copies are lost) plus an eigenvalue 7 it does not see at all.  With the
+    periodic dense check switched off: the uncertified engine returns a projection that lacks 7 and two copies of 5;
+    the certified one detects it and hands the input to the dense engine.  A generic start vector passes."""
+    n = 257
+    rng = np.random.default_rng(11)
+    lam = -rng.uniform(0.5, 3.0, n)
+    top = [9.0, 7.0, 5.0, 5.0, 5.0, 3.0, 1.0]
+    lam[:len(top)] = top
+    X = np.diag(lam)
+    ref = svec(np.diag(np.maximum(lam, 0.0)))
+    generic = rng.standard_normal(n)
+    deficient = generic.copy()
+    deficient[[1, 3, 4]] = 0.0                       # lambda = 7 and two of the three copies of lambda = 5
+    o = B.default_options()
+    B.set_option(o, "full_eig_lanczos_verify", 0)
+    B.set_option(o, "full_eig_lanczos_certify", 0)
+    # (previous positive count = 4 = what the deficient Krylov space can see: the count-collapse guard stays quiet)
+    raw, info0 = B.psd_project(svec(X), n, len(top) - 3, mode=2, options=o, resid=deficient)
+    assert info0["fell_back"] == 0 and info0["rank"] == len(top) - 3          # the hazard: three positive pairs dropped
+    assert abs(np.abs(raw - ref).max() - 7.0) <= 1e-9
+    o = B.default_options()
+    B.set_option(o, "full_eig_lanczos_verify", 0)    # certificate alone (default: 10 steps)
+    out, info = B.psd_project(svec(X), n, len(top) - 3, mode=2, options=o, resid=deficient)
+    assert info["fell_back"] == 1 and info["rank"] == len(top)
+    assert np.abs(out - ref).max() <= 1e-9 * 9.0
+    out, info = B.psd_project(svec(X), n, len(top), mode=2, options=o, resid=generic)
+    assert info["fell_back"] == 0 and info["rank"] == len(top)               # nothing left outside the returned pairs
+    assert np.abs(out - ref).max() <= 1e-9 * 9.0
+    # a repeated eigenvalue in a GENERIC basis and a dense matrix: certificate passes or fails, the result is right either way
+    Qm, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    Xd = (Qm * lam) @ Qm.T
+    Xd = (Xd + Xd.T) / 2
+    w, V = np.linalg.eigh(Xd)
+    refd = svec((V * np.maximum(w, 0.0)) @ V.T)
+    out, info = B.psd_project(svec(Xd), n, len(top), mode=2, options=o)
+    assert np.abs(out - refd).max() <= 1e-8 * 9.0 and info["rank"] == len(top)
 
 
 def test_final_rank_of_the_sign_path_is_bounded_against_the_reference_count():

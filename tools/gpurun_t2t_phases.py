@@ -14,7 +14,7 @@ from proxsdp_jl_amd import problems as P
 from proxsdp_jl_amd.optimizer import Optimizer
 
 KEYS = ("lanczos_matvecs", "lanczos_restarts", "lanczos_calls", "full_eigs", "full_eigs_lanczos", "full_eigs_lanczos_checks",
-        "full_eigs_sign", "sign_products", "host_eigs", "host_eig_merges", "host_eig_time", "host_eig_overlap_time",
+        "full_eigs_lanczos_certified", "full_eigs_lanczos_cert_failed", "cert_matvecs", "full_eigs_sign", "sign_products", "host_eigs", "host_eig_merges", "host_eig_time", "host_eig_overlap_time",
         "linesearch_trials", "loop_time", "t_primal", "t_psd", "t_linesearch", "t_residual", "warm_starts")
 n = int(os.environ.get("T2T_N", "4000"))
 extra = {}
