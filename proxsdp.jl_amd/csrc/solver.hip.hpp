@@ -1113,6 +1113,9 @@ inline bool Solver::lz_after_cycle(EigWork& W, LzRun& R, bool speculated) {
         if (K < krylovdim) return false;                 // invariant subspace without convergence (arpack rule)
     }
     if (R.numiter == R.maxiter) return false;
+    // (positive-part mode, measured in round 4 on the default-options n = 4000 solve, tools/gpurun_r04_pp.sh: Krylov
+    // dimension 4g / 5g instead of 3g + 8 and a kept part of positives + 25 % / 40 % of the rest all land within
+    // -3 % .. +11 % of this rule's 12.4 s with the same 8651 iterations -- the rule stays)
     const int keep = R.arpack ? std::min(krylovdim - 1, nev + std::max(1, (krylovdim - nev) / 2))
                               : (3 * krylovdim + 2 * converged) / 5;
     // arrow part of the restarted T for k_lz_orth: f (couplings of v_K with the kept Ritz
