@@ -236,7 +236,7 @@ typedef struct proxsdp_options {
     int32_t full_eig_sign;       /* full_eig! of a dense block without an eigendecomposition: X+ = (X + X sign(X)) / 2
                                   * with sign(X) from an odd-polynomial iteration of fp64 MFMA products (34 .. 64 products of
                                   * n x n symmetric matrices, see sign_start_row; every |eigenvalue| >= 1e-10 ||X|| is resolved to 1e-15,
-                                  * smaller ones contribute an error <= their own size): -1 auto (33 <= n <= 4096 and
+                                  * smaller ones contribute an error <= their own size): -1 auto (33 <= n <= 16384 with HBM for the work matrices, and
                                   * every requested tolerance >= 1e-8: below that the 1e-10 floor of this path could
                                   * stall a solve, and the dense eigensolver is used), 1 always, 0 = rocSOLVER dsyevd +
                                   * reconstruction */

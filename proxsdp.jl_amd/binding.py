@@ -509,7 +509,8 @@ def reconstruct(Z, lam, n, repeat=0, mfma=-1):
 
 def full_eig_kernel(packed, n, sign=1, repeat=1):
     """full_eig! of one packed block on device-resident data: (X+ packed, ms per call, rank, products per call).
-    sign: 0 rocSOLVER dsyevd, 1 sign-function projection (default sign_start_row), 100 + k: sign_start_row = k"""
+    sign: 0 rocSOLVER dsyevd, 1 sign-function projection (default sign_start_row), 100 + k: sign_start_row = k,
+    -1: the solver's automatic engine choice (full_eig_sign = -1)"""
     L = lib()
     xin = _f(packed)
     out = np.zeros(n * (n + 1) // 2)

@@ -234,7 +234,7 @@ int proxsdp_hip_full_eig_kernel(const double* packed_in, int64_t n, int32_t sign
     return guarded([&]() -> int {
         if (!packed_in || !packed_out) throw std::invalid_argument("NULL buffer");
         proxsdp_options o = Engine::fix(nullptr);
-        o.full_eig_decomp = 1; o.full_eig_lanczos = 0; o.full_eig_sign = sign ? 1 : 0;
+        o.full_eig_decomp = 1; o.full_eig_lanczos = 0; o.full_eig_sign = sign < 0 ? -1 : (sign ? 1 : 0);   // (-1: the solver's own choice of engine)
         if (sign >= 100) o.sign_start_row = sign - 100;
         Engine E(&o, n, 2);
         proxsdp::Solver& S = E.S;

@@ -490,9 +490,9 @@ lz_orth_body(const double* __restrict__ Ppart, int nt, int npad, const double* _
     double vrp[NCP], tp[16][NLP], eb = 0.0, ap = 0.0; // operator form: Vp columns, Vp'v partials, (E v)_i, v'Ev partials
     if constexpr (NCHP == 0) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) pv[u] = Ppart[(long long)min(wv + u * NWAVE, nt - 1) * npad + i];
+        for (int u = 0; u < 16; ++u) pv[u] = (wv + u * NWAVE < nt) ? Ppart[(long long)(wv + u * NWAVE) * npad + i] : 0.0;   // (uniform test)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) av[u] = Apart[min((int)threadIdx.x + u * TPB, napart - 1)];
+        for (int u = 0; u < 8; ++u) av[u] = (u * TPB < napart) ? Apart[min((int)threadIdx.x + u * TPB, napart - 1)] : 0.0;
     } else {
         const int gl0 = min(lane, pld - 1);
 #pragma unroll
@@ -505,7 +505,8 @@ lz_orth_body(const double* __restrict__ Ppart, int nt, int npad, const double* _
         for (int u = 0; u < 16; ++u) {
             const long long rec = (long long)min(wv + NWAVE * u, pld - 1) * RLD;
 #pragma unroll
-            for (int ch = 0; ch < NLP; ++ch) tp[u][ch] = (ch == 0 || 64 * ch < fo.rp) ? fo.tpart[rec + 64 * ch + lane] : 0.0;
+            for (int ch = 0; ch < NLP; ++ch)
+                tp[u][ch] = ((ch == 0 || 64 * ch < fo.rp) && (wv + NWAVE * u < nt || pld > WAVE)) ? fo.tpart[rec + 64 * ch + lane] : 0.0;
         }
         eb = fo.ebuf[i];
         ap = fo.apart[gl0];
@@ -697,7 +698,8 @@ __device__ __forceinline__ void lz_finish_body(const double* __restrict__ wbuf, 
                                                double* __restrict__ betas, LanczosCtl* __restrict__ ctl,
                                                double tol, int use_carry, int g,
                                                double* __restrict__ s_h, double* __restrict__ s_d,
-                                               double* __restrict__ s_beta, double* __restrict__ hred) {
+                                               double* __restrict__ s_beta, double* __restrict__ hred,
+                                               int nprod /* workgroups that wrote a record (the rest are zero) */) {
     constexpr int NC = 16 * NCH;
     __shared__ double s_p[NWAVE * 4 * 64 * NCH];         // per-wave group sums of the producers' records, [wave][group][column]
     const int lane = threadIdx.x & 63;
@@ -714,7 +716,8 @@ __device__ __forceinline__ void lz_finish_body(const double* __restrict__ wbuf, 
         const long long rec = (long long)min(wv + NWAVE * u, pld - 1) * KLD;
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch)
-            hp[u][ch] = (ch == 0 || 64 * ch < kk) ? hpart_in[rec + 64 * ch + lane] : 0.0;   // (uniform test: whole chunks beyond k are skipped)
+            hp[u][ch] = ((ch == 0 || 64 * ch < kk) && (wv + NWAVE * u < nprod || pld > WAVE))          // (uniform tests: chunks beyond k and
+                            ? hpart_in[rec + 64 * ch + lane] : 0.0;                                        // records nobody wrote are not loaded)
     }
     // the wave's basis columns j = wv + 4c: groups of four, groups beyond column k are not loaded
     double vr[NC];
@@ -845,7 +848,8 @@ k_lz_finish(const double* __restrict__ wbuf, int n, double* __restrict__ V, int 
     __shared__ double s_h[64 * NCH + 1];
     __shared__ double s_d[NWAVE * LZ_ROWS];
     __shared__ double s_beta;
-    lz_finish_body<NCH>(wbuf, V, ldv, k, hpart_in, pld, h1, alphas, betas, ctl, tol, use_carry, blockIdx.x, s_h, s_d, &s_beta, hred);
+    lz_finish_body<NCH>(wbuf, V, ldv, k, hpart_in, pld, h1, alphas, betas, ctl, tol, use_carry, blockIdx.x, s_h, s_d, &s_beta, hred,
+                        (int)gridDim.x);
 }
 
 // The step-closing work of step k and the mat-vec of step k+1 in ONE launch.
@@ -867,7 +871,7 @@ k_symv_finish(const double* __restrict__ xp, int n, int nt, int npad, double* __
     __shared__ double s_beta;
     if ((int)blockIdx.x < nt)
         lz_finish_body<NCH>(wbuf, V, ldv, k, hpart_in, pld, h1, alphas, betas, ctl, tol, use_carry, blockIdx.x,
-                            s_a, s_b, &s_beta, hred);
+                            s_a, s_b, &s_beta, hred, nt);
     else if (ctl->stop) return;
     else
         symv_tiles(xp, n, npad, nt * (nt + 1) / 2, wbuf, Ppart, (int)blockIdx.x - nt, (int)gridDim.x - nt, s_a, s_b, Apart);
@@ -924,7 +928,7 @@ k_lzb_mv(LzBatch B) {
         if (mode == 1) return;
         const int kc = b.k - 1;
         lz_finish_body<1>(b.wbuf, b.V, B.npad, kc, (kc & 1) ? b.hpart2 : b.hpart1, B.pld, b.hsum, b.alphas, b.betas, b.ctl,
-                          B.tol, kc > b.keep ? 1 : 0, blockIdx.x, s_a, s_b, &s_beta, b.hred);
+                          B.tol, kc > b.keep ? 1 : 0, blockIdx.x, s_a, s_b, &s_beta, b.hred, nt);
     } else {
         if (mode == 3 || b.ctl->stop) return;
         const double* v = (mode == 1) ? b.V + (long long)b.k * B.npad : b.wbuf;
@@ -1075,7 +1079,7 @@ k_fop_finish(const double* __restrict__ wbuf, double* __restrict__ V, int ldv, i
     __shared__ double s_beta;
     if ((int)blockIdx.x < nt) {
         lz_finish_body<NCH>(wbuf, V, ldv, k, hpart_in, pld, h1, alphas, betas, ctl, tol, use_carry, blockIdx.x,
-                            s_a, s_b, &s_beta, hred);
+                            s_a, s_b, &s_beta, hred, nt);
     } else {
         fop_body<NCHP>(wbuf, Vp, ldv, rp, ell_col, ell_sidx, ell_w, npad, esv, tpart, pld, ebuf, apart,
                        (int)blockIdx.x - nt, s_b, ctl, ov, k + 1);

@@ -226,7 +226,7 @@ inline bool Solver::exact_projection_by_sign(int idx, const double* xp, double* 
     if (opt.psd_sign_engine != 1) return false;
     EigWork& W = eig[idx];
     W.sign_check_pending = false;                                         // (a verification whose Lanczos half fell back)
-    if (W.n < 33 || W.n > 4096) return false;
+    if (W.n < 33 || W.n > 16384) return false;
     if (W.kry_ms < 0.0 || W.last_npos < 0) return false;                  // no Lanczos measurement of this block yet
     if (W.last_npos >= nev) return false;                                 // truncation was active last time: the reference's engine decides
     if (W.sign_backoff > 0) { --W.sign_backoff; return false; }           // after a rejected attempt

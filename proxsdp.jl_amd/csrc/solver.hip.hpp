@@ -1746,7 +1746,15 @@ inline bool Solver::full_eig_by_sign(int idx, const double* xp_in, double* xp_ou
     const int n = W.n;
     if (!force) {
         if (opt.full_eig_sign == 0) return false;
-        if (opt.full_eig_sign < 0 && (n < 33 || n > 4096)) return false;     // auto: measured window
+        // auto: from side 33 on (below: the batched Jacobi kernel / rocSOLVER are faster), up to the side whose five
+        // padded work matrices fit comfortably (side 16384: 10.7 GB; the cap was 4096 until round 4 -- maxG55 / maxG60,
+        // sides 5000 / 7000, fell to rocSOLVER's dsyevd at ~0.2 % of the fp64 peak) and while HBM has room for them
+        if (opt.full_eig_sign < 0 && (n < 33 || n > 16384)) return false;
+        if (opt.full_eig_sign < 0 && W.sg_ld != W.nt * dev::TILE) {
+            size_t free_b = 0, total_b = 0;
+            const size_t need = (size_t)6 * (size_t)(W.nt * dev::TILE) * (size_t)(W.nt * dev::TILE) * sizeof(double);
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need) return false;
+        }
         // auto: X+ carries an absolute error of up to ~1e-10 x the spectral scale on this path (l_0 of the
         // iteration): users who ask for tolerances near that floor get the LAPACK-accurate dense eigensolver
         if (opt.full_eig_sign < 0 && std::min({opt.tol_gap, opt.tol_feasibility, opt.tol_primal, opt.tol_dual}) < 1e-8) return false;

@@ -1455,6 +1455,24 @@ def test_sign_function_projection_on_64_tiles_large_block():
         assert info["rank"] == int((w > 0).sum())
 
 
+def test_sign_function_projection_beyond_side_4096_in_auto_mode():
+    """the auto window of full_eig_sign ended at side 4096, so full_eig! of maxG55 / maxG60-sized
+    blocks (5000 / 7000) fell to rocSOLVER's dsyevd (~0.2 % of the fp64 peak).  The window now ends at 16384 (with a
+    free-memory check): n = 4600 through the full_eig! test entry with the solver's AUTOMATIC engine choice, against
+    LAPACK; the product count says which engine ran."""
+    n = 4600
+    rng = np.random.default_rng(3)
+    Z = rng.standard_normal((n, 50)); M = rng.standard_normal((n, n)) * 0.03
+    X = Z @ Z.T - (M @ M.T)
+    w, V = np.linalg.eigh(X)
+    ref = (V * np.maximum(w, 0.0)) @ V.T
+    out, ms, rank, products = B.full_eig_kernel(svec(X), n, sign=-1)
+    print("n", n, "auto engine:", products, "products,", round(ms, 1), "ms per projection")
+    assert products >= 30                                          # the MFMA sign iteration ran, not dsyevd
+    assert np.abs(out - svec(ref)).max() <= 1e-9 * np.abs(w).max()
+    assert rank == int((w > 0).sum())
+
+
 def test_sign_engine_on_the_krylov_branch_reproduces_the_lanczos_solve(golden_dir):
     """psd_sign_engine = 1: when fewer than target_rank eigenvalues are positive, the truncated projection of
     prox_operators.jl:89-109 IS the exact one and min_eig <= 0, so the sign-function projection may replace the
