@@ -12,7 +12,7 @@ synchronisation.  The whole call is bracketed by barrier + cuda.synchronize.
 The problem is uploaded before the loop starts (inputs resident in HBM).
 
 N > 1: the single-PSD-block path does not shard (SURVEY.md section 8e,
-DESIGN.md section 7) -> N independent replicas (seed = rank), no data-path
+DESIGN.md section 8) -> N independent replicas (seed = rank), no data-path
 collective, scaling "weak"; value = total iterations of all ranks / max time.
 `python bench.py --gpus N` with no launcher in the environment starts the N
 ranks itself (torch.distributed.run, rendezvous on 127.0.0.1); under a launcher

@@ -96,7 +96,7 @@ typedef struct proxsdp_problem {
      * uses its own counter-based generator (csrc/host_util.hpp, mirrored in
      * oracle/eig.py:start_vector). */
     const double* eig_resid;
-    /* optional block-sharded solve (multi-GPU, one process per GPU; DESIGN.md section 7).
+    /* optional block-sharded solve (multi-GPU, one process per GPU; DESIGN.md section 8).
      * When reduce_fn != NULL this problem is ONE SHARD of a block-diagonal model (its PSD
      * blocks/variables and the constraint rows that touch only them).  The library calls
      *     reduce_fn(reduce_ctx, sums, nsum, maxs, nmax)
@@ -344,7 +344,7 @@ typedef struct proxsdp_stats {
     int64_t exit_matvecs;        /* mat-vecs of the exit path's lambda_min(dual cone) Lanczos   */
     double  host_eig_time;       /* s: K x K Rayleigh-quotient eigensolves done on the HOST     */
     int64_t host_eigs;           /* how many of them                                            */
-    int64_t device_eigs;         /* unused (0): a device-side K x K eigensolver was measured and dropped, DESIGN.md section 8 */
+    int64_t device_eigs;         /* unused (0): a device-side K x K eigensolver was measured and dropped, DESIGN.md section 9 */
     int64_t batched_small_eigs;  /* small-block (n <= 32) projections done by the batched Jacobi kernel */
     int64_t mfma_reconstructions;/* reconstructions that took the MFMA (v_mfma_f64_16x16x4) SYRK */
     int64_t orth_profiled;       /* k_lz_orth launches bracketed by events (profile_symv_every)  */

@@ -1639,7 +1639,7 @@ inline void Solver::run() {
             st.t_residual += now_s() - tl1;
             }
         }
-        {   // algorithmic bytes of this iteration (DESIGN.md section 5, SURVEY.md section 8d)
+        {   // algorithmic bytes of this iteration (DESIGN.md section 6, SURVEY.md section 8d)
             const double t = (double)last_trials;
             double bb = 8.0 * (double)P.n * (11.0 + 3.0 * t) + 12.0 * (double)P.nnz * (1.0 + t) +
                         8.0 * (double)P.Q * (8.0 + 6.0 * t);

@@ -1,6 +1,6 @@
 // RCCL entry points, loaded at run time (dlopen): the library does not LINK librccl, a process that never
 // hands over a communicator never loads it, and a box without RCCL can still run single-GPU solves.
-// Used by the block-sharded solve (DESIGN.md section 7, SURVEY.md section 8e): the packed scalar record of
+// Used by the block-sharded solve (DESIGN.md section 8, SURVEY.md section 8e): the packed scalar record of
 // every PDHG iteration and the coupling rows of M x are reduced by the library itself, on its own stream,
 // over the communicator the caller created (proxsdp_problem.nccl_comm) -- xGMI, no host callback.
 #pragma once

@@ -856,7 +856,7 @@ inline void Solver::launch_reconstruct(EigWork& W, const double* Z, int ldz, con
                                        const double* xp_old, int blk) {
     const int ntile = 8 * ceil_div(W.nt * (W.nt + 1) / 2, 8);     // padded to the 8 XCDs (xcd_tile)
     // fp64 MFMA SYRK from rank 16 on in auto mode (measured cross-over at n = 4000: equal at 12-16,
-    // 1.17x at 26, 1.32x at 63, 1.7x at n/2)
+    // 1.17x at 26, 1.32x at 63, 1.7x at n/2; docs/DESIGN_history_r1_r3.md section 5)
     const bool mfma = opt.reconstruct_mfma == 1 || (opt.reconstruct_mfma < 0 && r >= 16);
     if (mfma) {
         W.lst.mfma_reconstructions++;

@@ -1,4 +1,4 @@
-"""Multi-GPU plumbing for the paths that do not shard (DESIGN.md section 7).
+"""Multi-GPU plumbing for the paths that do not shard (DESIGN.md section 8).
 
 Every benchmarked BASELINE config has ONE PSD block, and a single block does not
 shard: N GPUs run N independent solves ("replicas only"),

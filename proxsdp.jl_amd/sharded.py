@@ -1,5 +1,5 @@
 """Block-sharded solve of a block-diagonal model: one process per GPU, GPU g owns the PSD
-blocks assigned to it and the constraint rows that touch only them (DESIGN.md section 7,
+blocks assigned to it and the constraint rows that touch only them (DESIGN.md section 8,
 SURVEY.md section 8e).  The reference processes the blocks of a model serially on one core
 (/root/reference/src/prox_operators.jl:40); here every shard runs the full PDHG loop on
 its own blocks and the shards exchange only scalars (linesearch norms, residual maxima,

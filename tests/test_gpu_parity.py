@@ -632,7 +632,7 @@ def test_sdplib_500_instances_follow_the_oracle_trace_until_the_degenerate_itera
     Measured (round 4, tools/gpurun_ab.py): on mcp500-1 library and oracle agree to 1e-13 (objectives; all seven trace
     columns to 1e-9 for 117 iterations) with identical linesearch trials and Lanczos mat-vec counts for the first 125
     iterations; at iteration 126 the truncated projection
-    meets a (near-)repeated eigenvalue at the truncation edge (DESIGN.md section 6: any orthonormal basis of that
+    meets a (near-)repeated eigenvalue at the truncation edge (DESIGN.md section 7: any orthonormal basis of that
     eigenspace is a valid KrylovKit answer, the two sides return different ones), the mat-vec counts differ and the
     trajectories are 1e-3 apart 70 iterations later.  From there on EVERY build is its own trajectory (round 3's and
     round 4's library, bit-identical to each other, and the oracle): end states are compared only through the solver's
@@ -661,7 +661,7 @@ def test_sdplib_500_instances_solved_to_tolerance_against_the_oracle_solves(gold
     objective inside the stop rule's slack around the literature optimum (mcp500-1 598.15: the rule stops both sides
     ~1e-3 relative short of it -- oracle 597.13 after 5182 iterations, library 597.15 after 5086; gpp500-1 25.3205: the
     library reaches it after 7385 iterations, the ORACLE stops at 26.89 after 4403 because the reference's rule does
-    not test dual feasibility and fires where primal and dual objective cross on the way down -- DESIGN.md section 6;
+    not test dual feasibility and fires where primal and dual objective cross on the way down -- DESIGN.md section 7;
     recorded, not asserted: it is the oracle's end state, not a property of the library)."""
     gold = json.loads((golden_dir / "solve_sdplib500.json").read_text())
 
