@@ -512,11 +512,19 @@ def step_roofline(st, n, N, rank, krylovdim, mv_step, ms_step):
         kern = "k_symv_finish + k_lz_orth (packed-triangle Lanczos step)"
     t_pair = (ms_mv + ms_or) * 1e-3
     ach = (b_mv + b_or) / t_pair / 1e9 if t_pair > 0 else None
+    traffic, tnote = None, None
+    if fop:
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["fop_step"][str(n)]
+            if krylovdim > 64:
+                traffic = rec["bytes_per_step_K_gt_64"]
+                tnote = ("bytes behind the L2s per step pair (k_fop_finish<1,2> + k_lz_orth<2,1>), 2*FETCH_SIZE + WRITE_SIZE: "
+                         "profiles/r04_pmc_traffic.md <- " + rec["source"])
+        except (OSError, KeyError, ValueError):
+            tnote = "no PMC record for the step kernels at n=%d under profiles/ (profiles/r04_pmc_traffic.md has n = 2000 and 4000)" % n
     return {"bound": "latency" if fop else "hbm", "kernel": kern, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": None,
-            "traffic_note": "rocprofv3 --pmc does not survive n >= 3000 solves in this image; at n = 2000 (rank 45) the two step "
-                            "launches move 4.1 + 2.6 MB by PMC (profiles/r03_pmc_traffic.md) against 16 MB for one pass over the "
-                            "packed triangle" if fop else None,
+            "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": traffic,
+            "traffic_note": tnote,
             "bytes_per_step_model": b_mv + b_or, "avg_matvec_launch_ms": ms_mv, "avg_orth_launch_ms": ms_or,
             "launches_profiled": [int(st["symv_profiled"]), int(st["orth_profiled"])],
             "launch_arithmetic": {"lanczos_steps_per_iteration": mv_step, "launches_per_step": 2,
