@@ -675,7 +675,7 @@ inline void default_options(proxsdp_options* o) {      // options.jl:1-132
     o->lanczos_operator = -1; o->initial_target_rank = 2;
     o->full_eig_lanczos = -1; o->lanczos_cycle_kernel = -1; o->lanczos_warm_start = 0; o->reconstruct_mfma = -1;
     o->small_block_batch = -1; o->full_eig_sign = -1; o->psd_sign_engine = -1;
-    o->full_eig_lanczos_verify = -1; o->full_eig_lanczos_posres = 1e-7; o->full_eig_lanczos_kdim10 = 30;
+    o->full_eig_lanczos_verify = -1; o->full_eig_lanczos_posres = 1e-6; o->full_eig_lanczos_kdim10 = 30;
     o->sign_small_tile_max = 3072; o->host_eig_threads = 0; o->block_threads = -1;
     o->host_eig_merge = -1; o->block_batch = -1; o->rocsolver_warmup = 0; o->host_wait_spin = -1; o->sign_start_row = -1; o->general_batch = -1;
     o->full_eig_lanczos_certify = -1; o->full_eig_lanczos_tol = 0.0;

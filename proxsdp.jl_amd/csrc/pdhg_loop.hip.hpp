@@ -364,7 +364,7 @@ inline bool Solver::full_eig_by_lanczos(int idx, const double* xp, double* xo, b
         if (cert_m >= 2) {
             double theta = 0.0, cscale = 0.0;
             if (lanczos_certificate(W, xp, npos, cert_m, theta, cscale)) {
-                const double posres = opt.full_eig_lanczos_posres > 0.0 ? opt.full_eig_lanczos_posres : 1e-7;
+                const double posres = opt.full_eig_lanczos_posres > 0.0 ? opt.full_eig_lanczos_posres : 1e-6;
                 if (!(theta <= posres * cscale)) {
                     // a positive direction the run did not see: the dense engine projects this input (intact: the
                     // reconstruction has not run yet); three failures leave the block to the dense engine for good

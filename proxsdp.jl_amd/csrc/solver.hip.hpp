@@ -1105,7 +1105,7 @@ inline bool Solver::lz_after_cycle(EigWork& W, LzRun& R, bool speculated) {
         // once and says nothing about the pairs around it)
         int jn = j;
         while (jn < K && D[jn] >= -1e-12 * scale) ++jn;
-        const double posres = opt.full_eig_lanczos_posres > 0.0 ? opt.full_eig_lanczos_posres : 1e-7;
+        const double posres = opt.full_eig_lanczos_posres > 0.0 ? opt.full_eig_lanczos_posres : 1e-6;
         if (converged >= j && (jn == K || std::fabs(f[jn]) <= std::max(tol, posres * scale))) { R.pos_count = j; return false; }
         if (K < krylovdim || R.numiter == R.maxiter) { R.pos_fail = true; return false; }
     } else {
