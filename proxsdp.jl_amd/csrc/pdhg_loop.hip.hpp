@@ -1856,6 +1856,10 @@ inline void Solver::run() {
         cache_solution(P.c_orig);
     }
     (void)n_snap;
+    if (debug && dbg_lz[5] > 0)
+        std::fprintf(stderr, "[proxsdp] single-block Lanczos: %.0f cycles; per cycle: wait for the GPU %.1f us | after-cycle host logic (eigensolve, "
+                     "convergence, restart rotation staging) %.1f us; per projection: results (Ritz coefficients + rotation staging) %.1f us\n",
+                     dbg_lz[5], 1e6 * dbg_lz[0] / dbg_lz[5], 1e6 * dbg_lz[1] / dbg_lz[5], 1e6 * dbg_lz[3] / std::max(1.0, (double)st.lanczos_calls));
     if (debug && dbg_batch[4] > 0)
         std::fprintf(stderr, "[dbg] batched Lanczos: %.0f cycles; per cycle enqueue %.1f us, wait %.1f us, restart logic %.1f us, flush %.1f us\n",
                      dbg_batch[4], 1e6 * dbg_batch[0] / dbg_batch[4], 1e6 * dbg_batch[1] / dbg_batch[4],

@@ -323,6 +323,8 @@ public:
     void lanczos_batch(const std::vector<int>& blocks, const double* xbase, const std::vector<int>& nevs);
     // batched rotations: U of every block staged in ONE pinned buffer, one upload, one launch (grid.z = block)
     double dbg_batch[5] = {0, 0, 0, 0, 0};         // debug: enqueue | wait | restart logic | flush seconds, cycles
+    double dbg_lz[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // debug (PROXSDP_HIP_DEBUG): single-block run -- wait for the cycle | second() +
+                                                   // merge | last row + convergence | Ritz coefficients | staging + upload + launch | cycles
     RotSink* rot_sink = nullptr;
     std::unique_ptr<SpinPool> restart_pool;        // helper threads for the per-block restart logic of a batched run
     DevBuf<double> lzb_U;
@@ -1506,7 +1508,9 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive
         PX_HIP(hipMemcpyAsync(W.rec_host, W.rec.p, EigWork::REC_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, stream));
         // host work under the GPU's cycle: the first part of the split eigensolve, or the arrow reduction of the QL path
         if (!(split_cycle && lz_split_first(W, R, k1))) lz_prepare_arrow(R);
+        const double tdbg0 = debug ? now_s() : 0.0;
         wait_stream();
+        if (debug) { dbg_lz[0] += now_s() - tdbg0; dbg_lz[5] += 1.0; }
         if (W.cye_pending) {
             W.cye_pending = false;
             float ms = 0.f;
@@ -1538,9 +1542,14 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive
             }
         }
         W.evo.used = 0;
-        if (!lz_after_cycle(W, R, speculate)) break;
+        const double tdbg1 = debug ? now_s() : 0.0;
+        const bool go_on = lz_after_cycle(W, R, speculate);
+        if (debug) dbg_lz[1] += now_s() - tdbg1;
+        if (!go_on) break;
     }
+    const double tdbg2 = debug ? now_s() : 0.0;
     lz_finish_run(W, R);
+    if (debug) dbg_lz[3] += now_s() - tdbg2;
 }
 
 inline void Solver::flush_rotations(RotSink& S) {

@@ -42,3 +42,11 @@ else:
         prev_end = e
     for k, (c, dur, gap) in sorted(agg.items(), key=lambda kv: -kv[1][1] - kv[1][2]):
         print("%-62s x%-4d busy %8.1f us  gaps before %8.1f us" % (k, c, dur, gap))
+    # the large idle gaps of the iteration (> 15 us): which kernel the GPU waited for, and for how long
+    prev_end = rows[a - 1][1] if a > 0 else rows[a][0]
+    print("idle gaps > 15 us (kernel that ended the wait):")
+    for s, e, nme in rows[a:b]:
+        g = (s - prev_end) / 1e3
+        if g > 15.0:
+            print("   %8.1f us before %s" % (g, nme.split("(")[0].replace("void ", "").replace("proxsdp::dev::", "")[:70]))
+        prev_end = e
