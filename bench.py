@@ -734,7 +734,7 @@ def bench_mimo(args, torch, dist, rank, world, dev_id, backend):
         # native RCCL: the library reduces the scalar record and the coupling rows itself on its own stream
         # (proxsdp_problem.nccl_comm); PROXSDP_BENCH_NATIVE_RCCL=0 keeps the torch.distributed callbacks
         comm = None
-        if os.environ.get("PROXSDP_BENCH_NATIVE_RCCL", "1") != "0" and binding.rccl_available():
+        if backend == "nccl" and os.environ.get("PROXSDP_BENCH_NATIVE_RCCL", "1") != "0" and binding.rccl_available():
             comm = sharded.make_native_comm(dist, rank, world, device_id=dev_id)
         opt, sol, _ = sharded.solve_sharded(model, dist, rank, world, device_id=dev_id,
                                             collective_device=cdev, native_comm=comm, max_iter=W + K)
