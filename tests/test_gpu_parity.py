@@ -689,6 +689,26 @@ def test_sdplib_500_instances_solved_to_tolerance_against_the_oracle_solves(gold
     assert abs(sol.objval - 25.3205) <= 1e-3 * 25.3205                      # the literature optimum
 
 
+def test_round4_step_kernels_reproduce_round3_bit_for_bit(golden_dir):
+    """Round 4 rebuilt the Lanczos step kernels (producer-major partial records reduced lane <-> column, no loads beyond
+    column k, unconditional row sums) WITHOUT moving a bit: the record sums keep the balanced-tree order of round 3's
+    fold network (kernels.hip.hpp tree_in_wave / tree_across).  Pinned against traces written by the ROUND-3 library
+    (tools/gpurun_ab.py on the build of commit af9cfd5): objectives, residuals and Lanczos mat-vec counts of the first 900
+    iterations of Max-Cut n = 2000 (default options: packed operator at first, operator form, 45 restarts, two rank
+    updates) and of the first 40 iterations of the headline regime (n = 4000, nev 63, krylovdim 127) must be EQUAL as
+    float64 bit patterns.  (A plain sequential record sum is 3 % faster and moved one rank update of the n = 2000 golden
+    solve by one iteration -- DESIGN.md section 5.)  An intentional change of summation order has to regenerate these files."""
+    for fname, pr, kw in (("bits_maxcut_n2000_round3.npy", P.maxcut(2000, seed=0), dict(max_iter=900)),
+                          ("bits_maxcut_n4000_rank63_round3.npy", P.maxcut(4000, seed=0),
+                           dict(max_iter=40, initial_target_rank=63, max_target_rank_krylov_eigs=64))):
+        gold = np.load(golden_dir / fname)
+        sol = Optimizer(**kw).optimize(pr, trace_capacity=kw["max_iter"])
+        got = sol.trace[:len(gold)][:, [1, 2, 5, 6, 13]]
+        same = (got.view(np.uint64) == gold.view(np.uint64)).all(axis=1)
+        print(fname, "rows equal as bit patterns:", int(same.sum()), "of", len(gold))
+        assert same.all(), np.nonzero(~same)[0][:5]
+
+
 def test_maxG51_default_options_follows_the_oracle_into_the_100_restart_regime(golden_dir):
     """VERDICT r3 item 4 (maxG51 with default options ends at the time limit): what the reference's algorithm does on
     this instance, pinned by 12 min of oracle CPU (tests/golden/trace_maxG51_default.json).  4012 iterations of 25-42
