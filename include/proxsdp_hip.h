@@ -40,7 +40,8 @@ extern "C" {
 /* 7 (round 3): proxsdp_options gained sign_start_row and general_batch (taken from reserved_i), proxsdp_stats gained
  * sign_short_pass / sign_short_fail (taken from reserved): same struct sizes and offsets as version 6
  * 8 (round 4): proxsdp_options gained full_eig_lanczos_certify (from reserved_i) and full_eig_lanczos_tol (from
- * reserved_d), proxsdp_stats full_eigs_lanczos_certified / _cert_failed / cert_matvecs (the last reserved slots):
+ * reserved_d) and host_merge_threads (from reserved_i), proxsdp_stats full_eigs_lanczos_certified / _cert_failed /
+ * cert_matvecs (the last reserved slots):
  * same struct sizes and offsets; debug_fail_iteration now needs PROXSDP_HIP_FAULT_INJECTION=1 */
 #define PROXSDP_HIP_ABI_VERSION 8
 
@@ -313,7 +314,12 @@ typedef struct proxsdp_options {
                                   * operator); its largest Ritz value must be <= full_eig_lanczos_posres x the spectral
                                   * scale, otherwise the dense engine projects that input.  -1 auto = 10 steps, 0 = off,
                                   * m >= 2 = m steps.  The periodic dense check (full_eig_lanczos_verify) stays behind it. */
-    int32_t reserved_i[2];       /* zero */
+    int32_t host_merge_threads;  /* helper threads for the rank-one merge of the K x K eigensolve (host_eig_merge): the secular
+                                  * roots, the Gu-Eisenstat weights and the eigenvector columns are independent per root /
+                                  * column and are handed out in chunks; the helpers spin only while a projection with
+                                  * krylovdim >= 64 is in progress.  Results are bit-identical to the serial merge.
+                                  * -1 auto = 3, 0 = none */
+    int32_t reserved_i[1];       /* zero */
     double  full_eig_lanczos_tol;/* convergence of the POSITIVE Ritz pairs of that engine: residual <= tol x the spectral
                                   * scale; 0 (default) = krylovkit_tol as an absolute residual (KrylovKit's rule) */
     double  reserved_d[1];       /* zero */
@@ -534,6 +540,9 @@ int proxsdp_host_symeig_arrow(int32_t K, int32_t m, const double* D, const doubl
  * m = 0.  info[3] (optional): non-deflated poles, deflated poles, most secular iterations of a root. */
 int proxsdp_host_symeig_split(int32_t K, int32_t m, int32_t k1, const double* D, const double* f,
                               const double* al, const double* be, double* U, double* d, int32_t* info);
+/* the same with `threads` helper threads for the merge's independent pieces (options.host_merge_threads): bit-identical */
+int proxsdp_host_symeig_split_threads(int32_t K, int32_t m, int32_t k1, const double* D, const double* f,
+                                      const double* al, const double* be, int32_t threads, double* U, double* d, int32_t* info);
 /* the library's Lanczos start vector (init 3/2/1 as options.jl:98-103) */
 int proxsdp_host_start_vector(int64_t n, int64_t seed, int32_t init, double* out);
 /* preprocess!/norm_scaling (scaling.jl): returns the variable order, the

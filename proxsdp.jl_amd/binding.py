@@ -110,7 +110,7 @@ def _opt_fields():
     a("full_eig_lanczos_verify", i32); a("full_eig_lanczos_posres", f64); a("full_eig_lanczos_kdim10", i32)
     a("sign_small_tile_max", i32); a("host_eig_threads", i32); a("block_threads", i32)
     a("host_eig_merge", i32); a("block_batch", i32); a("rocsolver_warmup", i32); a("debug_fail_iteration", i32); a("host_wait_spin", i32)
-    a("sign_start_row", i32); a("general_batch", i32); a("full_eig_lanczos_certify", i32); a("reserved_i", i32 * 2)
+    a("sign_start_row", i32); a("general_batch", i32); a("full_eig_lanczos_certify", i32); a("host_merge_threads", i32); a("reserved_i", i32 * 1)
     a("full_eig_lanczos_tol", f64); a("reserved_d", f64 * 1)
     return F
 
@@ -562,7 +562,7 @@ def host_start_vector(n, seed=1234, init=3):
     return out
 
 
-def host_symeig_split(D, f, al, be, k1):
+def host_symeig_split(D, f, al, be, k1, threads=0):
     """proxsdp_host_symeig_split: eigen-decomposition of the restarted Rayleigh quotient (as host_symeig_arrow) by a
     split at k1 + rank-one merge.  Returns (d ascending, U, info dict)."""
     D = _f(D); f = _f(f); al = _f(al); be = _f(be)
@@ -571,9 +571,9 @@ def host_symeig_split(D, f, al, be, k1):
     d = np.zeros(K)
     info = (i32 * 3)()
     L = lib()
-    L.proxsdp_host_symeig_split.argtypes = [i32, i32, i32, pf64, pf64, pf64, pf64, pf64, pf64, C.POINTER(i32)]
-    _check(L.proxsdp_host_symeig_split(K, m, int(k1), _p(D) if m else None, _p(f) if m else None, _p(al), _p(be),
-                                       _p(U), _p(d), info))
+    L.proxsdp_host_symeig_split_threads.argtypes = [i32, i32, i32, pf64, pf64, pf64, pf64, i32, pf64, pf64, C.POINTER(i32)]
+    _check(L.proxsdp_host_symeig_split_threads(K, m, int(k1), _p(D) if m else None, _p(f) if m else None, _p(al), _p(be),
+                                               int(threads), _p(U), _p(d), info))
     return d, U.T.copy(), dict(nondeflated=info[0], deflated=info[1], max_secular_iterations=info[2])
 
 

@@ -2,6 +2,7 @@
 // this boundary: every entry point catches, records the message in a
 // thread-local buffer and returns a negative PROXSDP_E_* code.  There is no CPU
 // fallback: without a HIP device the compute entry points fail with PROXSDP_E_HIP.
+#include <memory>
 #include <new>
 #include <string>
 
@@ -483,9 +484,25 @@ int proxsdp_host_symeig_arrow(int32_t K, int32_t m, const double* D, const doubl
 
 int proxsdp_host_symeig_split(int32_t K, int32_t m, int32_t k1, const double* D, const double* f,
                               const double* al, const double* be, double* U, double* d, int32_t* info) {
+    return proxsdp_host_symeig_split_threads(K, m, k1, D, f, al, be, 0, U, d, info);
+}
+
+int proxsdp_host_symeig_split_threads(int32_t K, int32_t m, int32_t k1, const double* D, const double* f,
+                                      const double* al, const double* be, int32_t threads, double* U, double* d, int32_t* info) {
     return guarded([&]() -> int {
         if (K < 2 || m < 0 || m >= K || k1 < 1 || k1 >= K || !al || !be || !U || !d) throw std::invalid_argument("invalid argument");
         proxsdp::SplitEig S;
+        std::unique_ptr<proxsdp::SpinPool> pool;
+        proxsdp::ParFor par;
+        struct Guard { proxsdp::SpinPool* p; ~Guard() { if (p) p->disarm(); } } guard{nullptr};
+        if (threads > 0) {
+            pool.reset(new proxsdp::SpinPool(std::min<int>(threads, 15)));
+            pool->arm();
+            guard.p = pool.get();
+            par = [&pool](int n, const std::function<void(int)>& body) { pool->run(n, body); };
+            S.M.par = &par;
+            S.M.nchunk = std::min<int>(threads, 15) + 1;
+        }
         if (S.first(k1, m, D, f, al, be) != 0 || S.second(K, al, be) != 0) throw std::invalid_argument("split eigensolver failed");
         std::vector<int> cols(K);
         for (int c = 0; c < K; ++c) { cols[c] = c; d[c] = S.M.evals[c]; }

@@ -25,6 +25,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <functional>
 #include <limits>
 #include <vector>
 #if defined(__x86_64__)
@@ -60,7 +61,13 @@ static inline void rank1_panel_8x4(const double* Qf, int K, const int* qcol, int
 }
 #endif
 
+// par(n, body): run body(0) .. body(n-1), possibly on helper threads (the driver passes its spin pool); nullptr = serial.
+// Every root / column is computed by the same code whichever thread takes it: results do not depend on the runner.
+using ParFor = std::function<void(int, const std::function<void(int)>&)>;
+
 struct Rank1Merge {
+    const ParFor* par = nullptr;           // set by the caller before build() / vectors()
+    int nchunk = 4;                        // independent chunks handed to the runner
     int K = 0, k1 = 0, k2 = 0, k = 0;      // k = number of non-deflated poles
     double rho = 0.0;
     std::vector<double> Qf;                // K x K column-major: eigenvectors of blkdiag(T1', T2') in pole order (+ deflation rotations)
@@ -94,8 +101,9 @@ struct Rank1Merge {
     }
 
     // root i of the secular equation; returns origin and tau (lambda = dn[org] + tau)
-    void solve_root(int i, int& org_out, double& tau_out) {
+    void solve_root(int i, int& org_out, double& tau_out, int& iters_out) const {
         const double eps = 2.220446049250313e-16;
+        iters_out = 0;
         if (k == 1) { org_out = 0; tau_out = rho * zn[0] * zn[0]; return; }
         const bool last = (i == k - 1);
         const int ia = last ? k - 2 : i, ib = ia + 1;        // the two poles kept exactly by the interpolation
@@ -156,7 +164,7 @@ struct Rank1Merge {
             if (tn == tau) break;
             tau = tn;
         }
-        max_iter_seen = std::max(max_iter_seen, it);
+        iters_out = it;
         org_out = org; tau_out = tau;
     }
 
@@ -235,36 +243,51 @@ struct Rank1Merge {
         lam.assign(k, 0.0);
         delta.assign((size_t)k * k, 0.0);
         max_iter_seen = 0;
-        for (int i = 0; i < k; ++i) {
-            int org; double tau;
-            solve_root(i, org, tau);
-            lam[i] = dn[org] + tau;
-            double* dl = delta.data() + (size_t)i * k;
-            for (int j = 0; j < k; ++j) dl[j] = (dn[j] - dn[org]) - tau;
-            // interlacing is what makes the Loewner formula below positive: enforce it against rounding
-            if (dl[i] >= 0.0) dl[i] = -std::numeric_limits<double>::min();
-            if (i + 1 < k && dl[i + 1] <= 0.0) dl[i + 1] = std::numeric_limits<double>::min();
-        }
+        // the three O(k^2) phases below are independent per root / per pole: chunks of them go to the runner
+        const int nc = (par != nullptr && k >= 32) ? std::max(1, nchunk) : 1;
+        auto chunks = [&](const std::function<void(int, int)>& body) {          // body(lo, hi) over [0, k) in nc pieces
+            if (nc == 1) { body(0, k); return; }
+            const std::function<void(int)> one = [&](int c) { body((int)((long long)k * c / nc), (int)((long long)k * (c + 1) / nc)); };
+            (*par)(nc, one);
+        };
+        std::vector<int> iters(std::max(k, 1), 0);
+        chunks([&](int lo, int hi) {
+            for (int i = lo; i < hi; ++i) {
+                int org; double tau;
+                solve_root(i, org, tau, iters[i]);
+                lam[i] = dn[org] + tau;
+                double* dl = delta.data() + (size_t)i * k;
+                for (int j = 0; j < k; ++j) dl[j] = (dn[j] - dn[org]) - tau;
+                // interlacing is what makes the Loewner formula below positive: enforce it against rounding
+                if (dl[i] >= 0.0) dl[i] = -std::numeric_limits<double>::min();
+                if (i + 1 < k && dl[i + 1] <= 0.0) dl[i + 1] = std::numeric_limits<double>::min();
+            }
+        });
+        for (int i = 0; i < k; ++i) max_iter_seen = std::max(max_iter_seen, iters[i]);
         // ---- Gu-Eisenstat: the z for which lam are the EXACT eigenvalues
         std::vector<double> zhat(k, 0.0);
-        for (int j = 0; j < k; ++j) {
-            // prod_i (lam_i - dn_j) / prod_{i != j} (dn_i - dn_j), paired so that every ratio is positive
-            double prod = -delta[(size_t)(k - 1) * k + j];                  // lam_{k-1} - dn_j > 0
-            for (int i = 0; i < j; ++i) prod *= delta[(size_t)i * k + j] / (dn[j] - dn[i]);             // (dn_j - lam_i)/(dn_j - dn_i)
-            for (int i = j; i < k - 1; ++i) prod *= delta[(size_t)i * k + j] / (dn[j] - dn[i + 1]);     // (dn_j - lam_i)/(dn_j - dn_{i+1}), both negative
-            const double v = std::sqrt(std::fabs(prod) / rho);
-            zhat[j] = zn[j] < 0.0 ? -v : v;
-        }
+        chunks([&](int lo, int hi) {
+            for (int j = lo; j < hi; ++j) {
+                // prod_i (lam_i - dn_j) / prod_{i != j} (dn_i - dn_j), paired so that every ratio is positive
+                double prod = -delta[(size_t)(k - 1) * k + j];                  // lam_{k-1} - dn_j > 0
+                for (int i = 0; i < j; ++i) prod *= delta[(size_t)i * k + j] / (dn[j] - dn[i]);             // (dn_j - lam_i)/(dn_j - dn_i)
+                for (int i = j; i < k - 1; ++i) prod *= delta[(size_t)i * k + j] / (dn[j] - dn[i + 1]);     // (dn_j - lam_i)/(dn_j - dn_{i+1}), both negative
+                const double v = std::sqrt(std::fabs(prod) / rho);
+                zhat[j] = zn[j] < 0.0 ? -v : v;
+            }
+        });
         // ---- eigenvectors of D + rho z z'
         S.assign((size_t)k * k, 0.0);
-        for (int i = 0; i < k; ++i) {
-            double* s = S.data() + (size_t)i * k;
-            const double* dl = delta.data() + (size_t)i * k;
-            double nn = 0.0;
-            for (int j = 0; j < k; ++j) { s[j] = zhat[j] / dl[j]; nn += s[j] * s[j]; }
-            const double inv = 1.0 / std::sqrt(nn);
-            for (int j = 0; j < k; ++j) s[j] *= inv;
-        }
+        chunks([&](int lo, int hi) {
+            for (int i = lo; i < hi; ++i) {
+                double* s = S.data() + (size_t)i * k;
+                const double* dl = delta.data() + (size_t)i * k;
+                double nn = 0.0;
+                for (int j = 0; j < k; ++j) { s[j] = zhat[j] / dl[j]; nn += s[j] * s[j]; }
+                const double inv = 1.0 / std::sqrt(nn);
+                for (int j = 0; j < k; ++j) s[j] *= inv;
+            }
+        });
         // ---- all eigenvalues of T, ascending, with their sources
         std::vector<std::pair<double, int>> all;
         all.reserve(K);
@@ -305,10 +328,13 @@ struct Rank1Merge {
         auto panel = [&](const std::vector<int>& idx, int r0, int nr) {
             const int kk = (int)idx.size();
             if (kk == 0 || nr <= 0) return;
-            std::vector<double> wbuf((size_t)4 * kk);
             std::vector<int> qcol(kk);
             for (int jj = 0; jj < kk; ++jj) qcol[jj] = nd[idx[jj]];
-            for (int c0 = 0; c0 < ncols; c0 += 4) {
+            const int nblk = (ncols + 3) / 4;
+            // blocks of four output columns are independent: pieces of them go to the runner (each with its own scratch)
+            auto blocks = [&](int b0, int b1) {
+            std::vector<double> wbuf((size_t)4 * kk);
+            for (int c0 = 4 * b0; c0 < std::min(ncols, 4 * b1); c0 += 4) {
                 const int cb = std::min(4, ncols - c0);
                 double* u[4] = {nullptr, nullptr, nullptr, nullptr};
                 for (int q = 0; q < 4; ++q) {
@@ -346,6 +372,13 @@ struct Rank1Merge {
                     if (u[2]) u[2][r] = a2;
                     if (u[3]) u[3][r] = a3;
                 }
+            }
+            };
+            const int nc = (par != nullptr && nblk >= 8) ? std::max(1, nchunk) : 1;
+            if (nc == 1) blocks(0, nblk);
+            else {
+                const std::function<void(int)> one = [&](int c) { blocks((int)((long long)nblk * c / nc), (int)((long long)nblk * (c + 1) / nc)); };
+                (*par)(nc, one);
             }
         };
         std::fill(U, U + (size_t)K * ncols, 0.0);

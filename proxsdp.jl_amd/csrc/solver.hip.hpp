@@ -327,6 +327,12 @@ public:
                                                    // merge | last row + convergence | Ritz coefficients | staging + upload + launch | cycles
     RotSink* rot_sink = nullptr;
     std::unique_ptr<SpinPool> restart_pool;        // helper threads for the per-block restart logic of a batched run
+    // helper threads for the rank-one merge of the K x K eigensolve (secular roots, Gu-Eisenstat weights, eigenvector columns:
+    // independent per root / column, so the results do not depend on who computes them).  They spin only while a projection
+    // with krylovdim >= 64 is in progress (armed at its start, disarmed at its end).
+    std::unique_ptr<SpinPool> merge_pool;
+    ParFor merge_par;
+    int merge_helpers() const { return opt.host_merge_threads < 0 ? 3 : std::min(15, (int)opt.host_merge_threads); }
     DevBuf<double> lzb_U;
     PinnedBuf lzb_U_host, lzb_rec_host;
     static constexpr size_t LZB_USTRIDE = 64 * 64 + 2 * dev::MAXK;
@@ -1463,6 +1469,18 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive
     // wanted set is re-ordered afterwards) and not under the persistent cycle kernel
     const int merge_from = opt.host_eig_merge == 0 ? (1 << 30) : (opt.host_eig_merge == 1 ? 24 : 64);
     const bool use_split = !cyc && !R.arpack && krylovdim >= merge_from;
+    struct PoolGuard { SpinPool* p; ~PoolGuard() { if (p) p->disarm(); } } pool_guard{nullptr};
+    W.split.M.par = nullptr;
+    if (use_split && merge_helpers() > 0 && StreamRef::tl == nullptr) {      // (not from a block worker thread: one pool per solver)
+        if (!merge_pool) {
+            merge_pool.reset(new SpinPool(merge_helpers()));
+            merge_par = [this](int n, const std::function<void(int)>& body) { merge_pool->run(n, body); };
+        }
+        merge_pool->arm();
+        pool_guard.p = merge_pool.get();
+        W.split.M.par = &merge_par;
+        W.split.M.nchunk = merge_helpers() + 1;
+    }
     if (use_split && W.side == nullptr) {
         PX_HIP(hipStreamCreateWithFlags(&W.side, hipStreamNonBlocking));
         PX_HIP(hipEventCreateWithFlags(&W.ev_mid, hipEventDisableTiming));

@@ -304,6 +304,9 @@ def test_split_and_rank_one_merge_eigensolver_against_lapack(K):
         assert info["nondeflated"] + info["deflated"] == K and info["max_secular_iterations"] <= 40, (name, info)
         if name == "decoupled":
             assert info["nondeflated"] == 0
+        # the merge's independent pieces on helper threads (options.host_merge_threads): the same bits
+        d3, U3, info3 = B.host_symeig_split(D_, f_, al_, be_, k1, threads=3)
+        assert np.array_equal(d3, d) and np.array_equal(U3, U) and info3 == info, name
 
 
 def test_julia_shim_constructs_the_problem_struct_with_every_field():
