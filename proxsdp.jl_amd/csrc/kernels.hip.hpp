@@ -915,8 +915,10 @@ k_lzb_begin(LzBatch B) {
     if (i == 0) { b.ctl->stop = 0; b.ctl->kstop = 0; b.ctl->carry = 0.0; }
 }
 // workgroups [0, nt): closing work; [nt, nt + ntile): mat-vec tiles (as k_symv_finish / k_symv_packed)
+// rec_out (pinned host memory) / rec_doubles: at the END of a block's cycle (mode 3) its closing workgroup 0 also copies the
+// block's record [alphas | betas | ctl] out -- the separate gather launch of round 3 is gone (one launch less per cycle)
 __global__ void __launch_bounds__(TPB)
-k_lzb_mv(LzBatch B) {
+k_lzb_mv(LzBatch B, double* __restrict__ rec_out, int rec_doubles) {
     __shared__ double s_a[2 * NWAVE * TILE];
     __shared__ double s_b[NWAVE * LZ_ROWS];
     __shared__ double s_beta;
@@ -929,6 +931,11 @@ k_lzb_mv(LzBatch B) {
         const int kc = b.k - 1;
         lz_finish_body<1>(b.wbuf, b.V, B.npad, kc, (kc & 1) ? b.hpart2 : b.hpart1, B.pld, b.hsum, b.alphas, b.betas, b.ctl,
                           B.tol, kc > b.keep ? 1 : 0, blockIdx.x, s_a, s_b, &s_beta, b.hred, nt);
+        if (mode == 3 && blockIdx.x == 0 && rec_out != nullptr) {
+            __syncthreads();                                 // thread 0's alphas[kc] / betas[kc] / ctl stores are visible to the workgroup
+            const double* src = b.alphas;                    // the record starts at the alphas
+            for (int t = threadIdx.x; t < rec_doubles; t += TPB) rec_out[(long long)blockIdx.z * rec_doubles + t] = src[t];
+        }
     } else {
         if (mode == 3 || b.ctl->stop) return;
         const double* v = (mode == 1) ? b.V + (long long)b.k * B.npad : b.wbuf;

@@ -308,6 +308,7 @@ public:
             if (W.side) (void)hipStreamDestroy(W.side);
         }
         if (ev_main) (void)hipEventDestroy(ev_main);
+        if (lzb_ev) (void)hipEventDestroy(lzb_ev);
         for (auto& pr : dense_ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
         if (blas) (void)rocblas_destroy_handle(blas);
         if (stream.main) (void)hipStreamDestroy(stream.main);
@@ -327,6 +328,7 @@ public:
                                                    // merge | last row + convergence | Ritz coefficients | staging + upload + launch | cycles
     RotSink* rot_sink = nullptr;
     std::unique_ptr<SpinPool> restart_pool;        // helper threads for the per-block restart logic of a batched run
+    hipEvent_t lzb_ev = nullptr;                   // end of a batched cycle's record copies (the speculated mat-vecs run behind it)
     // helper threads for the rank-one merge of the K x K eigensolve (secular roots, Gu-Eisenstat weights, eigenvector columns:
     // independent per root / column, so the results do not depend on who computes them).  They spin only while a projection
     // with krylovdim >= 64 is in progress (armed at its start, disarmed at its end).
@@ -1642,27 +1644,32 @@ inline void Solver::lanczos_batch(const std::vector<int>& blocks, const double* 
     long long nlaunch = 0, prof_blocks = 0;
     double tp0 = debug ? now_s() : 0.0;                  // PROXSDP_HIP_DEBUG: host-time split of the batched run
     auto lap = [&](double& acc) { if (debug) { const double t = now_s(); acc += t - tp0; tp0 = t; } };
+    std::vector<char> presymv(nb, 0);                // the first mat-vec of the block's next cycle is already in Ppart (speculated)
+    if (lzb_ev == nullptr) PX_HIP(hipEventCreateWithFlags(&lzb_ev, hipEventDisableTiming));
+    double* const rec_out = lzb_rec_host.p;
+    const int rec_n = (int)EigWork::REC_DOUBLES;
     while (true) {
         int tmax = 0, nlive = 0;
         for (int q = 0; q < nb; ++q)
             if (live[q]) { tmax = std::max(tmax, Rq(q).krylovdim - Rq(q).kfirst); ++nlive; }
         if (nlive == 0) break;
         for (int t = 0; t <= tmax; ++t) {
-            bool any_orth = false;
+            bool any_orth = false, any_mv = false;
             for (int q = 0; q < nb; ++q) {
                 dev::LzBlk& b = fill(q);               // (V / arrow pointers change at a restart)
                 b.mode = 0;
                 if (!live[q]) continue;
                 const int k = Rq(q).kfirst + t, kd = Rq(q).krylovdim;
                 b.k = k; b.keep = Rq(q).kfirst;
-                b.mode = (t == 0) ? 1 : (k < kd) ? 2 : (k == kd) ? 3 : 0;
+                b.mode = (t == 0) ? (presymv[q] ? 0 : 1) : (k < kd) ? 2 : (k == kd) ? 3 : 0;
+                any_mv = any_mv || b.mode != 0;
                 if (k < kd) {
                     any_orth = true;
                     eig[blocks[q]].lst.symv_launches++; eig[blocks[q]].lst.symv_bytes += mv_bytes;
                 }
             }
             // every profile_symv_every-th batched mat-vec launch carries its own start/stop events
-            const bool prof = opt.profile_symv_every > 0 && t > 0 && t < tmax && (nlaunch++ % opt.profile_symv_every) == 0;
+            const bool prof = any_mv && opt.profile_symv_every > 0 && t > 0 && t < tmax && (nlaunch++ % opt.profile_symv_every) == 0;
             if (prof) {
                 if (W0.ev.used == W0.ev.e0.size()) {
                     hipEvent_t a, b2;
@@ -1671,25 +1678,37 @@ inline void Solver::lanczos_batch(const std::vector<int>& blocks, const double* 
                 }
                 const size_t slot = W0.ev.used++;
                 hipExtLaunchKernelGGL(dev::k_lzb_mv, dim3(W0.nt + ntile, 1, nb), dim3(dev::TPB), 0, stream,
-                                      W0.ev.e0[slot], W0.ev.e1[slot], 0, B);
+                                      W0.ev.e0[slot], W0.ev.e1[slot], 0, B, rec_out, rec_n);
                 int act = 0;
                 for (int q = 0; q < nb; ++q) act += (B.b[q].mode == 2) ? 1 : 0;
                 prof_blocks += act;
-            } else
-            hipLaunchKernelGGL(dev::k_lzb_mv, dim3(W0.nt + ntile, 1, nb), dim3(dev::TPB), 0, stream, B);
+            } else if (any_mv)          // (t = 0 with every live block's first mat-vec already speculated: nothing to launch)
+            hipLaunchKernelGGL(dev::k_lzb_mv, dim3(W0.nt + ntile, 1, nb), dim3(dev::TPB), 0, stream, B, rec_out, rec_n);
             if (!any_orth) continue;
-            for (int q = 0; q < nb; ++q)
-                if (B.b[q].mode == 3 || (live[q] && B.b[q].k >= Rq(q).krylovdim)) B.b[q].mode = 0;
+            for (int q = 0; q < nb; ++q) {
+                dev::LzBlk& b = B.b[q];
+                const bool act = live[q] && b.k < Rq(q).krylovdim;       // step b.k of the block's cycle exists
+                b.mode = act ? 1 : 0;                                     // (k_lzb_orth: != 0 = active)
+            }
             hipLaunchKernelGGL(dev::k_lzb_orth, dim3(W0.nt, 1, nb), dim3(dev::TPB), 0, stream, B);
             st.batched_block_steps += nlive;
         }
-        // every live block's record [alphas | betas | ctl] in ONE gather launch
-        for (int q = 0; q < nb; ++q) fill(q).mode = live[q] ? 1 : 0;
-        // (the kernel stores into pinned host memory: no copy command behind it -- MIMO x 8: 265 -> 279 it/s)
-        hipLaunchKernelGGL(dev::k_lzb_gather_rec, dim3(1, 1, nb), dim3(dev::TPB), 0, stream, B, lzb_rec_host.p, (int)EigWork::REC_DOUBLES);
+        // every live block's record [alphas | betas | ctl] has been copied out by the closing workgroup 0 of its mode-3 launch
+        // (straight into pinned host memory): the host waits for THAT point of the stream ...
+        PX_HIP(hipEventRecord(lzb_ev, stream));
+        // ... while the GPU already runs the first mat-vec of every block's NEXT cycle (on v_K = V[:, krylovdim], final since
+        // the mode-3 closing; the restart rotation copies it to column `keep`, so the tiles' result stays valid) -- wasted
+        // only for the blocks that turn out to have converged
+        for (int q = 0; q < nb; ++q) {
+            dev::LzBlk& b = fill(q);
+            b.mode = live[q] ? 1 : 0;
+            b.k = live[q] ? Rq(q).krylovdim : 0; b.keep = 0;
+        }
+        hipLaunchKernelGGL(dev::k_lzb_mv, dim3(W0.nt + ntile, 1, nb), dim3(dev::TPB), 0, stream, B, (double*)nullptr, 0);
+        for (int q = 0; q < nb; ++q) presymv[q] = live[q];
         for (int q = 0; q < nb; ++q) if (live[q]) lz_prepare_arrow(Rq(q));
         lap(dbg_batch[0]);                               // enqueue (+ arrow reductions)
-        wait_stream();
+        wait_event(lzb_ev);
         lap(dbg_batch[1]);                               // waiting for the GPU
         for (int q = 0; q < nb; ++q)
             if (live[q]) std::memcpy(eig[blocks[q]].rec_host, lzb_rec_host.p + (size_t)q * EigWork::REC_DOUBLES, EigWork::REC_DOUBLES * sizeof(double));
