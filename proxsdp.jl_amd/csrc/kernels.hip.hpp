@@ -1109,7 +1109,13 @@ k_lz_rotate(const double* __restrict__ V, int ldv, int n, int K, const double* _
         const int j = t % K, c = t / K;
         s_U[t] = U[(long long)c * ldu + j];
     }
-    for (int j = wv; j < K; j += NWAVE) s_V[j * (LZ_ROWS + 1) + lane] = V[(long long)j * ldv + i];
+    for (int j0 = wv; j0 < K; j0 += 16 * NWAVE) {       // batches of 16 loads in flight per wave (see k_lz_rotate_mfma)
+        double tv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) tv[u] = V[(long long)min(j0 + NWAVE * u, K - 1) * ldv + i];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) if (j0 + NWAVE * u < K) s_V[(j0 + NWAVE * u) * (LZ_ROWS + 1) + lane] = tv[u];
+    }
     __syncthreads();
     for (int c = wv; c < ncols; c += NWAVE) {
         const double* u = s_U + (size_t)c * K;
@@ -1146,7 +1152,13 @@ k_lzb_rotate(LzRotBatch B) {
     const int i = blockIdx.x * LZ_ROWS + lane;
     const int ldv = B.npad;
     for (int t = threadIdx.x; t < K * ncols; t += TPB) s_U[t] = q.U[t];           // compact K x ncols
-    for (int j = wv; j < K; j += NWAVE) s_V[j * (LZ_ROWS + 1) + lane] = q.V[(long long)j * ldv + i];
+    for (int j0 = wv; j0 < K; j0 += 16 * NWAVE) {       // batches of 16 loads in flight per wave (see k_lz_rotate_mfma)
+        double tv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) tv[u] = q.V[(long long)min(j0 + NWAVE * u, K - 1) * ldv + i];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) if (j0 + NWAVE * u < K) s_V[(j0 + NWAVE * u) * (LZ_ROWS + 1) + lane] = tv[u];
+    }
     __syncthreads();
     for (int c = wv; c < ncols; c += NWAVE) {
         const double* u = s_U + (size_t)c * K;
@@ -1417,13 +1429,38 @@ k_lz_rotate_mfma(const double* __restrict__ V, int ldv, int K, const double* __r
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int l15 = lane & 15, l4 = lane >> 4;
     const int i0 = blockIdx.x * LZ_ROWS;
-    for (int j = w; j < Kp; j += NWAVE) s_V[j * RM_LDV + lane] = (j < K) ? V[(long long)j * ldv + i0 + lane] : 0.0;
+    // staging with the loads of a batch all in flight (round 4: one load per loop turn made this a chain of ~32 memory round
+    // trips -- the kernel took 30-39 us for 8 us of work, profiles/r04_kernel_stats_*.md)
+    for (int j0 = w; j0 < Kp; j0 += 16 * NWAVE) {
+        double tv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int j = j0 + NWAVE * u;
+            tv[u] = (j < K) ? V[(long long)j * ldv + i0 + lane] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int j = j0 + NWAVE * u;
+            if (j < Kp) s_V[j * RM_LDV + lane] = tv[u];
+        }
+    }
     for (int c0 = 0; c0 < ncols; c0 += RM_CG) {
         const int cn = min(RM_CG, ncols - c0);
         __syncthreads();                           // previous group's reads of s_U are done (and s_V is complete)
-        for (int t = threadIdx.x; t < RM_CG * Kp; t += TPB) {
-            const int c = t / Kp, j = t - c * Kp;
-            s_U[c * ldu + j] = (c < cn && j < K) ? U[(long long)(c0 + c) * K + j] : 0.0;
+        // wave w stages columns w, w + 4, ... of the group (RM_CG / NWAVE = 12 of them), lanes along j: no index division
+        for (int jb = 0; jb < Kp; jb += WAVE) {
+            double tu[RM_CG / NWAVE];
+            const int j = jb + lane;
+#pragma unroll
+            for (int u = 0; u < RM_CG / NWAVE; ++u) {
+                const int c = w + NWAVE * u;
+                tu[u] = (c < cn && j < K) ? U[(long long)(c0 + c) * K + j] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < RM_CG / NWAVE; ++u) {
+                const int c = w + NWAVE * u;
+                if (j < Kp) s_U[c * ldu + j] = tu[u];
+            }
         }
         __syncthreads();
         v4f64 acc[3];
