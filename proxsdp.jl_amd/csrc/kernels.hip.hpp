@@ -1416,7 +1416,11 @@ k_reconstruct_mfma(const double* __restrict__ Z, int ldz, const double* __restri
 // column-major matrix the host uploads.  Same sums in a different order: results agree with the scalar kernel to rounding.
 // ---------------------------------------------------------------------------
 constexpr int RM_LDV = TILE + 16;        // LDS row stride of the V tile (as MF_LD)
-constexpr int RM_CG = 48;                // U columns staged per group (3 MFMA column blocks)
+constexpr int RM_CG = 16;                // U columns per workgroup (one MFMA column block per wave)
+// Round 4: grid = (64-row tiles, groups of RM_CG output columns).  Round 3 gave one workgroup per row tile and let it walk
+// the column groups of 48 one after the other: 63 workgroups, each a serial chain of staging rounds -- 39 us at K = 127
+// (25 us once the staging loads went out in batches) for ~8 us of work.  Every output element is still the same sequence of
+// MFMA steps over k = 0, 4, 8, ...: which workgroup forms it does not change its bits.
 __global__ void __launch_bounds__(TPB)
 k_lz_rotate_mfma(const double* __restrict__ V, int ldv, int K, const double* __restrict__ U, int ncols,
                  double* __restrict__ out, int ldo, int copy_src, int copy_dst) {
@@ -1429,61 +1433,55 @@ k_lz_rotate_mfma(const double* __restrict__ V, int ldv, int K, const double* __r
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int l15 = lane & 15, l4 = lane >> 4;
     const int i0 = blockIdx.x * LZ_ROWS;
-    // staging with the loads of a batch all in flight (round 4: one load per loop turn made this a chain of ~32 memory round
-    // trips -- the kernel took 30-39 us for 8 us of work, profiles/r04_kernel_stats_*.md)
-    for (int j0 = w; j0 < Kp; j0 += 16 * NWAVE) {
-        double tv[16];
+    const int c0 = blockIdx.y * RM_CG;
+    const int cn = min(RM_CG, ncols - c0);         // (>= 1 for every launched group; 0 only for the copy-only launch)
+    // staging with the loads of a batch all in flight (one load per loop turn is a chain of memory round trips)
+    if (cn > 0) {
+        double tu[RM_CG / NWAVE][2];               // wave w stages columns w, w + 4, ... of the group, lanes along j (K <= 128 per pass)
+        for (int jb = 0; jb < Kp; jb += 2 * WAVE) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int j = j0 + NWAVE * u;
-            tv[u] = (j < K) ? V[(long long)j * ldv + i0 + lane] : 0.0;
+            for (int u = 0; u < RM_CG / NWAVE; ++u)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int c = w + NWAVE * u, j = jb + WAVE * h + lane;
+                    tu[u][h] = (c < cn && j < K) ? U[(long long)(c0 + c) * K + j] : 0.0;
+                }
+#pragma unroll
+            for (int u = 0; u < RM_CG / NWAVE; ++u)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int c = w + NWAVE * u, j = jb + WAVE * h + lane;
+                    if (j < Kp) s_U[c * ldu + j] = tu[u][h];
+                }
         }
+        for (int j0 = w; j0 < Kp; j0 += 16 * NWAVE) {
+            double tv[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int j = j0 + NWAVE * u;
-            if (j < Kp) s_V[j * RM_LDV + lane] = tv[u];
-        }
-    }
-    for (int c0 = 0; c0 < ncols; c0 += RM_CG) {
-        const int cn = min(RM_CG, ncols - c0);
-        __syncthreads();                           // previous group's reads of s_U are done (and s_V is complete)
-        // wave w stages columns w, w + 4, ... of the group (RM_CG / NWAVE = 12 of them), lanes along j: no index division
-        for (int jb = 0; jb < Kp; jb += WAVE) {
-            double tu[RM_CG / NWAVE];
-            const int j = jb + lane;
-#pragma unroll
-            for (int u = 0; u < RM_CG / NWAVE; ++u) {
-                const int c = w + NWAVE * u;
-                tu[u] = (c < cn && j < K) ? U[(long long)(c0 + c) * K + j] : 0.0;
+            for (int u = 0; u < 16; ++u) {
+                const int j = j0 + NWAVE * u;
+                tv[u] = (j < K) ? V[(long long)j * ldv + i0 + lane] : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < RM_CG / NWAVE; ++u) {
-                const int c = w + NWAVE * u;
-                if (j < Kp) s_U[c * ldu + j] = tu[u];
+            for (int u = 0; u < 16; ++u) {
+                const int j = j0 + NWAVE * u;
+                if (j < Kp) s_V[j * RM_LDV + lane] = tv[u];
             }
         }
         __syncthreads();
-        v4f64 acc[3];
-#pragma unroll
-        for (int b = 0; b < 3; ++b) acc[b] = (v4f64){0.0, 0.0, 0.0, 0.0};
+        v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
         for (int q = 0; q < Kp / 4; ++q) {
             const double bv = s_V[(4 * q + l4) * RM_LDV + w * 16 + l15];
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                const double av = s_U[(b * 16 + l15) * ldu + 4 * q + l4];
-                acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[b], 0, 0, 0);
-            }
+            const double av = s_U[l15 * ldu + 4 * q + l4];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
         }
-        // D[c][i]: c = b*16 + l4 + 4 reg (column of this group), i = w*16 + l15 (row of the tile)
+        // D[c][i]: c = l4 + 4 reg (column of this group), i = w*16 + l15 (row of the tile)
 #pragma unroll
-        for (int b = 0; b < 3; ++b)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int c = b * 16 + l4 + 4 * reg;
-                if (c < cn) out[(long long)(c0 + c) * ldo + i0 + w * 16 + l15] = acc[b][reg];
-            }
+        for (int reg = 0; reg < 4; ++reg) {
+            const int c = l4 + 4 * reg;
+            if (c < cn) out[(long long)(c0 + c) * ldo + i0 + w * 16 + l15] = acc[reg];
+        }
     }
-    if (copy_src >= 0 && w == 0) out[(long long)copy_dst * ldo + i0 + lane] = V[(long long)copy_src * ldv + i0 + lane];
+    if (copy_src >= 0 && blockIdx.y == 0 && w == 0) out[(long long)copy_dst * ldo + i0 + lane] = V[(long long)copy_src * ldv + i0 + lane];
 }
 
 // ---------------------------------------------------------------------------

@@ -917,12 +917,12 @@ inline void Solver::rotate(EigWork& W, int K, const std::vector<double>& U, int 
     for (int q = 0; q < nextra; ++q) tmp[(size_t)K * ncols + q] = extra[q];
     W.U.upload(tmp, (size_t)K * ncols + (size_t)std::max(nextra, 0), stream);
     if (nextra > 0) W.arrow_p = W.U.p + (size_t)K * ncols;
-    // fp64 MFMA form from K = 32 / 16 columns on (skinny GEMM: 55-60 us -> ~15 us at K = 127); LDS: V tile + 48-column U group
+    // fp64 MFMA form from K = 32 / 16 columns on (skinny GEMM); grid = row tiles x groups of 16 columns; LDS: V tile + one U group
     {
         const int Kp = (K + 3) & ~3;
         const size_t lds_m = ((size_t)Kp * dev::RM_LDV + (size_t)dev::RM_CG * (Kp + 2)) * sizeof(double);
         if (K >= 32 && ncols >= 16 && (int)lds_m <= rotate_mfma_lds_cap) {
-            hipLaunchKernelGGL(dev::k_lz_rotate_mfma, dim3(W.nt), dim3(dev::TPB), lds_m, stream,
+            hipLaunchKernelGGL(dev::k_lz_rotate_mfma, dim3(W.nt, ceil_div(ncols, dev::RM_CG)), dim3(dev::TPB), lds_m, stream,
                                (const double*)W.V.p, W.npad, K, (const double*)W.U.p, ncols, out, W.npad, copy_src, copy_dst);
             return;
         }
