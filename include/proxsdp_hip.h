@@ -42,8 +42,11 @@ extern "C" {
  * 8 (round 4): proxsdp_options gained full_eig_lanczos_certify (from reserved_i) and full_eig_lanczos_tol (from
  * reserved_d) and host_merge_threads (from reserved_i), proxsdp_stats full_eigs_lanczos_certified / _cert_failed /
  * cert_matvecs (the last reserved slots):
- * same struct sizes and offsets; debug_fail_iteration now needs PROXSDP_HIP_FAULT_INJECTION=1 */
-#define PROXSDP_HIP_ABI_VERSION 8
+ * same struct sizes and offsets; debug_fail_iteration now needs PROXSDP_HIP_FAULT_INJECTION=1
+ * 9 (round 5): proxsdp_options grew at its END (equilibration_reference_aliasing, lanczos_device_restart, full_eig_block,
+ * new reserved slots -- offsets of every earlier member unchanged, struct_size larger); new proxsdp_state and
+ * proxsdp_hip_solve_ex (capture / resume of the solver state at an iteration boundary); PROXSDP_E_COMM_ABORTED */
+#define PROXSDP_HIP_ABI_VERSION 9
 
 /* error codes (negative return values) */
 #define PROXSDP_E_INVALID  (-1)   /* invalid argument / inconsistent problem data */
@@ -51,6 +54,9 @@ extern "C" {
 #define PROXSDP_E_NOMEM    (-3)   /* host or device allocation failed             */
 #define PROXSDP_E_UNSUPP   (-4)   /* option combination not implemented           */
 #define PROXSDP_E_INTERNAL (-5)
+#define PROXSDP_E_COMM_ABORTED (-6) /* block-sharded solve on the native RCCL path: the solve failed AND the library called
+                                     * ncclCommAbort on proxsdp_problem.nccl_comm -- the communicator is already released:
+                                     * it must NOT be destroyed or used again by the caller */
 
 /* solver status: Result.status, /root/reference/src/MOI_wrapper.jl:381-399 */
 #define PROXSDP_STATUS_NOT_CALLED       0
@@ -145,9 +151,12 @@ typedef struct proxsdp_problem {
      * reduce_fn / reduce_vec_fn may then be NULL (they are ignored).  librccl.so is loaded at run time
      * (dlopen): the library does not link it, and a process that never passes a communicator never loads it.
      * Every host wait behind one of these collectives is bounded (PROXSDP_HIP_COLLECTIVE_TIMEOUT_S seconds, default
-     * 300): a rank whose peer left the solve aborts its communicator (ncclCommAbort) and returns PROXSDP_E_INTERNAL
-     * instead of waiting for ever; a rank that fails for its own reasons aborts its communicator on the way out.  An
-     * aborted communicator must be destroyed by the caller, not reused. */
+     * 300): a rank whose peer left the solve aborts its communicator (ncclCommAbort) and returns
+     * PROXSDP_E_COMM_ABORTED instead of waiting for ever; a rank that fails for its own reasons AFTER its first collective
+     * was enqueued aborts its communicator on the way out and returns PROXSDP_E_COMM_ABORTED as well (a failure before any
+     * collective -- argument errors -- leaves the communicator untouched and returns the ordinary error code).
+     * ncclCommAbort RELEASES the communicator: after PROXSDP_E_COMM_ABORTED the handle is dead -- do not pass it to
+     * proxsdp_hip_rccl_comm_destroy / ncclCommDestroy, do not reuse it. */
     void* nccl_comm;
     int64_t reserved3;
 } proxsdp_problem;
@@ -323,6 +332,24 @@ typedef struct proxsdp_options {
     double  full_eig_lanczos_tol;/* convergence of the POSITIVE Ritz pairs of that engine: residual <= tol x the spectral
                                   * scale; 0 (default) = krylovkit_tol as an absolute residual (KrylovKit's rule) */
     double  reserved_d[1];       /* zero */
+    /* ---- ABI 9 (appended) ---- */
+    int32_t equilibration_reference_aliasing; /* equilibrate! (equilibration.jl:1-72) builds `E = Diagonal(u)`, `D = Diagonal(v)`
+                                  * WITHOUT copying (:16-17), so `E.diag .= exp.(u)` (:25-26) overwrites u with exp(u) (v with
+                                  * exp(v)) at the top of every iteration and the gradient steps start from there.  1 (default):
+                                  * that arithmetic, line by line -- what the reference computes; 0: the iteration the code
+                                  * evidently intends (u, v kept; E = exp(u), D = exp(v)): rounds 1-4 behaviour */
+    int32_t lanczos_device_restart; /* thick restart of a KrylovKit run without a host round trip: the K x K Rayleigh-quotient
+                                  * eigensolve, the convergence test, keep = (3K + 2 conv) / 5 and the rotation coefficients are
+                                  * computed by ONE workgroup on the device and the next cycle's launches are already enqueued
+                                  * (they turn into no-ops once the run has ended); the host reads one record per projection.
+                                  * -1 auto (krylovdim <= 40, several restarts expected), 0 off, 1 whenever krylovdim <= 40 */
+    int32_t full_eig_block;      /* the Lanczos-served full_eig! (full_eig_lanczos) warm-started by BLOCK subspace iteration:
+                                  * the previous projection's positive Ritz basis (+ guard columns) is pushed through a
+                                  * Chebyshev filter in ONE launch per operator application (block operator form) and
+                                  * Rayleigh-Ritz'ed; accepted under the same per-call certificate, single-vector run as the
+                                  * fall-back.  -1 auto, 0 off, 1 on */
+    int32_t reserved_i2[9];      /* zero */
+    double  reserved_d2[4];      /* zero */
 } proxsdp_options;
 
 #define PROXSDP_TRACE_COLS 14
@@ -417,6 +444,36 @@ typedef struct proxsdp_result {
     proxsdp_stats stats;
 } proxsdp_result;
 
+/* State of a solve at an ITERATION BOUNDARY (after iteration `iteration`'s control logic, pdhg.jl:246-483, before
+ * primal_step! of the next one): everything chambolle_pock carries from one iteration to the next.  At that point
+ * x_old = x, y_old = y, Mty_old = Mty, Mx_old = Mx (residuals.jl:65-68), so four vectors suffice.  Vectors are in the
+ * solver's INTERNAL order and scaling (preprocess! + norm_scaling, scaling.jl:2-49: cone variables first, PSD
+ * off-diagonals carrying sqrt(2)).  Test / measurement seam (oracle resume-from-state, steady-window baselines): the
+ * eigensolver workspaces are not part of it -- the reference's KrylovKit start vector is fixed
+ * (krylovkit_reset_resid = false) and the library's own caches (previous Ritz factors, engine statistics) are rebuilt.
+ * Not available during a certificate search, for block-sharded solves or with equilibration. */
+#define PROXSDP_STATE_NHIST 7
+typedef struct proxsdp_state {
+    int64_t struct_size;       /* = sizeof(proxsdp_state) */
+    int64_t iteration;         /* capture: IN  the iteration to capture after (>= 1); resume: the iteration the state belongs to */
+    int64_t n, Q, n_psd;       /* array lengths; must equal the problem's n, p + m, n_psd */
+    int64_t hist_len;          /* = 2 * options.convergence_window */
+    double* x;                 /* n */
+    double* y;                 /* Q */
+    double* Mty;               /* n */
+    double* Mx;                /* Q */
+    int64_t* target_rank;      /* n_psd (Params.target_rank, structs.jl:159-192) */
+    int64_t* current_rank;     /* n_psd */
+    double* min_eig;           /* n_psd */
+    double* hist;              /* PROXSDP_STATE_NHIST x hist_len, raw circular storage (structs.jl:2-30: entry i at slot
+                                * (i-1) mod hist_len): dual_gap | prim_obj | dual_obj | feasibility | primal_residual |
+                                * dual_residual | comb_residual */
+    double scal[16];           /* 0 primal_step 1 primal_step_old 2 dual_step 3 beta 4 theta 5 adapt_level
+                                * 6 equa_feasibility 7 ineq_feasibility 8 dual_feasibility; rest zero */
+    int64_t ints[8];           /* 0 rank_update 1 update_cont 2 ada_count (pdhg.jl:306-332) 3 OUT captured (1 = written);
+                                * rest zero */
+} proxsdp_state;
+
 /* ------------------------------------------------------------------ drop-in */
 int  proxsdp_hip_abi_version(void);
 void proxsdp_hip_default_options(proxsdp_options* opt);          /* options.jl defaults */
@@ -427,6 +484,12 @@ int  proxsdp_hip_get_option(const proxsdp_options* opt, const char* name, double
 /* replaces chambolle_pock(aff, con, opt) -- MOI_wrapper.jl:310, pdhg.jl:1-530 */
 int  proxsdp_hip_solve(const proxsdp_problem* prob, const proxsdp_options* opt,
                        proxsdp_result* res);
+/* the same solve with the state seam: `resume` (may be NULL) = continue from this state with iteration
+ * resume->iteration + 1 instead of starting at pdhg.jl:54-142's initial point; `capture` (may be NULL) = write the state
+ * after iteration capture->iteration into the caller-allocated arrays (capture->ints[3] = 1 when that iteration was
+ * reached).  proxsdp_hip_solve(p, o, r) == proxsdp_hip_solve_ex(p, o, r, NULL, NULL). */
+int  proxsdp_hip_solve_ex(const proxsdp_problem* prob, const proxsdp_options* opt, proxsdp_result* res,
+                          const proxsdp_state* resume, proxsdp_state* capture);
 const char* proxsdp_hip_last_error(void);
 int  proxsdp_hip_device_count(void);          /* <0: PROXSDP_E_HIP */
 

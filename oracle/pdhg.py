@@ -109,6 +109,7 @@ class Result:                # structs.jl:60-81
     # not in the reference: instrumentation used by tests / bench
     stats: dict = field(default_factory=dict)
     trace: list = field(default_factory=list)
+    state: dict = None           # export_state() at capture_iteration (chambolle_pock's test seam)
 
 
 class Residuals:             # structs.jl:100-125
@@ -578,11 +579,67 @@ def cache_solution(st, res, cones, aff, p, opt, c, A, b, G, h, var_ordering, a, 
         stats=dict(p.stats, dual_feasibility=dfeas))
 
 
+STATE_HIST = ("dual_gap", "prim_obj", "dual_obj", "feasibility", "primal_residual", "dual_residual", "comb_residual")
+STATE_SCAL = ("primal_step", "primal_step_old", "dual_step", "beta", "theta", "adapt_level")
+
+
+def export_state(st, a, p, res, ada_count):
+    """Everything chambolle_pock carries across an iteration boundary (after the control logic of iteration p.iter,
+    pdhg.jl:246-483): the same dictionary proxsdp_hip_solve_ex captures / resumes (include/proxsdp_hip.h
+    proxsdp_state).  x_old = x, y_old = y, Mty_old = Mty, Mx_old = Mx hold there (residuals.jl:65-68); the
+    KrylovKit start vector is fixed (krylovkit_reset_resid = false), so no eigensolver state is carried."""
+    d = dict(iteration=int(p.iter), x=st.x.copy(), y=st.y.copy(), Mty=np.asarray(a.Mty, float).copy(),
+             Mx=np.asarray(a.Mx, float).copy(),
+             target_rank=np.asarray(p.target_rank, np.int64).copy(),
+             current_rank=np.asarray(p.current_rank, np.int64).copy(),
+             min_eig=np.asarray(p.min_eig, float).copy(),
+             hist=np.stack([getattr(res, nme).v.copy() for nme in STATE_HIST]),
+             rank_update=int(p.rank_update), update_cont=int(p.update_cont), ada_count=int(ada_count),
+             equa_feasibility=float(res.equa_feasibility), ineq_feasibility=float(res.ineq_feasibility),
+             dual_feasibility=float(p.dual_feasibility))
+    for nme in STATE_SCAL:
+        d[nme] = float(getattr(p, nme))
+    return d
+
+
+def _import_state(state, st, a, p, res, aff):
+    nQ = aff.p + aff.m
+    if len(state["x"]) != aff.n or len(state["y"]) != nQ or len(state["Mty"]) != aff.n or len(state["Mx"]) != nQ:
+        raise ValueError("resume state does not match the problem")
+    st.x = np.array(state["x"], dtype=float)
+    st.x_old = st.x.copy()
+    st.y = np.array(state["y"], dtype=float)
+    st.y_old = st.y.copy()
+    a.Mty = np.array(state["Mty"], dtype=float)
+    a.Mty_old = a.Mty.copy()
+    a.Mx = np.array(state["Mx"], dtype=float)
+    a.Mx_old = a.Mx.copy()
+    for nme in STATE_SCAL:
+        setattr(p, nme, float(state[nme]))
+    p.target_rank = np.array(state["target_rank"], dtype=np.int64)
+    p.current_rank = np.array(state["current_rank"], dtype=np.int64)
+    p.min_eig = np.array(state["min_eig"], dtype=float)
+    p.rank_update, p.update_cont = int(state["rank_update"]), int(state["update_cont"])
+    p.dual_feasibility = float(state.get("dual_feasibility", -1.0))
+    res.equa_feasibility = float(state.get("equa_feasibility", 0.0))
+    res.ineq_feasibility = float(state.get("ineq_feasibility", 0.0))
+    h = np.asarray(state["hist"], dtype=float)
+    if h.shape != (len(STATE_HIST), 2 * p.window):
+        raise ValueError("resume state: hist must be 7 x 2*convergence_window")
+    for q, nme in enumerate(STATE_HIST):
+        getattr(res, nme).v[:] = h[q]
+    p.iter = int(state["iteration"])
+    return int(state["ada_count"])
+
+
 def chambolle_pock(aff_in, cones, opt_in=None, *, eig_resid=None, trace=False,
-                   iter_callback=None, proj_callback=None):
+                   iter_callback=None, proj_callback=None, resume=None, capture_iteration=None):
     """chambolle_pock (pdhg.jl:1-530).  `aff_in` and `opt_in` are not mutated
     (the reference mutates both; the C ABI must not -- SURVEY.md section 8b).
-    eig_resid: optional list of start vectors, one per PSD block."""
+    eig_resid: optional list of start vectors, one per PSD block.
+    resume: a state dictionary (export_state, or the library's proxsdp_hip_solve_ex capture): the loop continues with
+    iteration state['iteration'] + 1 from that iterate instead of pdhg.jl:54-142's initial point (test seam: late
+    windows of long solves).  capture_iteration: k -> Result.state = export_state after iteration k."""
     opt = (opt_in or Options()).copy()
     aff = AffineSets(aff_in.n, aff_in.p, aff_in.m,
                      sp.csc_matrix(aff_in.A, dtype=float).copy(), sp.csc_matrix(aff_in.G, dtype=float).copy(),
@@ -681,10 +738,19 @@ def chambolle_pock(aff_in, cones, opt_in=None, *, eig_resid=None, trace=False,
         a.Mx_old = M @ st.x_old
 
     tr = []
-    t_loop0 = time.time()
+    captured = None
     k = 0
+    if resume is not None:
+        if opt.equilibration:
+            raise ValueError("resume: not with equilibration")
+        ada_count = _import_state(resume, st, a, p, res, aff)
+        k = p.iter
+    t_loop0 = time.time()
     kmax = 2 * opt.max_iter_local
     while k < kmax:
+        if capture_iteration is not None and captured is None and k == capture_iteration and k > 0 \
+                and not (resume is not None and k == int(resume["iteration"])):
+            captured = export_state(st, a, p, res, ada_count)
         k += 1
         p.iter = k
         primal_step(st, a, cones, M, aff.c, opt, p, arc_list, proj_callback)
@@ -900,6 +966,8 @@ def chambolle_pock(aff_in, cones, opt_in=None, *, eig_resid=None, trace=False,
                     break
 
     loop_time = time.time() - t_loop0
+    if capture_iteration is not None and captured is None and p.iter == capture_iteration:
+        captured = export_state(st, a, p, res, ada_count)
     p.stats["loop_time"] = loop_time
     p.stats["lanczos_matvecs"] = int(sum(arc.matvecs for arc in arc_list))
     p.stats["lanczos_restarts"] = int(sum(arc.restarts for arc in arc_list))
@@ -920,5 +988,6 @@ def chambolle_pock(aff_in, cones, opt_in=None, *, eig_resid=None, trace=False,
         sol.append(_final_cache(c_orig))
     out = sol[0]
     out.trace = tr
+    out.state = captured
     out.stats.update(p.stats)
     return out

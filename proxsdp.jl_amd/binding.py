@@ -112,6 +112,8 @@ def _opt_fields():
     a("host_eig_merge", i32); a("block_batch", i32); a("rocsolver_warmup", i32); a("debug_fail_iteration", i32); a("host_wait_spin", i32)
     a("sign_start_row", i32); a("general_batch", i32); a("full_eig_lanczos_certify", i32); a("host_merge_threads", i32); a("reserved_i", i32 * 1)
     a("full_eig_lanczos_tol", f64); a("reserved_d", f64 * 1)
+    a("equilibration_reference_aliasing", i32); a("lanczos_device_restart", i32); a("full_eig_block", i32)
+    a("reserved_i2", i32 * 9); a("reserved_d2", f64 * 4)
     return F
 
 
@@ -149,6 +151,19 @@ class Result(C.Structure):
                 ("primal", pf64), ("dual_cone", pf64), ("dual_eq", pf64), ("dual_in", pf64),
                 ("slack_eq", pf64), ("slack_in", pf64), ("trace", pf64), ("trace_rows", i64),
                 ("status_string", C.c_char * 256), ("stats", Stats)]
+
+
+STATE_NHIST = 7
+STATE_HIST_NAMES = ("dual_gap", "prim_obj", "dual_obj", "feasibility", "primal_residual", "dual_residual", "comb_residual")
+STATE_SCAL_NAMES = ("primal_step", "primal_step_old", "dual_step", "beta", "theta", "adapt_level",
+                    "equa_feasibility", "ineq_feasibility", "dual_feasibility")
+
+
+class State(C.Structure):
+    _fields_ = [("struct_size", i64), ("iteration", i64), ("n", i64), ("Q", i64), ("n_psd", i64), ("hist_len", i64),
+                ("x", pf64), ("y", pf64), ("Mty", pf64), ("Mx", pf64),
+                ("target_rank", pi64), ("current_rank", pi64), ("min_eig", pf64), ("hist", pf64),
+                ("scal", f64 * 16), ("ints", i64 * 8)]
 
 
 _lib = None
@@ -190,6 +205,8 @@ def lib():
     L.proxsdp_hip_set_option.argtypes = [C.POINTER(Options), C.c_char_p, f64]
     L.proxsdp_hip_get_option.argtypes = [C.POINTER(Options), C.c_char_p, pf64]
     L.proxsdp_hip_solve.argtypes = [C.POINTER(Problem), C.POINTER(Options), C.POINTER(Result)]
+    L.proxsdp_hip_solve_ex.argtypes = [C.POINTER(Problem), C.POINTER(Options), C.POINTER(Result),
+                                       C.POINTER(State), C.POINTER(State)]
     L.proxsdp_hip_psd_project.argtypes = [pf64, i64, i32, i32, C.POINTER(Options), pf64, pf64,
                                           C.POINTER(i32), pf64, pi64, C.POINTER(i32), C.POINTER(i32)]
     L.proxsdp_hip_eigsolve.argtypes = [pf64, i64, i32, C.POINTER(Options), pf64, i32, pf64, pf64,
@@ -205,7 +222,7 @@ def lib():
     L.proxsdp_hip_rccl_unique_id.argtypes = [C.c_void_p]
     L.proxsdp_hip_rccl_comm_init.argtypes = [i32, C.c_void_p, i32, i32, C.POINTER(C.c_void_p)]
     L.proxsdp_hip_rccl_comm_destroy.argtypes = [C.c_void_p]
-    if L.proxsdp_hip_abi_version() != 8:
+    if L.proxsdp_hip_abi_version() != 9:
         raise ProxSDPHipError(-1, "ABI version mismatch")
     _lib = L
     return L
@@ -356,7 +373,52 @@ def rccl_comm_destroy(comm):
         _check(lib().proxsdp_hip_rccl_comm_destroy(C.c_void_p(comm)))
 
 
-def solve(prob, options=None, eig_resid=None, trace_capacity=0, reduce=None, coupling=None, index_base=0, nccl_comm=None):
+def _state_struct(n, Q, n_psd, window, state=None, iteration=0):
+    """proxsdp_state over fresh numpy arrays (filled from the dict `state` when given).  Returns (struct, arrays)."""
+    hl = 2 * int(window)
+    arr = dict(x=np.zeros(max(n, 1)), y=np.zeros(max(Q, 1)), Mty=np.zeros(max(n, 1)), Mx=np.zeros(max(Q, 1)),
+               target_rank=np.zeros(max(n_psd, 1), dtype=np.int64), current_rank=np.zeros(max(n_psd, 1), dtype=np.int64),
+               min_eig=np.zeros(max(n_psd, 1)), hist=np.zeros((STATE_NHIST, hl)))
+    S = State()
+    S.struct_size = C.sizeof(State)
+    S.iteration, S.n, S.Q, S.n_psd, S.hist_len = int(iteration), n, Q, n_psd, hl
+    if state is not None:
+        S.iteration = int(state["iteration"])
+        for k in ("x", "y", "Mty", "Mx", "min_eig"):
+            v = _f(state[k]).ravel()
+            if len(v) != {"x": n, "Mty": n, "y": Q, "Mx": Q, "min_eig": n_psd}[k]:
+                raise ValueError(f"state[{k!r}] has the wrong length")
+            arr[k][:len(v)] = v
+        for k in ("target_rank", "current_rank"):
+            v = _i(state[k]).ravel()
+            if len(v) != n_psd:
+                raise ValueError(f"state[{k!r}] has the wrong length")
+            arr[k][:len(v)] = v
+        h = np.asarray(state["hist"], dtype=np.float64)
+        if h.shape != (STATE_NHIST, hl):
+            raise ValueError("state['hist'] must be 7 x 2*convergence_window")
+        arr["hist"][:] = h
+        for q, nme in enumerate(STATE_SCAL_NAMES):
+            S.scal[q] = float(state[nme])
+        S.ints[0], S.ints[1], S.ints[2] = int(state["rank_update"]), int(state["update_cont"]), int(state["ada_count"])
+    S.x, S.y, S.Mty, S.Mx = _p(arr["x"]), _p(arr["y"]), _p(arr["Mty"]), _p(arr["Mx"])
+    S.target_rank, S.current_rank = _p(arr["target_rank"], pi64), _p(arr["current_rank"], pi64)
+    S.min_eig, S.hist = _p(arr["min_eig"]), _p(arr["hist"])
+    return S, arr
+
+
+def _state_dict(S, arr, n, Q, n_psd):
+    d = dict(iteration=int(S.iteration), x=arr["x"][:n].copy(), y=arr["y"][:Q].copy(), Mty=arr["Mty"][:n].copy(),
+             Mx=arr["Mx"][:Q].copy(), target_rank=arr["target_rank"][:n_psd].copy(),
+             current_rank=arr["current_rank"][:n_psd].copy(), min_eig=arr["min_eig"][:n_psd].copy(),
+             hist=arr["hist"].copy(), rank_update=int(S.ints[0]), update_cont=int(S.ints[1]), ada_count=int(S.ints[2]))
+    for q, nme in enumerate(STATE_SCAL_NAMES):
+        d[nme] = float(S.scal[q])
+    return d
+
+
+def solve(prob, options=None, eig_resid=None, trace_capacity=0, reduce=None, coupling=None, index_base=0, nccl_comm=None,
+          resume=None, capture_iteration=None):
     """proxsdp_hip_solve: replaces chambolle_pock(aff, con, options) (MOI_wrapper.jl:310).
     Returns the minimisation objective; sign/constant fix-up is the caller's
     (MOI_wrapper.jl:336-337), see optimizer.Optimizer.
@@ -366,7 +428,10 @@ def solve(prob, options=None, eig_resid=None, trace_capacity=0, reduce=None, cou
     reduce_vec=callable(ptr: int, length: int, on_device: bool) -> None summing the buffer in place over
     the shards, on_device=bool) -- the rows shared with other shards (proxsdp_problem.coupling_rows).
     nccl_comm: optional RCCL communicator handle (rccl_comm_init): the library then reduces the scalar record and
-    the coupling rows itself on its own stream (proxsdp_problem.nccl_comm); `reduce` / reduce_vec are not used."""
+    the coupling rows itself on its own stream (proxsdp_problem.nccl_comm); `reduce` / reduce_vec are not used.
+    resume: optional state dict (as returned in `.state`, or by oracle.export_state) -- the solve continues with iteration
+    state['iteration'] + 1 (proxsdp_hip_solve_ex); capture_iteration: k >= 1 -- the state after iteration k comes back as
+    `.state` (None when the solve ended before k).  Vectors are in the solver's internal order and scaling."""
     L = lib()
     o = options if options is not None else default_options()
     if trace_capacity:
@@ -417,9 +482,22 @@ def solve(prob, options=None, eig_resid=None, trace_capacity=0, reduce=None, cou
     R = Result()
     R.primal, R.dual_cone, R.dual_eq, R.dual_in, R.slack_eq, R.slack_in = [_p(a) for a in arrays]
     R.trace = _p(trace)
-    _check(L.proxsdp_hip_solve(C.byref(M.P), C.byref(o), C.byref(R)))
+    if resume is None and capture_iteration is None:
+        _check(L.proxsdp_hip_solve(C.byref(M.P), C.byref(o), C.byref(R)))
+        arrays = [a[:k] for a, k in zip(arrays, (n, n, p, m, p, m))]
+        return SolveResult(R, n, p, m, arrays, trace)
+    Q, nb = p + m, int(M.P.n_psd)
+    rs = cs = None
+    if resume is not None:
+        rs, rarr = _state_struct(n, Q, nb, o.convergence_window, state=resume)
+    if capture_iteration is not None:
+        cs, carr = _state_struct(n, Q, nb, o.convergence_window, iteration=capture_iteration)
+    _check(L.proxsdp_hip_solve_ex(C.byref(M.P), C.byref(o), C.byref(R),
+                                  C.byref(rs) if rs is not None else None, C.byref(cs) if cs is not None else None))
     arrays = [a[:k] for a, k in zip(arrays, (n, n, p, m, p, m))]
-    return SolveResult(R, n, p, m, arrays, trace)
+    out = SolveResult(R, n, p, m, arrays, trace)
+    out.state = _state_dict(cs, carr, n, Q, nb) if (cs is not None and cs.ints[3] == 1) else None
+    return out
 
 
 # ----------------------------------------------------------------- kernel-level entry points

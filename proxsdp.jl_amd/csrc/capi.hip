@@ -148,7 +148,13 @@ int proxsdp_hip_device_count(void) {
 }
 
 int proxsdp_hip_solve(const proxsdp_problem* prob, const proxsdp_options* opt, proxsdp_result* res) {
-    return guarded([&]() -> int {
+    return proxsdp_hip_solve_ex(prob, opt, res, nullptr, nullptr);
+}
+
+int proxsdp_hip_solve_ex(const proxsdp_problem* prob, const proxsdp_options* opt, proxsdp_result* res,
+                         const proxsdp_state* resume, proxsdp_state* capture) {
+    bool comm_aborted = false;
+    const int rc = guarded([&]() -> int {
         if (!prob || !res) throw std::invalid_argument("NULL problem or result");
         proxsdp_options o = Engine::fix(opt);
         res->status = PROXSDP_STATUS_NOT_CALLED;
@@ -158,16 +164,26 @@ int proxsdp_hip_solve(const proxsdp_problem* prob, const proxsdp_options* opt, p
         res->status_string[0] = 0;
         if (o.trace_capacity > 0 && !res->trace) o.trace_capacity = 0;
         proxsdp::Solver S(*prob, o, *res);
+        S.resume_state = resume;
+        S.capture_state = capture;
         try {
             S.run();
         } catch (...) {
             // native RCCL path: this rank leaves the solve -- stop its own pending collectives so that its stream drains;
-            // the peers' waits are bounded (Solver::wait_collective) and fail the same way
-            if (S.nccl && !S.nccl_aborted) S.abort_comm();
+            // the peers' waits are bounded (Solver::wait_collective) and fail the same way.  Only when a collective of this
+            // solve may be pending: an argument error raised before the first one leaves the caller's communicator alone
+            // (ADVICE r4).  ncclCommAbort releases the communicator: the caller learns it through PROXSDP_E_COMM_ABORTED.
+            if (S.nccl && !S.nccl_aborted && S.collective_enqueued) S.abort_comm();
+            comm_aborted = S.nccl_aborted;
             throw;
         }
         return 0;
     });
+    if (rc != 0 && comm_aborted) {
+        g_last_error += " [the RCCL communicator was aborted (ncclCommAbort): it is released, do not destroy or reuse it]";
+        return PROXSDP_E_COMM_ABORTED;
+    }
+    return rc;
 }
 
 int proxsdp_hip_psd_project(const double* packed_in, int64_t n, int32_t target_rank, int32_t mode,

@@ -55,6 +55,7 @@ inline void Solver::reduce_coupling(double* Mx_dev) {
     if (nccl) {
         // native: in-place sum over the shards on THIS stream -- no host synchronisation, no callback
         Rccl& rc = Rccl::get();
+        collective_enqueued = true;
         rc.check(rc.AllReduce(coup_buf_d.p, coup_buf_d.p, (size_t)nc, ncclFloat64, ncclSum, nccl, stream), "ncclAllReduce");
         st.rccl_reductions++;
     } else if (reduce_vec_on_device) {
@@ -1228,6 +1229,7 @@ inline int Solver::linesearch_residual_support() {
     dual_step = beta * primal_step;
     st.linesearch_trials += trials;
     // ---- residuals and gap from the accepted candidate's scalars
+    const double tr0 = now_s();
     const double m0 = std::max(s_acc[2], hbscal[NC * 11]);
     const double m1 = std::max(s_acc[3], hbscal[NC * 11 + 1]);
     const double pres = std::sqrt(g_n) * m0 / std::max({m1, g_norm_b, g_norm_h, 1.0});
@@ -1246,6 +1248,7 @@ inline int Solver::linesearch_residual_support() {
     h_dobj.at(iter) = d_o;
     h_gap.at(iter) = std::fabs(po - d_o) / (1.0 + std::fabs(po) + std::fabs(d_o));
     xc = 1 - xc; yc = 1 - yc; mxc = 1 - mxc;
+    last_resid_s = now_s() - tr0;
     return trials;
 }
 
@@ -1347,6 +1350,7 @@ inline int Solver::linesearch_residual_general() {
     dual_step = beta * primal_step;
     st.linesearch_trials += trials;
     // ---- residuals and gap from the accepted candidate's scalars (residual_and_gap)
+    const double tr0 = now_s();
     const double* s = s_acc + 2;
     if (debug && iter <= 5)
         std::fprintf(stderr, "[dbg] it %lld res: %.6e %.6e cx %.6e | %.6e %.6e eq %.6e in %.6e by %.6e hy %.6e\n",
@@ -1367,6 +1371,7 @@ inline int Solver::linesearch_residual_general() {
     h_dobj.at(iter) = d_o;
     h_gap.at(iter) = std::fabs(po - d_o) / (1.0 + std::fabs(po) + std::fabs(d_o));
     xc = 1 - xc; mtyc = 1 - mtyc; yc = 1 - yc; mxc = 1 - mxc;
+    last_resid_s = now_s() - tr0;
     return trials;
 }
 
@@ -1398,6 +1403,91 @@ inline void Solver::test_spmv(bool transpose, const double* in, double* out) {
         spmv(xin.p, xout.p);
     xout.download(out, transpose ? P.n : P.Q, stream);
     PX_HIP(hipStreamSynchronize(stream));
+}
+
+// ---- state seam (include/proxsdp_hip.h proxsdp_state)
+inline void Solver::check_state_shape(const proxsdp_state& s, const char* what) const {
+    const std::string w(what);
+    if (s.struct_size != (int64_t)sizeof(proxsdp_state)) throw std::invalid_argument(w + " state: struct_size mismatch");
+    if (s.n != P.n || s.Q != P.Q || s.n_psd != (int64_t)P.blocks.size())
+        throw std::invalid_argument(w + " state: n / Q / n_psd do not match the problem");
+    if (s.hist_len != 2 * (int64_t)opt.convergence_window)
+        throw std::invalid_argument(w + " state: hist_len must be 2 * convergence_window");
+    if (s.iteration < 1) throw std::invalid_argument(w + " state: iteration must be >= 1");
+    if (!s.x || !s.Mty || !s.hist || (P.Q > 0 && (!s.y || !s.Mx)) ||
+        (!P.blocks.empty() && (!s.target_rank || !s.current_rank || !s.min_eig)))
+        throw std::invalid_argument(w + " state: NULL array");
+    if (sharded() || P.equilibrated) throw std::domain_error("state capture / resume: not with a block-sharded solve or equilibration");
+}
+
+// continue from resume_state: called after the "Init" section built every buffer; overwrites the initial point
+inline void Solver::apply_resume() {
+    const proxsdp_state& s = *resume_state;
+    check_state_shape(s, "resume");
+    xbuf[xc].upload(s.x, P.n, stream);
+    ybuf[yc].upload(s.y, P.Q, stream);
+    Mxbuf[mxc].upload(s.Mx, P.Q, stream);
+    Mtybuf[mtyc].upload(s.Mty, P.n, stream);
+    std::vector<double> mtyS;
+    if (use_support) {                                   // the support path carries M'y on the support only
+        std::vector<int> supp(ns);
+        supp_d.download(supp.data(), ns, stream);
+        PX_HIP(hipStreamSynchronize(stream));
+        mtyS.resize(std::max(ns, 1), 0.0);
+        for (int q = 0; q < ns; ++q) mtyS[q] = s.Mty[supp[q]];
+        MtyS_cur.upload(mtyS.data(), ns, stream);
+    }
+    PX_HIP(hipStreamSynchronize(stream));
+    primal_step = s.scal[0]; primal_step_old = s.scal[1]; dual_step = s.scal[2];
+    beta = s.scal[3]; theta = s.scal[4]; adapt_level = s.scal[5];
+    equa_feasibility = s.scal[6]; ineq_feasibility = s.scal[7]; dual_feasibility = s.scal[8];
+    rank_update = (int)s.ints[0]; update_cont = (int)s.ints[1]; ada_count = (int)s.ints[2];
+    for (size_t idx = 0; idx < P.blocks.size(); ++idx) {
+        target_rank[idx] = std::min<long long>(std::max<long long>(s.target_rank[idx], 1), P.blocks[idx].n);
+        current_rank[idx] = s.current_rank[idx];
+        min_eig[idx] = s.min_eig[idx];
+    }
+    CircularVector* H[PROXSDP_STATE_NHIST] = {&h_gap, &h_pobj, &h_dobj, &h_feas, &h_pres, &h_dres, &h_comb};
+    for (int q = 0; q < PROXSDP_STATE_NHIST; ++q)
+        std::copy(s.hist + (size_t)q * s.hist_len, s.hist + (size_t)(q + 1) * s.hist_len, H[q]->v.begin());
+    iter = s.iteration;
+    // the iterate is a general matrix now: neither zero off the support nor known in factored form
+    for (EigWork& W : eig) { W.have_factors = false; W.x_prev_sparse = false; }
+}
+
+// write capture_state: the stream is idle (every iteration ends with a synchronisation)
+inline void Solver::write_capture() {
+    proxsdp_state& s = *capture_state;
+    if (certificate_search) throw std::domain_error("state capture: not during a certificate search");
+    PX_HIP(hipStreamSynchronize(stream));
+    harvest_small_ranks();
+    xbuf[xc].download(s.x, P.n, stream);
+    ybuf[yc].download(s.y, P.Q, stream);
+    Mxbuf[mxc].download(s.Mx, P.Q, stream);
+    if (use_support) {
+        std::vector<int> supp(ns);
+        std::vector<double> mtyS(std::max(ns, 1), 0.0);
+        supp_d.download(supp.data(), ns, stream);
+        MtyS_cur.download(mtyS.data(), ns, stream);
+        PX_HIP(hipStreamSynchronize(stream));
+        std::fill(s.Mty, s.Mty + P.n, 0.0);
+        for (int q = 0; q < ns; ++q) s.Mty[supp[q]] = mtyS[q];
+    } else {
+        Mtybuf[mtyc].download(s.Mty, P.n, stream);
+    }
+    PX_HIP(hipStreamSynchronize(stream));
+    std::fill(std::begin(s.scal), std::end(s.scal), 0.0);
+    std::fill(std::begin(s.ints), std::end(s.ints), 0);
+    s.scal[0] = primal_step; s.scal[1] = primal_step_old; s.scal[2] = dual_step;
+    s.scal[3] = beta; s.scal[4] = theta; s.scal[5] = adapt_level;
+    s.scal[6] = equa_feasibility; s.scal[7] = ineq_feasibility; s.scal[8] = dual_feasibility;
+    s.ints[0] = rank_update; s.ints[1] = update_cont; s.ints[2] = ada_count;
+    for (size_t idx = 0; idx < P.blocks.size(); ++idx) {
+        s.target_rank[idx] = target_rank[idx]; s.current_rank[idx] = current_rank[idx]; s.min_eig[idx] = min_eig[idx];
+    }
+    CircularVector* H[PROXSDP_STATE_NHIST] = {&h_gap, &h_pobj, &h_dobj, &h_feas, &h_pres, &h_dres, &h_comb};
+    for (int q = 0; q < PROXSDP_STATE_NHIST; ++q) std::copy(H[q]->v.begin(), H[q]->v.end(), s.hist + (size_t)q * s.hist_len);
+    s.ints[3] = 1;
 }
 
 // chambolle_pock (pdhg.jl:1-530)
@@ -1445,7 +1535,7 @@ inline void Solver::run() {
         throw std::domain_error("block-sharded solve: check_dual_feas / dense vector passes / no linesearch not implemented");
     if (opt.max_iter <= 0) max_iter_local = g_conic ? opt.max_iter_conic : opt.max_iter_lp;
     else max_iter_local = opt.max_iter;
-    int ada_count = 0;
+    ada_count = 0;
     h_gap.init(2 * window); h_pobj.init(2 * window); h_dobj.init(2 * window); h_feas.init(2 * window);
     h_pres.init(2 * window); h_dres.init(2 * window); h_comb.init(2 * window);
     b_host = P.b; h_host = P.h; c_host = P.c;
@@ -1598,6 +1688,9 @@ inline void Solver::run() {
         PX_HIP(hipStreamSynchronize(stream));
     }
     PX_HIP(hipStreamSynchronize(stream));
+    long long k_first = 1;
+    if (resume_state) { apply_resume(); k_first = resume_state->iteration + 1; }
+    if (capture_state) { check_state_shape(*capture_state, "capture"); capture_state->ints[3] = 0; }
     st.init_time = now_s() - t_init0;
 
     auto snapshot = [&]() { cache_solution(P.c_orig); };
@@ -1618,18 +1711,23 @@ inline void Solver::run() {
     // ---- "CP loop" (pdhg.jl:145-484)
     const double t_loop0 = now_s();
     const long long kmax = 2 * max_iter_local;
-    for (long long k = 1; k <= kmax; ++k) {
+    for (long long k = k_first; k <= kmax; ++k) {
+        if (capture_state && k == capture_state->iteration + 1 && k > k_first) write_capture();
         iter = k;
         lz_matvec_iter = 0; recon_r_iter = 0;
+        const double tp0 = now_s();
         primal_step_dev();
+        st.t_primal += now_s() - tp0;                    // "primal" section of pdhg.jl:150 (includes t_psd)
         const double tl0 = now_s();
         if (use_support) {
+            // (fused paths: the residual / gap REDUCTIONS ride in the candidates' batch and its one read-back -- they are
+            // part of t_linesearch; t_residual counts what is left of compute_residual! / compute_gap!: the host scalars)
             last_trials = linesearch_residual_support();
-            st.t_linesearch += now_s() - tl0;
+            st.t_linesearch += now_s() - tl0 - last_resid_s; st.t_residual += last_resid_s;
         } else {
             if (opt.line_search_flag && !P.dense() && !sharded() && opt.general_batch != 0) {
                 last_trials = linesearch_residual_general();       // trials + residual + gap in one batch and one read-back
-                st.t_linesearch += now_s() - tl0;
+                st.t_linesearch += now_s() - tl0 - last_resid_s; st.t_residual += last_resid_s;
             } else {
             if (opt.line_search_flag) last_trials = P.dense() ? linesearch_dense() : linesearch();
             else { dual_step_plain(); last_trials = 1; }
@@ -1829,6 +1927,7 @@ inline void Solver::run() {
         }
     }
     PX_HIP(hipStreamSynchronize(stream));
+    if (capture_state && capture_state->ints[3] == 0 && iter == capture_state->iteration) write_capture();
     for (EigWork& W : eig) harvest_full_eig_events(W);
     merge_block_stats();
     if (cy_dbg.n) {

@@ -446,6 +446,15 @@ public:
         nccl_aborted = true;
     }
     bool nccl_aborted = false;
+    bool collective_enqueued = false;     // a collective of this solve may be pending on the stream (abort only then)
+    // state seam (proxsdp_hip_solve_ex): continue from / write out the iterate at an iteration boundary
+    const proxsdp_state* resume_state = nullptr;
+    proxsdp_state* capture_state = nullptr;
+    void check_state_shape(const proxsdp_state& s, const char* what) const;
+    void apply_resume();
+    void write_capture();
+    int ada_count = 0;                    // pdhg.jl:306-332 (a local of chambolle_pock)
+    double last_resid_s = 0.0;            // host part of compute_residual! / compute_gap! of the last fused linesearch call
     void wait_event(hipEvent_t ev) {
         if (opt.host_wait_spin == 0) { PX_HIP(hipEventSynchronize(ev)); return; }
         for (;;) {
@@ -463,6 +472,7 @@ public:
             Rccl& rc = Rccl::get();
             if (nccl_tmp.n < v.size()) nccl_tmp.alloc(v.size());
             nccl_tmp.upload(v.data(), v.size(), stream);
+            collective_enqueued = true;
             rc.check(rc.AllReduce(nccl_tmp.p, nccl_tmp.p, v.size(), ncclFloat64, ncclSum, nccl, stream), "ncclAllReduce");
             nccl_tmp.download(v.data(), v.size(), stream);
             wait_collective(stream);
@@ -2091,6 +2101,7 @@ inline void Solver::reduce_native(std::vector<double>& sums, std::vector<double>
     std::copy(sums.begin(), sums.end(), h);
     std::copy(maxs.begin(), maxs.end(), h + ns);
     PX_HIP(hipMemcpyAsync(nccl_send.p, h, n * sizeof(double), hipMemcpyHostToDevice, stream));
+    collective_enqueued = true;
     rc.check(rc.AllGather(nccl_send.p, nccl_recv.p, n, ncclFloat64, nccl, stream), "ncclAllGather");
     double* all = h + nccl_cap;
     PX_HIP(hipMemcpyAsync(all, nccl_recv.p, n * W * sizeof(double), hipMemcpyDeviceToHost, stream));

@@ -65,11 +65,12 @@ class Optimizer:
 
     # -- _optimize!
     def optimize(self, problem, eig_resid=None, trace_capacity=0, reduce=None, coupling=None, index_base=0,
-                 nccl_comm=None):
+                 nccl_comm=None, resume=None, capture_iteration=None):
         self.empty()
         self.problem = problem
         sol = binding.solve(problem, self.options, eig_resid=eig_resid, trace_capacity=trace_capacity,
-                            reduce=reduce, coupling=coupling, index_base=index_base, nccl_comm=nccl_comm)
+                            reduce=reduce, coupling=coupling, index_base=index_base, nccl_comm=nccl_comm,
+                            resume=resume, capture_iteration=capture_iteration)
         sign = -1.0 if problem.max_sense else 1.0          # :336-337
         sol.objval = sign * sol.objval + problem.objective_constant
         sol.dual_objval = sign * sol.dual_objval + problem.objective_constant

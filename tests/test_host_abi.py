@@ -27,7 +27,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert len(names) >= 14
     for name in names:
         assert hasattr(L, name), f"{name} declared in include/proxsdp_hip.h but not exported"
-    assert L.proxsdp_hip_abi_version() == 8
+    assert L.proxsdp_hip_abi_version() == 9
 
 
 def test_options_struct_layout_and_defaults_match_reference_options():
