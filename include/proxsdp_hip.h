@@ -44,7 +44,9 @@ extern "C" {
  * cert_matvecs (the last reserved slots):
  * same struct sizes and offsets; debug_fail_iteration now needs PROXSDP_HIP_FAULT_INJECTION=1
  * 9 (round 5): proxsdp_options grew at its END (equilibration_reference_aliasing, lanczos_device_restart, full_eig_block,
- * new reserved slots -- offsets of every earlier member unchanged, struct_size larger); new proxsdp_state and
+ * new reserved slots -- offsets of every earlier member unchanged, struct_size larger), proxsdp_stats grew at its end
+ * (proxsdp_result with it: it is the LAST member); a Krylov dimension beyond 255 is served by the dense eigensolver
+ * instead of PROXSDP_E_INVALID; new proxsdp_state and
  * proxsdp_hip_solve_ex (capture / resume of the solver state at an iteration boundary); PROXSDP_E_COMM_ABORTED */
 #define PROXSDP_HIP_ABI_VERSION 9
 
@@ -414,6 +416,15 @@ typedef struct proxsdp_stats {
     int64_t full_eigs_lanczos_cert_failed;/* ... whose certificate found a positive direction outside the returned pairs: the
                                            * dense engine projected that input instead */
     int64_t cert_matvecs;                 /* mat-vecs of those certificate runs (included in lanczos_matvecs) */
+    /* ---- ABI 9 (appended) ---- */
+    int64_t dense_truncated_projections;  /* Krylov-branch projections whose krylovdim = max(2 target_rank + 1, eigsolver_min_lanczos)
+                                           * exceeds the step kernels' 255 columns: served by the dense eigensolver (top target_rank
+                                           * pairs of dsyevd, the same truncated projection and min_eig); status_string says so */
+    int64_t device_restarts;              /* thick restarts done on the device (lanczos_device_restart), included in lanczos_restarts */
+    int64_t block_filter_projections;     /* Lanczos-served full_eig! calls answered by the warm-started block iteration (full_eig_block) */
+    int64_t block_filter_applies;         /* ... block operator applications they took (each counts its columns in lanczos_matvecs) */
+    int64_t block_filter_fallbacks;       /* ... attempts that did not pass their tests: the single-vector run served the call */
+    int64_t reserved_s[3];                /* zero */
 } proxsdp_stats;
 
 /* Result (structs.jl:60-81).  Arrays are caller-allocated with the stated

@@ -103,6 +103,9 @@ class Options:
     equilibration_ub: float = 10.0
     equilibration_limit: float = 0.9
     equilibration_force: bool = False
+    # no reference counterpart: True restates equilibrate!'s Diagonal(u) aliasing (equilibration.jl:16-17,25-26)
+    # exactly, False runs the iteration the code evidently intends; mirrored by the library
+    equilibration_reference_aliasing: bool = True
     approx_norm: bool = True
     # no reference counterpart (pdhg.jl:19-20 hard-codes 2): lets a benchmark start at the rank a
     # BASELINE config names ("rank ~ sqrt(n)", "target rank 50"); mirrored by the library

@@ -502,14 +502,14 @@ def dual_feas(y, cones, aff, c, A, G, a):
 def equilibrate(M, aff, opt):
     """equilibrate! (equilibration.jl:1-72): projected-gradient row/column scaling.  The reference
     replaces v by its mean in every iteration (:56-58), so D is a multiple of the identity: kept.
-    DELIBERATE DEVIATION: in the reference `E = Diagonal(u)`, `D = Diagonal(v)` (:16-17) wrap u and v
-    WITHOUT copying, so `E.diag .= exp.(u)` (:25-26) overwrites u with exp(u) (v with exp(v)) at the
-    top of every iteration and the gradient steps start from there.  Restated with that aliasing, the
-    scaling comes out badly conditioned (maxcut n=30: E ~ 0.023, D ~ 110) and the solver fails known
-    answers it passes without it (e.g. lp_in_SDP_equality_form, "feasibility stalled") -- the option is
-    off by default and never switched on by the reference's tests, so this cannot be checked against
-    Julia here.  Oracle and library implement the algorithm the code evidently intends (u, v kept,
-    E = exp(u), D = exp(v)); any positive diagonal scaling leaves the solution set unchanged.
+    In the reference `E = Diagonal(u)`, `D = Diagonal(v)` (:16-17) wrap u and v WITHOUT copying, so
+    `E.diag .= exp.(u)` (:25-26) overwrites u with exp(u) (v with exp(v)) at the top of every iteration and
+    gradient, step and running average continue from there.  opt.equilibration_reference_aliasing = True
+    (default) restates exactly that; False = the iteration the code evidently intends (u, v kept, E = exp(u),
+    D = exp(v)) -- what rounds 1-4 implemented.  With the aliasing the scaling comes out badly conditioned
+    (maxcut n=30: E ~ 0.023, D ~ 110) and some known answers the unscaled solver passes are missed
+    (tests/test_oracle_kat.py records which); the option is off by default and never switched on by the
+    reference's tests, so neither variant can be checked against Julia here ("parity unpinned").
     Returns the diagonals (E over rows, D over columns)."""
     M = sp.csc_matrix(M)
     nQ, n = aff.m + aff.p, aff.n
@@ -521,8 +521,11 @@ def equilibrate(M, aff, opt):
     u_, v_ = np.zeros(nQ), np.zeros(n)
     rows = M.indices
     cols = np.repeat(np.arange(n), np.diff(M.indptr))
+    alias = bool(getattr(opt, "equilibration_reference_aliasing", True))
     for it in range(1, opt.equilibration_iters + 1):
         Ed, Dd = np.exp(u), np.exp(v)
+        if alias:                                 # E.diag === u, D.diag === v (equilibration.jl:16-17,25-26)
+            u, v = Ed.copy(), Dd.copy()
         d2 = (M.data * Dd[cols] * Ed[rows]) ** 2
         step_size = 2.0 / (gamma * (it + 1.0))
         row_norms = np.bincount(rows, weights=d2, minlength=nQ)

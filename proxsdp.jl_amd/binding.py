@@ -139,7 +139,9 @@ class Stats(C.Structure):
                 ("batched_block_steps", i64), ("rccl_reductions", i64),
                 ("batched_profiled_blocks", i64), ("host_eig_merges", i64),
                 ("host_eig_overlap_time", f64), ("sign_short_pass", i64), ("sign_short_fail", i64),
-                ("full_eigs_lanczos_certified", i64), ("full_eigs_lanczos_cert_failed", i64), ("cert_matvecs", i64)]
+                ("full_eigs_lanczos_certified", i64), ("full_eigs_lanczos_cert_failed", i64), ("cert_matvecs", i64),
+                ("dense_truncated_projections", i64), ("device_restarts", i64), ("block_filter_projections", i64),
+                ("block_filter_applies", i64), ("block_filter_fallbacks", i64), ("reserved_s", i64 * 3)]
 
 
 class Result(C.Structure):

@@ -483,7 +483,11 @@ public:
         job_.store(&f, std::memory_order_relaxed);
         njobs_.store(n, std::memory_order_relaxed);
         done_.store(0, std::memory_order_relaxed);
-        const uint64_t g = ++gen_;
+        // the ticket carries 32 bits of the generation: keep the counter itself in that range (after 2^32
+        // run() calls `t >> 32` could never equal a 64-bit g again) and never hand out generation 0 (the helpers' "nothing seen")
+        gen_ = (gen_ + 1) & 0xffffffffull;
+        if (gen_ == 0) gen_ = 1;
+        const uint64_t g = gen_;
         ticket_.store(g << 32, std::memory_order_release);
         work(g);
         while (done_.load(std::memory_order_acquire) < n) {

@@ -162,6 +162,11 @@ inline void Solver::project_block(int idx, const double* xin, double* xout, bool
     }
     const bool used_fop = W.use_fop;
     const int nev = (int)target_rank[idx];
+    if (!lanczos_done && !krylovdim_fits(nev)) {          // Krylov dimension beyond the step kernels: dense eigensolver, same projection
+        W.use_fop = false;
+        truncated_project_dense(idx, xp, xo, fuse, nev);
+        return;
+    }
     if (!lanczos_done) {                      // (a batched run has already filled W.vals / W.Z)
         if (exact_projection_by_sign(idx, xp, xo, fuse, nev)) return;
         const double t_kry = opt.psd_sign_engine == 1 ? now_s() : 0.0;
@@ -365,7 +370,7 @@ inline bool Solver::full_eig_by_lanczos(int idx, const double* xp, double* xo, b
         if (cert_m >= 2) {
             double theta = 0.0, cscale = 0.0;
             if (lanczos_certificate(W, xp, npos, cert_m, theta, cscale)) {
-                const double posres = opt.full_eig_lanczos_posres > 0.0 ? opt.full_eig_lanczos_posres : 1e-6;
+                const double posres = lanczos_posres();
                 if (!(theta <= posres * cscale)) {
                     // a positive direction the run did not see: the dense engine projects this input (intact: the
                     // reconstruction has not run yet); three failures leave the block to the dense engine for good
@@ -792,7 +797,9 @@ inline void Solver::cache_solution(const std::vector<double>& cvec) {
         dfeas = maxs[0];
     }
     res.status = stop_reason;
-    std::snprintf(res.status_string, sizeof(res.status_string), "%s", stop_reason_string.c_str());
+    merge_block_stats();
+    std::snprintf(res.status_string, sizeof(res.status_string), "%s%s", stop_reason_string.c_str(),
+                  st.dense_truncated_projections > 0 ? " [Krylov dimension > 255: dense eigensolver served those projections]" : "");
     if (res.primal)    for (int64_t i = 0; i < P.n; ++i) res.primal[i] = x[P.inv[i]];
     if (res.dual_cone) for (int64_t i = 0; i < P.n; ++i) res.dual_cone[i] = dcone[P.inv[i]];
     if (res.dual_eq)   for (int64_t i = 0; i < P.p; ++i) res.dual_eq[i] = deq[i];

@@ -72,19 +72,23 @@ inline void check_csc(const proxsdp_csc& M, int64_t rows, int64_t cols, int base
 
 // equilibrate! (equilibration.jl:1-72) on the reordered, unscaled M (CSC).  The reference replaces
 // v by its mean in every iteration (:56-58), so D comes out as a multiple of the identity: kept.
-// DELIBERATE DEVIATION (same in oracle/pdhg.py:equilibrate, see there): the reference's
-// `E = Diagonal(u)` / `D = Diagonal(v)` (:16-17) alias u and v, so `E.diag .= exp.(u)` (:25-26)
-// overwrites u by exp(u) every iteration; restated that way the scaling is badly conditioned and
-// known answers fail.  Implemented here without the aliasing (u, v kept; E = exp(u), D = exp(v)).
+// The reference's `E = Diagonal(u)` / `D = Diagonal(v)` (:16-17) wrap u and v WITHOUT copying, so
+// `E.diag .= exp.(u)` / `D.diag .= exp.(v)` (:25-26) overwrite u by exp(u) and v by exp(v) at the top of
+// every iteration, and gradient, step and running average continue from those values.
+// options.equilibration_reference_aliasing = 1 (default) restates exactly that arithmetic; 0 = the
+// iteration the code evidently intends (u, v kept; E = exp(u), D = exp(v)) -- rounds 1-4 behaviour.
+// Same switch in oracle/pdhg.py:equilibrate.
 inline void equilibrate_host(const Prep& R, const proxsdp_options& opt, std::vector<double>& Ed, std::vector<double>& Dd) {
     const int64_t nQ = R.Q, n = R.n;
     const double alpha = std::pow((double)n / (double)nQ, 0.25), beta = std::pow((double)nQ / (double)n, 0.25);
     const double alpha2 = alpha * alpha, beta2 = beta * beta, gamma = 0.1;
     std::vector<double> u(nQ, 0.0), v(n, 0.0), u_(nQ, 0.0), v_(n, 0.0), rn(nQ), cn(n);
     Ed.assign(nQ, 1.0); Dd.assign(n, 1.0);
+    const bool alias = opt.equilibration_reference_aliasing != 0;
     for (int64_t it = 1; it <= opt.equilibration_iters; ++it) {
         for (int64_t r = 0; r < nQ; ++r) Ed[r] = std::exp(u[r]);
         for (int64_t k = 0; k < n; ++k) Dd[k] = std::exp(v[k]);
+        if (alias) { u = Ed; v = Dd; }                    // E.diag === u, D.diag === v (equilibration.jl:16-17,25-26)
         std::fill(rn.begin(), rn.end(), 0.0);
         for (int64_t k = 0; k < n; ++k) {
             double cs = 0.0;

@@ -577,6 +577,16 @@ private:
     void full_eig_project(int idx, const double* xp_in, double* xp_out, bool fuse);
     bool full_eig_by_lanczos(int idx, const double* xp_in, double* xp_out, bool fuse);
     bool full_eig_by_sign(int idx, const double* xp_in, double* xp_out, bool fuse, bool force = false);
+    void truncated_project_dense(int idx, const double* xp_in, double* xp_out, bool fuse, int nev);
+    // acceptance threshold of the Lanczos-served full_eig! (options.full_eig_lanczos_posres, default 1e-6 of the spectral
+    // scale), never looser than 1 % of the tightest tolerance the user asked for (a user at tolerance 1e-7
+    // must not be handed a projection that may miss a positive eigenvalue of 1e-6)
+    double lanczos_posres() const {
+        const double base = opt.full_eig_lanczos_posres > 0.0 ? opt.full_eig_lanczos_posres : 1e-6;
+        const double tmin = std::min({opt.tol_gap, opt.tol_feasibility, opt.tol_primal, opt.tol_dual});
+        return tmin > 0.0 ? std::min(base, 1e-2 * tmin) : base;
+    }
+    bool krylovdim_fits(int nev) const { return std::max(2 * nev + 1, (int)opt.eigsolver_min_lanczos) <= dev::MAXK - 1; }
     bool exact_projection_by_sign(int idx, const double* xp, double* xo, bool fuse, int nev);
     void verify_sign_engine(int idx, const double* xo);
     template <int EPI, bool FUSE>
@@ -630,10 +640,11 @@ inline void Solver::alloc_eigwork(EigWork& W, int n, int max_nev) {
     W.nt = ceil_div(n, dev::TILE);
     W.npad = W.nt * dev::TILE;
     W.nwg = ceil_div(n, dev::TPB);
-    int kd = std::max(2 * max_nev + 1, (int)opt.eigsolver_min_lanczos);
+    // the step kernels hold up to dev::MAXK - 1 = 255 basis columns; a projection whose Krylov dimension
+    // max(2 target_rank + 1, eigsolver_min_lanczos) is larger (options.jl:76,88 accept any value) is served by the dense
+    // eigensolver instead (Solver::truncated_project_dense): the workspace is sized for what the kernels can run
+    int kd = std::min(std::max(2 * max_nev + 1, (int)opt.eigsolver_min_lanczos), dev::MAXK - 1);
     W.cap = kd + 1;
-    if (W.cap > 256)
-        throw std::invalid_argument("krylov dimension exceeds the library limit (krylovdim <= 255, i.e. target rank <= 127)");
     W.V.alloc((size_t)W.npad * W.cap);
     W.Z.alloc((size_t)W.npad * W.cap);
     W.w.alloc(W.npad);
@@ -1125,7 +1136,7 @@ inline bool Solver::lz_after_cycle(EigWork& W, LzRun& R, bool speculated) {
         // once and says nothing about the pairs around it)
         int jn = j;
         while (jn < K && D[jn] >= -1e-12 * scale) ++jn;
-        const double posres = opt.full_eig_lanczos_posres > 0.0 ? opt.full_eig_lanczos_posres : 1e-6;
+        const double posres = lanczos_posres();
         if (converged >= j && (jn == K || std::fabs(f[jn]) <= std::max(tol, posres * scale))) { R.pos_count = j; return false; }
         if (K < krylovdim || R.numiter == R.maxiter) { R.pos_fail = true; return false; }
     } else {
@@ -1433,16 +1444,25 @@ inline bool Solver::lanczos_certificate(EigWork& W, const double* xp, int npos, 
     PX_HIP(hipMemcpyAsync(W.rec_host, W.rec.p, EigWork::REC_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, stream));
     wait_stream();
     std::swap(W.V.p, W.Z.p);
+    W.evo.used = 0; W.ev.used = 0;                                  // (profile events recorded by lz_launch_step: not a projection's)
     W.lst.lanczos_matvecs += msteps; W.mv_iter += msteps; W.lst.cert_matvecs += msteps;
+    // the deflated recurrence may end early (beta <= 0 exactly: what is left of the operator acts as a multiple of the
+    // identity on the complement -- the later launches are no-ops and their record entries are stale values of the main
+    // run): only the steps that ran form the tridiagonal
+    dev::LanczosCtl hctl{};
+    std::memcpy(&hctl, W.rec_host + 2 * dev::MAXK, sizeof(hctl));
+    if (hctl.stop) msteps = std::max(0, std::min(msteps, hctl.kstop - npos));
+    if (msteps < 1) return false;
     const double* al = W.rec_host + npos;
     const double* be = W.rec_host + dev::MAXK + npos;
     std::vector<double> T((size_t)msteps * msteps, 0.0), d(msteps, 0.0);
     for (int j = 0; j < msteps; ++j) {
-        if (!(al[j] == al[j]) || !(be[j] == be[j])) return false;
+        if (!(al[j] == al[j]) || !(j + 1 < msteps ? be[j] == be[j] : true)) return false;
         T[(size_t)j * msteps + j] = al[j];
         if (j + 1 < msteps) T[(size_t)j * msteps + j + 1] = T[(size_t)(j + 1) * msteps + j] = be[j];
     }
-    if (symeig_dense(msteps, T.data(), d.data(), true) != 0) return false;
+    if (msteps == 1) d[0] = al[0];
+    else if (symeig_dense(msteps, T.data(), d.data(), true) != 0) return false;
     theta_max = d[msteps - 1];
     scale = std::max({std::fabs(d[0]), std::fabs(theta_max), npos > 0 ? std::fabs(W.vals[0]) : 0.0});
     return true;
@@ -1806,11 +1826,6 @@ inline bool Solver::full_eig_by_sign(int idx, const double* xp_in, double* xp_ou
         // padded work matrices fit comfortably (side 16384: 10.7 GB; the cap was 4096 until round 4 -- maxG55 / maxG60,
         // sides 5000 / 7000, fell to rocSOLVER's dsyevd at ~0.2 % of the fp64 peak) and while HBM has room for them
         if (opt.full_eig_sign < 0 && (n < 33 || n > 16384)) return false;
-        if (opt.full_eig_sign < 0 && W.sg_ld != W.nt * dev::TILE) {
-            size_t free_b = 0, total_b = 0;
-            const size_t need = (size_t)6 * (size_t)(W.nt * dev::TILE) * (size_t)(W.nt * dev::TILE) * sizeof(double);
-            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need) return false;
-        }
         // auto: X+ carries an absolute error of up to ~1e-10 x the spectral scale on this path (l_0 of the
         // iteration): users who ask for tolerances near that floor get the LAPACK-accurate dense eigensolver
         if (opt.full_eig_sign < 0 && std::min({opt.tol_gap, opt.tol_feasibility, opt.tol_primal, opt.tol_dual}) < 1e-8) return false;
@@ -1818,8 +1833,22 @@ inline bool Solver::full_eig_by_sign(int idx, const double* xp_in, double* xp_ou
     const int ld = W.nt * dev::TILE;
     const int ntile = W.nt * (W.nt + 1) / 2, grid = 8 * ceil_div(ntile, 8);
     if (W.sg_ld != ld) {
+        // first use: the five work matrices must fit -- whoever asks (auto mode, full_eig_sign = 1, or the opt-in
+        // psd_sign_engine with force = true: ADVICE r4); no room, or an allocation that fails anyway (several block
+        // threads can pass the test together), DECLINES this engine instead of failing the solve
+        static std::mutex sign_alloc_mu;
+        std::lock_guard<std::mutex> lk(sign_alloc_mu);
+        size_t free_b = 0, total_b = 0;
+        const size_t need = (size_t)6 * (size_t)ld * (size_t)ld * sizeof(double);
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need) return false;
         const size_t sz = (size_t)ld * ld;
-        W.sgA.alloc(sz); W.sgX.alloc(sz); W.sgX2.alloc(sz); W.sgY.alloc(sz); W.sgQ.alloc(sz);
+        try {
+            W.sgA.alloc(sz); W.sgX.alloc(sz); W.sgX2.alloc(sz); W.sgY.alloc(sz); W.sgQ.alloc(sz);
+        } catch (const std::bad_alloc&) {
+            W.sgA.release(); W.sgX.release(); W.sgX2.release(); W.sgY.release(); W.sgQ.release();
+            (void)hipGetLastError();
+            return false;
+        }
         W.sgA.zero(stream);                                  // the padding stays zero: only entries < n are rewritten
         const int small_max = opt.sign_small_tile_max > 0 ? opt.sign_small_tile_max : 3072;   // measured: 32-tiles win up to n ~ 3500
         W.sg_small = ld <= small_max;
@@ -1979,6 +2008,27 @@ inline void Solver::full_eig_project(int idx, const double* xp_in, double* xp_ou
     if (prof) { PX_HIP(hipEventRecord(W.fe[2], stream)); W.fe_pending = true; }
     W.recon_r += npos;
 }
+// The Krylov branch (prox_operators.jl:68-109) for a Krylov dimension the step kernels cannot hold (> 255 columns:
+// target_rank > 127, or eigsolver_min_lanczos > 255): the same truncated projection from the dense eigensolver -- the
+// top `nev` eigenpairs of dsyevd are what a converged KrylovKit / ARPACK run returns, min_eig is the smallest of them
+// (:74,:95), the positive ones among them rebuild the block (:78-85,:99-106).
+inline void Solver::truncated_project_dense(int idx, const double* xp_in, double* xp_out, bool fuse, int nev) {
+    EigWork& W = eig[idx];
+    std::vector<double> D;
+    full_eig_values(W, xp_in, dev::INV_SQRT2, true, D);
+    const int n = W.n, k = std::min(nev, n);
+    int npos = 0;
+    for (int i = n - k; i < n; ++i) if (D[i] > 0.0) ++npos;       // ascending: the top k are the trailing k
+    min_eig[idx] = D[n - k];
+    current_rank[idx] += npos;
+    W.last_npos = npos;
+    W.converged = true; W.converged_eigs = k;
+    launch_reconstruct(W, W.A.p + (size_t)(n - npos) * n, n, W.D.p + (n - npos), npos, xp_out,
+                       fuse ? xp_in : nullptr, fuse ? idx : -1);
+    W.recon_r += npos;
+    W.have_factors = false; W.x_prev_sparse = false; W.use_fop = false;
+    W.lst.dense_truncated_projections++;
+}
 inline void Solver::harvest_full_eig_events(EigWork& W) {
     if (!W.fe_pending) return;
     W.fe_pending = false;
@@ -2070,6 +2120,8 @@ inline void Solver::merge_block_stats() {
         PX_MERGE(full_eig_solver_ms); PX_MERGE(full_eig_recon_ms);
         PX_MERGE(full_eigs_lanczos); PX_MERGE(full_eigs_lanczos_checks); PX_MERGE(full_eigs_lanczos_mismatches);
         PX_MERGE(full_eigs_lanczos_certified); PX_MERGE(full_eigs_lanczos_cert_failed); PX_MERGE(cert_matvecs);
+        PX_MERGE(dense_truncated_projections); PX_MERGE(device_restarts); PX_MERGE(block_filter_projections);
+        PX_MERGE(block_filter_applies); PX_MERGE(block_filter_fallbacks);
         PX_MERGE(full_eigs_sign); PX_MERGE(sign_products); PX_MERGE(sign_short_pass); PX_MERGE(sign_short_fail);
         PX_MERGE(sign_engine_projections); PX_MERGE(sign_engine_rejected);
         PX_MERGE(sign_engine_checks); PX_MERGE(sign_engine_mismatches);

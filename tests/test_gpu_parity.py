@@ -1126,8 +1126,9 @@ def test_operator_form_matvec_matches_packed_matvec(case):
         assert np.allclose(b.trace[:tight, [1, 2, 3, 4, 7, 11]], G[:tight], rtol=1e-7, atol=1e-10)
 
 
-@pytest.mark.parametrize("kw", [dict(equilibration_force=1), dict(approx_norm=0),
-                                dict(equilibration_force=1, approx_norm=0)])
+@pytest.mark.parametrize("kw", [dict(equilibration_force=1, equilibration_reference_aliasing=0), dict(approx_norm=0),
+                                dict(equilibration_force=1, approx_norm=0, equilibration_reference_aliasing=0),
+                                dict(equilibration_force=1), dict(equilibration_force=1, approx_norm=0)])
 @pytest.mark.parametrize("build", ["sdp_wiki_min", "lp_in_SDP_inequality_form", "maxcut30", "mimo6"])
 def test_equilibration_and_spectral_norm_against_oracle(build, kw):
     """equilibrate! (host, once) + un-scaling at the exit (pdhg.jl:64-92,751-755) and the
@@ -1142,8 +1143,8 @@ def test_equilibration_and_spectral_norm_against_oracle(build, kw):
     for k, v in kw.items():
         o.set(k, bool(v))
     ref = oracle.solve(pr, o, trace=True)
-    # (equilibration is implemented WITHOUT the reference's Diagonal(u) aliasing quirk on both sides --
-    # a documented deviation, oracle/pdhg.py:equilibrate)
+    # (equilibration_reference_aliasing: 1 = default = equilibrate!'s Diagonal(u) aliasing restated exactly on both
+    # sides, 0 = the intended iteration; oracle/pdhg.py:equilibrate, csrc/prep.hpp:equilibrate_host)
     assert sol.status == ref.status
     assert abs(sol.iter - ref.iter) <= max(2, 0.02 * ref.iter)
     m = min(len(ref.trace), len(sol.trace), 40)

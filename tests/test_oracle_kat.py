@@ -201,17 +201,42 @@ def test_unbounded_lp_certificate():
 
 # ----------------------------------------------------------------- off-by-default preprocessing variants
 @pytest.mark.parametrize("name", ["simple_lp", "sdp_wiki_min", "lp_in_SDP_equality_form", "double_sdp_from_moi"])
-@pytest.mark.parametrize("kw", [dict(equilibration_force=True), dict(approx_norm=False)])
+@pytest.mark.parametrize("kw", [dict(equilibration_force=True, equilibration_reference_aliasing=False), dict(approx_norm=False)])
 def test_known_answers_with_equilibration_and_spectral_norm(name, kw):
-    """equilibrate! (equilibration.jl, pdhg.jl:64-92,751-755) and the svds step size
-    (pdhg.jl:108-119).  The reference's tests never switch these on (parity unpinned beyond
-    this): the known answers must be invariant under them."""
+    """equilibrate! (equilibration.jl, pdhg.jl:64-92,751-755; here the iteration the code intends,
+    equilibration_reference_aliasing = False) and the svds step size (pdhg.jl:108-119).  The reference's tests
+    never switch these on (parity unpinned beyond this): the known answers must be invariant under them."""
     build, expected, atol, xexp = KATS[name]
     r = oracle.solve(build(), _opt(**kw))
     assert r.status == 1 and abs(r.objval - expected) <= atol
     assert r.primal_feasible_user_tol and r.dual_feasible_user_tol
     if xexp is not None:
         assert np.allclose(r.primal, xexp, atol=atol)
+
+
+@pytest.mark.parametrize("name,solved", [("simple_lp", True), ("sdp_wiki_min", True), ("lp_in_SDP_inequality_form", True),
+                                         ("lp_in_SDP_equality_form", False), ("double_sdp_from_moi", False)])
+def test_equilibration_with_the_reference_aliasing_recorded_behaviour(name, solved):
+    """equilibration_reference_aliasing = True (default): `E = Diagonal(u)` wraps u without a copy
+    (equilibration.jl:16-17), so `E.diag .= exp.(u)` (:25-26) overwrites u every iteration -- restated line by line.
+    The scaling it produces is badly conditioned (maxcut n = 30: E = 0.023, D = 110 against 1.87 / 1.05 without the
+    aliasing); three of the five small known answers are still reached (in 1.2x .. 15x the iterations), two end as
+    'feasibility stalled'.  RECORDED behaviour of the restatement -- the reference's own tests never force the option,
+    so Julia's outcome on these five is unknown here (parity unpinned)."""
+    build, expected, atol, xexp = KATS[name]
+    r = oracle.solve(build(), _opt(equilibration_force=True))
+    if solved:
+        assert r.status == 1 and abs(r.objval - expected) <= atol
+    else:
+        assert r.status == 6 and "feasibility stalled" in r.status_string
+    from oracle import pdhg as opdhg
+    aff, cones = oracle.to_standard_form(P.maxcut(30, seed=2))
+    Ed, Dd = opdhg.equilibrate(sp_vstack(aff), aff, Options())
+    assert abs(Ed[0] - 0.0230664) < 1e-6 and abs(Dd[0] - 110.2012) < 1e-3
+    o = Options()
+    o.equilibration_reference_aliasing = False
+    Ed, Dd = opdhg.equilibrate(sp_vstack(aff), aff, o)
+    assert abs(Ed[0] - 1.8675246) < 1e-6 and abs(Dd[0] - 1.0460596) < 1e-6
 
 
 def test_equilibration_switches_itself_off_and_scales_uniformly():

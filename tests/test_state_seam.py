@@ -127,7 +127,6 @@ def test_library_state_continued_by_the_oracle_and_back():
 @gpu
 def test_state_seam_argument_errors():
     pr = P.maxcut(40, seed=1)
-    st = oracle.solve(pr, oracle.Options(), capture_iteration=30).state if False else None
     o = oracle.Options()
     o.max_iter = 40
     st = oracle.solve(pr, o, capture_iteration=30).state
@@ -135,9 +134,113 @@ def test_state_seam_argument_errors():
     bad["hist"] = st["hist"][:, :100]
     with pytest.raises(ValueError):
         Optimizer(max_iter=50).optimize(pr, resume=bad)
-    with pytest.raises(B.ProxSDPHipError, match="hist_len"):
+    with pytest.raises(ValueError):                                       # the binding sizes hist from the options
         Optimizer(max_iter=50, convergence_window=100).optimize(pr, resume=st)
+    # straight through the C ABI: a state whose hist_len does not match the options is PROXSDP_E_INVALID
+    import ctypes as C
+    S, arr = B._state_struct(pr.n, pr.A.shape[0] + pr.G.shape[0], 1, 200, state=st)
+    S.hist_len = 100
+    M = B._Marshalled(pr)
+    R = B.Result()
+    opt = B.default_options()
+    rc = B.lib().proxsdp_hip_solve_ex(C.byref(M.P), C.byref(opt), C.byref(R), C.byref(S), None)
+    assert rc == -1 and b"hist_len" in B.lib().proxsdp_hip_last_error()
     sol = Optimizer(max_iter=20).optimize(pr, capture_iteration=30)       # never reached
     assert sol.state is None and sol.iter == 20
     sol = Optimizer(max_iter=30).optimize(pr, capture_iteration=30)       # the last iteration
     assert sol.state is not None and sol.state["iteration"] == 30
+
+
+# ----------------------------------------------------------------- the metric instance's late windows
+def _late():
+    return json.load(open(GOLDEN / "trace_maxcut_n4000_late.json"))["windows"]
+
+
+TRACE_KEYS = ((1, "prim_obj"), (2, "dual_obj"), (3, "gap"), (4, "feas"), (5, "prim_res"), (6, "dual_res"), (7, "primal_step"),
+              (8, "beta"), (9, "theta"))
+
+
+def _compare_window(rows, lt, tol, what):
+    """library trace rows (dict iteration -> row) against the oracle's golden rows: same target ranks and linesearch
+    trials, the same Lanczos mat-vec count wherever the reference runs KrylovKit (target rank <= 16), values to tol"""
+    worst = 0.0
+    for t in rows:
+        r = lt[t["iter"]]
+        assert int(r[10]) == t["target_rank"], (what, t["iter"], "target_rank", r[10], t["target_rank"])
+        assert int(r[11]) == t["trials"], (what, t["iter"], "linesearch trials", r[11], t["trials"])
+        if t["target_rank"] <= 16:
+            assert int(r[13]) == t["matvecs"], (what, t["iter"], "Lanczos mat-vecs", r[13], t["matvecs"])
+        for col, key in TRACE_KEYS:
+            d = abs(r[col] - t[key]) / max(1.0, abs(t[key]))
+            worst = max(worst, d)
+            assert d <= tol, (what, t["iter"], key, r[col], t[key])
+    return worst
+
+
+@gpu
+def test_metric_instance_into_the_full_eig_regime_against_lapack_in_the_loop():
+    """Max-Cut n = 4000, seed 0, reference default options.  The oracle was resumed (tests/golden/make_golden_late_n4000.py)
+    from the library's state 12 iterations before the 16 -> 17 rank update and run through it into the implicit
+    full_eig! regime with LAPACK dsyevr in the loop (prox_operators.jl:46-59,111-126; pdhg.jl:267-283) -- the regime
+    that is 65 % of the default solve's time and that the library serves with its OWN algorithm (positive-part
+    Lanczos / block iteration + per-call certificate).  The library, resumed from the same state, must follow: same
+    rank schedule, same linesearch trials, same mat-vec counts while KrylovKit is in charge, trace to 1e-8, and the
+    same current_rank at the end of the window; every Lanczos-served full_eig! certified."""
+    W = _late()["kU"]
+    rows = W["rows"]
+    st = expand_state(load_compact_state(GOLDEN / "state_maxcut_n4000_kU.npz"))
+    k0, k1 = int(st["iteration"]), rows[-1]["iter"]
+    assert W["resumed_from"] == k0 and rows[0]["iter"] == k0 + 1
+    ranks = [t["target_rank"] for t in rows]
+    assert ranks[0] == 16 and ranks[-1] >= 17 and W["full_eigs"] >= 30          # the window does cross into full_eig!
+    pr = P.maxcut(4000, seed=0)
+    sol = Optimizer(max_iter=k1).optimize(pr, trace_capacity=k1 - k0, resume=st, capture_iteration=k1)
+    assert sol.iter == k1
+    worst = _compare_window(rows, _lib_trace(sol), 1e-8, "resumed")
+    print("worst relative trace difference over %d iterations: %.2e" % (len(rows), worst))
+    assert int(sol.state["current_rank"][0]) == rows[-1]["current_rank"]
+    assert int(sol.state["target_rank"][0]) == rows[-1]["target_rank"]
+    s = sol.stats
+    n_full = sum(1 for t in rows if t["target_rank"] > 16)
+    assert s["full_eigs"] == n_full == W["full_eigs"]
+    served = s["full_eigs_lanczos"]
+    assert served >= n_full - 2, "the library's own engine did not serve the regime"      # (first call: dense engine, by design)
+    assert s["full_eigs_lanczos_certified"] + s["block_filter_projections"] >= served and s["full_eigs_lanczos_cert_failed"] == 0
+
+
+@gpu
+def test_metric_instance_steady_window_1000_against_the_oracle():
+    """the steady Krylov-phase window of SURVEY section 8d (iterations 1001-1060 from the saved state at 1000):
+    identical mat-vec counts in every iteration, trace to 1e-9"""
+    W = _late()["k1000"]
+    rows = W["rows"]
+    st = expand_state(load_compact_state(GOLDEN / "state_maxcut_n4000_k1000.npz"))
+    k0, k1 = int(st["iteration"]), rows[-1]["iter"]
+    pr = P.maxcut(4000, seed=0)
+    sol = Optimizer(max_iter=k1).optimize(pr, trace_capacity=k1 - k0, resume=st)
+    worst = _compare_window(rows, _lib_trace(sol), 1e-9, "resumed")
+    print("worst relative trace difference over %d iterations: %.2e" % (len(rows), worst))
+
+
+@gpu
+def test_metric_instance_from_iteration_one_reaches_the_saved_states_and_follows_the_oracle_windows():
+    """the same two windows WITHOUT the seam on the library's side: one uninterrupted default-options solve from
+    iteration 1 passes through the committed states (x, y to 1e-9: the states were written by the round-5 build; a
+    later build whose reduction orders differ stays within that) and its trace follows the oracle's windows."""
+    L = _late()
+    pr = P.maxcut(4000, seed=0)
+    kU = L["kU"]["resumed_from"]
+    k_end = L["kU"]["rows"][-1]["iter"]
+    sol = Optimizer(max_iter=k_end).optimize(pr, trace_capacity=k_end, capture_iteration=kU)
+    lt = _lib_trace(sol)
+    st = expand_state(load_compact_state(GOLDEN / "state_maxcut_n4000_kU.npz"))
+    got = sol.state
+    assert got["iteration"] == kU and int(got["target_rank"][0]) == int(st["target_rank"][0]) == 16
+    sx = np.abs(st["x"]).max()
+    assert np.abs(got["x"] - st["x"]).max() <= 1e-9 * sx
+    assert np.abs(got["y"] - st["y"]).max() <= 1e-9 * max(1.0, np.abs(st["y"]).max())
+    for k in ("rank_update", "update_cont", "ada_count"):
+        assert got[k] == st[k], k
+    for tag, tol in (("k1000", 1e-8), ("kU", 1e-7)):
+        worst = _compare_window(L[tag]["rows"], lt, tol, tag + " from iteration 1")
+        print(tag, "worst relative trace difference: %.2e" % worst)
