@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--block-batch", dest="block_batch", type=int, default=None,
                     help="library-only: equal-side PSD blocks in one launch per Lanczos step (-1 auto, 0 off = stream per block)")
     ap.add_argument("--block-threads", dest="block_threads", type=int, default=None)
+    ap.add_argument("--block-batch-groups", dest="block_batch_groups", type=int, default=None,
+                    help="library-only: concurrent groups of the batched multi-block Lanczos (-1 auto = 2, 1 = one group)")
     ap.add_argument("--host-eig-merge", dest="host_eig_merge", type=int, default=None,
                     help="library-only: K x K Rayleigh-quotient eigensolves by split + rank-one merge (-1 auto, 0 = implicit QL)")
     ap.add_argument("--rand-n", type=int, default=2000)
@@ -537,7 +539,7 @@ def extra_opts(args):
     """library-only knobs passed through to every GPU leg (empty = the KrylovKit-faithful parity path)"""
     kw = {}
     for name in ("lanczos_warm_start", "lanczos_cycle_kernel", "full_eig_lanczos", "reconstruct_mfma", "full_eig_sign",
-                 "psd_sign_engine", "block_batch", "block_threads", "host_eig_merge"):
+                 "psd_sign_engine", "block_batch", "block_threads", "host_eig_merge", "block_batch_groups"):
         v = getattr(args, name, None)
         if v is not None:
             kw[name] = v

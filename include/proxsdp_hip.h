@@ -350,7 +350,15 @@ typedef struct proxsdp_options {
                                   * Chebyshev filter in ONE launch per operator application (block operator form) and
                                   * Rayleigh-Ritz'ed; accepted under the same per-call certificate, single-vector run as the
                                   * fall-back.  -1 auto, 0 off, 1 on */
-    int32_t reserved_i2[9];      /* zero */
+    int32_t block_batch_groups;  /* batched multi-block Lanczos (block_batch): equal-side blocks are split into this many groups that
+                                  * run CONCURRENTLY (own stream + host thread each): one group's restart logic on the host overlaps
+                                  * the other groups' cycles on the GPU.  -1 auto = 1 = one group (rounds 3-4 behaviour), k >= 2 = k
+                                  * groups (from 4 blocks on, when the block worker pool is up: block_threads != 0).  Per block
+                                  * nothing changes.  MEASURED NEGATIVE on MIMO 8 x 513 (same session: 313 / 303 / 217 it/s with
+                                  * 1 / 2 / 4 groups): a cycle is bound by its chain of dependent launches on the GPU (135 us of
+                                  * the 200), kernels of different streams do not overlap enough to pay for twice the launches --
+                                  * kept as an opt-in for models with many more blocks */
+    int32_t reserved_i2[8];      /* zero */
     double  reserved_d2[4];      /* zero */
 } proxsdp_options;
 

@@ -103,21 +103,54 @@ inline void Solver::project_blocks(const std::vector<int>& blocks, const double*
         size_t i0 = 0;
         while (i0 < cand.size()) {
             size_t i1 = i0;
-            while (i1 < cand.size() && eig[cand[i1]].n == eig[cand[i0]].n && i1 - i0 < (size_t)dev::LZB_MAX) ++i1;
-            if (i1 - i0 >= 2) groups.emplace_back(cand.begin() + i0, cand.begin() + i1);
-            else rest.push_back(cand[i0]);
+            while (i1 < cand.size() && eig[cand[i1]].n == eig[cand[i0]].n) ++i1;
+            // equal-side run [i0, i1): groups of up to LZB_MAX blocks; with the worker pool up, at least two groups of >= 2
+            // blocks on request (options.block_batch_groups) so that they can overlap
+            const size_t cnt = i1 - i0;
+            if (cnt < 2) { rest.push_back(cand[i0]); i0 = i1; continue; }
+            size_t ng = (cnt + dev::LZB_MAX - 1) / dev::LZB_MAX;
+            const int want = opt.block_batch_groups < 0 ? 1 : (int)opt.block_batch_groups;   // (auto = 1: measured, see the header)
+            if (parallel_blocks && want >= 2 && cnt >= 4) ng = std::max<size_t>(ng, std::min<size_t>((size_t)want, cnt / 2));
+            for (size_t q = 0; q < ng; ++q) {
+                const size_t a = i0 + q * cnt / ng, b = i0 + (q + 1) * cnt / ng;
+                groups.emplace_back(cand.begin() + a, cand.begin() + b);
+            }
             i0 = i1;
         }
         std::sort(rest.begin(), rest.end());
     } else {
         rest = blocks;
     }
-    for (const std::vector<int>& g : groups) {
-        std::vector<int> nevs;
-        for (int idx : g) { current_rank[idx] = 0; nevs.push_back((int)target_rank[idx]); }
-        lanczos_batch(g, xin, nevs);
-        for (int idx : g) project_block(idx, xin, xout, fuse, true);
+    // groups run CONCURRENTLY when the block worker pool is up (one worker thread + the leader block's stream per group):
+    // while one group's restart logic runs on the host the other group's cycle runs on the GPU (the step launches are
+    // latency-bound: two groups side by side advance about as fast as one).  Per block nothing changes.
+    if (batch_ctx.size() < groups.size()) {
+        const size_t have = batch_ctx.size();
+        batch_ctx.resize(groups.size());
+        for (size_t q = have; q < groups.size(); ++q) batch_ctx[q].reset(new BatchCtx());
     }
+    for (const std::vector<int>& g : groups) for (int idx : g) current_rank[idx] = 0;
+    bool leaders_have_streams = parallel_blocks && groups.size() >= 2;
+    for (const std::vector<int>& g : groups) leaders_have_streams = leaders_have_streams && eig[g[0]].stream != nullptr;
+    if (leaders_have_streams) {
+        std::vector<int> leaders;
+        std::vector<int> slot_of(eig.size(), -1);
+        for (size_t q = 0; q < groups.size(); ++q) { leaders.push_back(groups[q][0]); slot_of[groups[q][0]] = (int)q; }
+        run_blocks(leaders, [this, xin, &groups, &slot_of](int leader) {
+            const std::vector<int>& g = groups[slot_of[leader]];
+            std::vector<int> nevs;
+            for (int idx : g) nevs.push_back((int)target_rank[idx]);
+            lanczos_batch(g, xin, nevs, slot_of[leader]);
+        });
+    } else {
+        for (size_t q = 0; q < groups.size(); ++q) {
+            std::vector<int> nevs;
+            for (int idx : groups[q]) nevs.push_back((int)target_rank[idx]);
+            lanczos_batch(groups[q], xin, nevs, (int)q);
+        }
+    }
+    for (const std::vector<int>& g : groups)
+        for (int idx : g) project_block(idx, xin, xout, fuse, true);
     if (!groups.empty()) merge_block_stats();
     if (!rest.empty()) run_blocks(rest, [this, xin, xout, fuse](int idx) { project_block(idx, xin, xout, fuse); });
 }
@@ -702,7 +735,7 @@ inline double Solver::dual_feas_host(const std::vector<double>& y, const std::ve
             DevBuf<double> tmp(B.N);
             double mn = 0.0;
             bool have_mn = false;
-            if (B.n > opt.min_size_krylov_eigs && opt.eigsolver != 1 && W.cap >= 26) {
+            if (B.n > opt.min_size_krylov_eigs && opt.eigsolver != 1 && W.cap >= 26 && krylovdim_fits(1)) {
                 std::vector<double> neg(dc.begin() + B.off, dc.begin() + B.off + B.N);
                 for (double& v : neg) v = -v;
                 tmp.upload(neg.data(), B.N, stream);

@@ -308,7 +308,6 @@ public:
             if (W.side) (void)hipStreamDestroy(W.side);
         }
         if (ev_main) (void)hipEventDestroy(ev_main);
-        if (lzb_ev) (void)hipEventDestroy(lzb_ev);
         for (auto& pr : dense_ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
         if (blas) (void)rocblas_destroy_handle(blas);
         if (stream.main) (void)hipStreamDestroy(stream.main);
@@ -321,24 +320,32 @@ public:
     void lanczos(EigWork& W, const double* xp, int nev, bool positive_part = false);
     void lz_launch_step(EigWork& W, const double* xp, int k, int kfirst, double step_tol, bool& presymv);
     bool lanczos_certificate(EigWork& W, const double* xp, int npos, int msteps, double& theta_max, double& scale);
-    void lanczos_batch(const std::vector<int>& blocks, const double* xbase, const std::vector<int>& nevs);
+    void lanczos_batch(const std::vector<int>& blocks, const double* xbase, const std::vector<int>& nevs, int ctx_slot = 0);
     // batched rotations: U of every block staged in ONE pinned buffer, one upload, one launch (grid.z = block)
     double dbg_batch[5] = {0, 0, 0, 0, 0};         // debug: enqueue | wait | restart logic | flush seconds, cycles
     double dbg_lz[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // debug (PROXSDP_HIP_DEBUG): single-block run -- wait for the cycle | second() +
                                                    // merge | last row + convergence | Ritz coefficients | staging + upload + launch | cycles
-    RotSink* rot_sink = nullptr;
-    std::unique_ptr<SpinPool> restart_pool;        // helper threads for the per-block restart logic of a batched run
-    hipEvent_t lzb_ev = nullptr;                   // end of a batched cycle's record copies (the speculated mat-vecs run behind it)
+    // (thread-local: several batched runs may be in progress at once, one per group of blocks, each on its own worker thread)
+    static inline thread_local RotSink* rot_sink = nullptr;
+    // per-GROUP state of a batched run (round 5: equal-side blocks are split into groups that run CONCURRENTLY, each on its own
+    // stream and host thread -- one group's restart logic on the host overlaps the other group's cycle on the GPU)
+    struct BatchCtx {
+        DevBuf<double> U;
+        PinnedBuf U_host, rec_host;
+        hipEvent_t ev = nullptr;                   // end of a batched cycle's record copies (the speculated mat-vecs run behind it)
+        std::unique_ptr<SpinPool> pool;            // helper threads for the per-block restart logic
+        ~BatchCtx() { if (ev) (void)hipEventDestroy(ev); }
+    };
+    std::vector<std::unique_ptr<BatchCtx>> batch_ctx;
+    std::mutex batch_stats_mu;
     // helper threads for the rank-one merge of the K x K eigensolve (secular roots, Gu-Eisenstat weights, eigenvector columns:
     // independent per root / column, so the results do not depend on who computes them).  They spin only while a projection
     // with krylovdim >= 64 is in progress (armed at its start, disarmed at its end).
     std::unique_ptr<SpinPool> merge_pool;
     ParFor merge_par;
     int merge_helpers() const { return opt.host_merge_threads < 0 ? 3 : std::min(15, (int)opt.host_merge_threads); }
-    DevBuf<double> lzb_U;
-    PinnedBuf lzb_U_host, lzb_rec_host;
     static constexpr size_t LZB_USTRIDE = 64 * 64 + 2 * dev::MAXK;
-    void flush_rotations(RotSink& sink);
+    void flush_rotations(RotSink& sink, BatchCtx& C);
     bool lz_init(EigWork& W, struct LzRun& R, int nev, bool positive_part);
     void lz_prepare_arrow(struct LzRun& R);
     bool lz_after_cycle(EigWork& W, struct LzRun& R, bool speculated);
@@ -1602,7 +1609,7 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive
     if (debug) dbg_lz[3] += now_s() - tdbg2;
 }
 
-inline void Solver::flush_rotations(RotSink& S) {
+inline void Solver::flush_rotations(RotSink& S, BatchCtx& C) {
     dev::LzRotBatch B{};
     size_t used = 0, lds = 0;
     int nt = 0;
@@ -1611,16 +1618,16 @@ inline void Solver::flush_rotations(RotSink& S) {
         r.valid = false;
         const size_t len = r.data.size();
         if (used + len > (size_t)dev::LZB_MAX * LZB_USTRIDE) throw std::logic_error("flush_rotations: staging buffer too small");
-        std::memcpy(lzb_U_host.p + used, r.data.data(), len * sizeof(double));
-        B.r[B.nb++] = dev::LzRot{r.V, lzb_U.p + used, r.out, r.K, r.ncols, r.copy_src, r.copy_dst};
-        if (r.nextra > 0) r.W->arrow_p = lzb_U.p + used + (size_t)r.K * std::max(r.ncols, 0);
+        std::memcpy(C.U_host.p + used, r.data.data(), len * sizeof(double));
+        B.r[B.nb++] = dev::LzRot{r.V, C.U.p + used, r.out, r.K, r.ncols, r.copy_src, r.copy_dst};
+        if (r.nextra > 0) r.W->arrow_p = C.U.p + used + (size_t)r.K * std::max(r.ncols, 0);
         lds = std::max(lds, ((size_t)r.K * std::max(r.ncols, 0) + (size_t)r.K * (dev::LZ_ROWS + 1)) * sizeof(double));
         B.npad = r.W->npad; nt = r.W->nt;
         used += (len + 7) & ~(size_t)7;
     }
     if (B.nb == 0) return;
     if ((int)lds > rotate_lds_cap) throw std::logic_error("flush_rotations: LDS budget exceeded");
-    PX_HIP(hipMemcpyAsync(lzb_U.p, lzb_U_host.p, used * sizeof(double), hipMemcpyHostToDevice, stream));
+    PX_HIP(hipMemcpyAsync(C.U.p, C.U_host.p, used * sizeof(double), hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(dev::k_lzb_rotate, dim3(nt, 1, B.nb), dim3(dev::TPB), lds, stream, B);
 }
 
@@ -1629,8 +1636,12 @@ inline void Solver::flush_rotations(RotSink& S) {
 // (lz_after_cycle) between the cycles.  Per block the arithmetic, the mat-vec count and the restart count are
 // those of lanczos(); blocks that have converged drop out of the launches.  Preconditions (checked by
 // batch_eligible): plain KrylovKit mode, packed-triangle operator, krylovdim <= 63.
-inline void Solver::lanczos_batch(const std::vector<int>& blocks, const double* xbase, const std::vector<int>& nevs) {
+inline void Solver::lanczos_batch(const std::vector<int>& blocks, const double* xbase, const std::vector<int>& nevs, int ctx_slot) {
     const int nb = (int)blocks.size();
+    if (ctx_slot < 0 || ctx_slot >= (int)batch_ctx.size() || !batch_ctx[ctx_slot]) throw std::logic_error("lanczos_batch: no context for this group");
+    BatchCtx& C = *batch_ctx[ctx_slot];
+    const bool concurrent = StreamRef::tl != nullptr;        // running on a group worker thread: shared counters go through a lock
+    long long steps_local = 0;
     if (nb < 1 || nb > dev::LZB_MAX) throw std::invalid_argument("lanczos_batch: 1..LZB_MAX blocks");
     auto Rq = [&](int q) -> LzRun& { return eig[blocks[q]].lzrun; };     // host state of block q's run (lives in its workspace)
     std::vector<char> live(nb, 0), ran(nb, 0);
@@ -1655,17 +1666,17 @@ inline void Solver::lanczos_batch(const std::vector<int>& blocks, const double* 
         return b;
     };
     const int ntile = 8 * ceil_div(W0.nt * (W0.nt + 1) / 2, 8);
-    if (lzb_U.n == 0) {
-        lzb_U.alloc(dev::LZB_MAX * LZB_USTRIDE); lzb_U_host.alloc(dev::LZB_MAX * LZB_USTRIDE);
-        lzb_rec_host.alloc(dev::LZB_MAX * EigWork::REC_DOUBLES);
+    if (C.U.n == 0) {
+        C.U.alloc(dev::LZB_MAX * LZB_USTRIDE); C.U_host.alloc(dev::LZB_MAX * LZB_USTRIDE);
+        C.rec_host.alloc(dev::LZB_MAX * EigWork::REC_DOUBLES);
     }
     RotSink sink;
     // helper threads for the restart logic (options.block_threads: -1 auto = one per block up to 8, 0 = none): they spin
     // only while this projection is in progress
     const int nhelp = std::min(nb, opt.block_threads < 0 ? 8 : (int)opt.block_threads) - 1;
-    if (nhelp >= 1 && (!restart_pool || restart_pool->helpers() < nhelp)) restart_pool.reset(new SpinPool(nhelp));
-    SpinPool* pool = (nhelp >= 1) ? restart_pool.get() : nullptr;
-    struct SinkGuard { Solver& s; SpinPool* p; ~SinkGuard() { s.rot_sink = nullptr; if (p) p->disarm(); } } guard{*this, pool};
+    if (nhelp >= 1 && (!C.pool || C.pool->helpers() < nhelp)) C.pool.reset(new SpinPool(nhelp));
+    SpinPool* pool = (nhelp >= 1) ? C.pool.get() : nullptr;
+    struct SinkGuard { SpinPool* p; ~SinkGuard() { Solver::rot_sink = nullptr; if (p) p->disarm(); } } guard{pool};
     rot_sink = &sink;
     if (pool) pool->arm();
     for (int q = 0; q < nb; ++q) fill(q).mode = live[q] ? 1 : 0;
@@ -1673,10 +1684,10 @@ inline void Solver::lanczos_batch(const std::vector<int>& blocks, const double* 
     const double mv_bytes = 8.0 * (double)W0.N + 16.0 * (double)W0.n;
     long long nlaunch = 0, prof_blocks = 0;
     double tp0 = debug ? now_s() : 0.0;                  // PROXSDP_HIP_DEBUG: host-time split of the batched run
-    auto lap = [&](double& acc) { if (debug) { const double t = now_s(); acc += t - tp0; tp0 = t; } };
+    auto lap = [&](double& acc) { if (debug && !concurrent) { const double t = now_s(); acc += t - tp0; tp0 = t; } };
     std::vector<char> presymv(nb, 0);                // the first mat-vec of the block's next cycle is already in Ppart (speculated)
-    if (lzb_ev == nullptr) PX_HIP(hipEventCreateWithFlags(&lzb_ev, hipEventDisableTiming));
-    double* const rec_out = lzb_rec_host.p;
+    if (C.ev == nullptr) PX_HIP(hipEventCreateWithFlags(&C.ev, hipEventDisableTiming));
+    double* const rec_out = C.rec_host.p;
     const int rec_n = (int)EigWork::REC_DOUBLES;
     while (true) {
         int tmax = 0, nlive = 0;
@@ -1721,11 +1732,11 @@ inline void Solver::lanczos_batch(const std::vector<int>& blocks, const double* 
                 b.mode = act ? 1 : 0;                                     // (k_lzb_orth: != 0 = active)
             }
             hipLaunchKernelGGL(dev::k_lzb_orth, dim3(W0.nt, 1, nb), dim3(dev::TPB), 0, stream, B);
-            st.batched_block_steps += nlive;
+            steps_local += nlive;
         }
         // every live block's record [alphas | betas | ctl] has been copied out by the closing workgroup 0 of its mode-3 launch
         // (straight into pinned host memory): the host waits for THAT point of the stream ...
-        PX_HIP(hipEventRecord(lzb_ev, stream));
+        PX_HIP(hipEventRecord(C.ev, stream));
         // ... while the GPU already runs the first mat-vec of every block's NEXT cycle (on v_K = V[:, krylovdim], final since
         // the mode-3 closing; the restart rotation copies it to column `keep`, so the tiles' result stays valid) -- wasted
         // only for the blocks that turn out to have converged
@@ -1738,10 +1749,10 @@ inline void Solver::lanczos_batch(const std::vector<int>& blocks, const double* 
         for (int q = 0; q < nb; ++q) presymv[q] = live[q];
         for (int q = 0; q < nb; ++q) if (live[q]) lz_prepare_arrow(Rq(q));
         lap(dbg_batch[0]);                               // enqueue (+ arrow reductions)
-        wait_event(lzb_ev);
+        wait_event(C.ev);
         lap(dbg_batch[1]);                               // waiting for the GPU
         for (int q = 0; q < nb; ++q)
-            if (live[q]) std::memcpy(eig[blocks[q]].rec_host, lzb_rec_host.p + (size_t)q * EigWork::REC_DOUBLES, EigWork::REC_DOUBLES * sizeof(double));
+            if (live[q]) std::memcpy(eig[blocks[q]].rec_host, C.rec_host.p + (size_t)q * EigWork::REC_DOUBLES, EigWork::REC_DOUBLES * sizeof(double));
         for (size_t sl = 0; sl < W0.ev.used; ++sl) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, W0.ev.e0[sl], W0.ev.e1[sl]) == hipSuccess) {
@@ -1753,20 +1764,27 @@ inline void Solver::lanczos_batch(const std::vector<int>& blocks, const double* 
         std::exception_ptr err[dev::LZB_MAX] = {};
         auto job = [&](int q) {
             if (!live[q]) return;
+            RotSink* const prev = Solver::rot_sink;          // (thread-local: a helper thread stages into THIS run's sink)
+            Solver::rot_sink = &sink;
             try { live[q] = lz_after_cycle(eig[blocks[q]], Rq(q), false) ? 1 : 0; }
             catch (...) { err[q] = std::current_exception(); live[q] = 0; }
+            Solver::rot_sink = prev;
         };
         if (pool) pool->run(nb, job);
         else for (int q = 0; q < nb; ++q) job(q);
         for (int q = 0; q < nb; ++q) if (err[q]) std::rethrow_exception(err[q]);
         lap(dbg_batch[2]);                               // restart logic
-        flush_rotations(sink);                       // the restart rotations of this cycle: one upload, one launch
+        flush_rotations(sink, C);                    // the restart rotations of this cycle: one upload, one launch
         lap(dbg_batch[3]);
-        dbg_batch[4] += 1.0;
+        if (!concurrent) dbg_batch[4] += 1.0;
     }
     for (int q = 0; q < nb; ++q) if (ran[q]) lz_finish_run(eig[blocks[q]], Rq(q));
-    flush_rotations(sink);                           // the Ritz vectors of every block
-    st.batched_profiled_blocks += prof_blocks;       // blocks served by the event-bracketed launches (bytes = this x (8N + 16n))
+    flush_rotations(sink, C);                        // the Ritz vectors of every block
+    {
+        std::lock_guard<std::mutex> lk(batch_stats_mu);
+        st.batched_block_steps += steps_local;
+        st.batched_profiled_blocks += prof_blocks;   // blocks served by the event-bracketed launches (bytes = this x (8N + 16n))
+    }
 }
 
 // eigen!(Symmetric(smat(xp))) through rocSOLVER dsyevd (ascending), the dense

@@ -810,7 +810,7 @@ def test_config4_mimo_8x512_solved_to_tolerance_against_the_oracle_solve(golden_
     close = np.all(np.isclose(T[:m, 1:8], G[:m, 1:8], rtol=1e-6, atol=1e-9), axis=1) & (T[:m, 11] == G[:m, 11])
     first_off = int(np.argmin(close)) if not close.all() else m
     print("traces agree (1e-6, trial counts) for the first", first_off, "of", m, "iterations")
-    assert first_off >= 20
+    assert first_off >= 25                               # measured: 27 (rounds 4 and 5)
     assert abs(sol.stats["lanczos_matvecs"] - gold["matvecs"]) <= 0.05 * gold["matvecs"]
 
 

@@ -31,9 +31,10 @@ __global__ void __launch_bounds__(256) k_flag(double* buf, int iters, double* ou
     double acc = 0.0;
     for (int it = 0; it < iters; ++it) {
         const int slot = it & 1;
-        if (MODE == 3) { if (t < REC) buf[((size_t)slot * G + g) * REC + t] = acc * 1e-30 + g + it; }
+        if (MODE == 3 || MODE == 4) { if (t < REC) buf[((size_t)slot * G + g) * REC + t] = acc * 1e-30 + g + it; }
         else put_rec(buf, slot, g, G, t, acc * 1e-30 + g + it);
         if (MODE == 3) __threadfence();
+        if (MODE == 4) __atomic_thread_fence(__ATOMIC_RELEASE);      // (every storing wave: L2 write-back of its lines)
         __syncthreads();
         if (t == 0) {
             const unsigned target = (unsigned)(it + 1) * G;
@@ -54,7 +55,13 @@ __global__ void __launch_bounds__(256) k_flag(double* buf, int iters, double* ou
             }
         }
         __syncthreads();
-        if (MODE == 3) {
+        if (MODE == 4) {
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);                 // buffer_inv: the plain loads below miss to memory once
+            const double* bp = buf + (size_t)slot * G * REC;
+            double a = 0.0;
+            for (int q = t; q < G * REC; q += 256) a += bp[q];
+            acc += a;
+        } else if (MODE == 3) {
             __threadfence();
             double a = 0.0;
             for (int q = t; q < G * REC; q += 256) a += __builtin_nontemporal_load(&buf[(size_t)slot * G * REC + q]);
@@ -77,18 +84,20 @@ __global__ void __launch_bounds__(256) k_read(const double* buf, int slot, doubl
 }
 
 int main() {
-    const char* names[4] = {"poll (one counter)", "poll + s_sleep", "last arriver broadcasts per-WG go words", "plain stores + __threadfence, one counter"};
+    const char* names[5] = {"poll (one counter)", "poll + s_sleep", "last arriver broadcasts per-WG go words", "plain stores + __threadfence, nontemporal loads",
+                            "plain stores + release | acquire + plain loads"};
     for (int G : {63, 126}) {
+        for (int pass = 0; pass < 1; ++pass) {}
         const int iters = 4000;
         double *buf, *out; unsigned *ctr, *go;
         hipMalloc(&buf, sizeof(double) * 2 * G * REC); hipMalloc(&out, sizeof(double) * G * 256); hipMalloc(&ctr, 4); hipMalloc(&go, 4 * 32 * G);
         hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-        for (int mode = 0; mode < 4; ++mode) {
+        for (int mode = 0; mode < 5; ++mode) {
             for (int rep = 0; rep < 2; ++rep) {
                 hipMemset(ctr, 0, 4); hipMemset(go, 0, 4 * 32 * G); hipMemset(buf, 0, sizeof(double) * 2 * G * REC);
                 int it = iters;
                 void* args[] = {&buf, &it, &out, &ctr, &go};
-                void* fn = mode == 0 ? (void*)k_flag<0> : mode == 1 ? (void*)k_flag<1> : mode == 2 ? (void*)k_flag<2> : (void*)k_flag<3>;
+                void* fn = mode == 0 ? (void*)k_flag<0> : mode == 1 ? (void*)k_flag<1> : mode == 2 ? (void*)k_flag<2> : mode == 3 ? (void*)k_flag<3> : (void*)k_flag<4>;
                 hipEventRecord(a);
                 hipError_t e = hipLaunchCooperativeKernel(fn, dim3(G), dim3(256), args, 0, 0);     // (cooperative only for co-residency)
                 hipEventRecord(b); hipEventSynchronize(b);
