@@ -324,8 +324,6 @@ def main():
                     "full_eigs_lanczos_checks": int(s["full_eigs_lanczos_checks"]),
                     "full_eigs_lanczos_mismatches": int(s["full_eigs_lanczos_mismatches"]),
                     "full_eigs_lanczos_certified": int(s["full_eigs_lanczos_certified"]),
-                    "block_filter_projections": int(s["block_filter_projections"]),
-                    "block_filter_fallbacks": int(s["block_filter_fallbacks"]),
                     "section_seconds": {"primal": s["t_primal"], "psd_projection": s["t_psd"], "linesearch": s["t_linesearch"],
                                         "residual_host_part": s["t_residual"]},
                     "host_eigensolve_s": s["host_eig_time"],

@@ -43,7 +43,7 @@ extern "C" {
  * reserved_d) and host_merge_threads (from reserved_i), proxsdp_stats full_eigs_lanczos_certified / _cert_failed /
  * cert_matvecs (the last reserved slots):
  * same struct sizes and offsets; debug_fail_iteration now needs PROXSDP_HIP_FAULT_INJECTION=1
- * 9 (round 5): proxsdp_options grew at its END (equilibration_reference_aliasing, lanczos_device_restart, full_eig_block,
+ * 9 (round 5): proxsdp_options grew at its END (equilibration_reference_aliasing, block_batch_groups,
  * new reserved slots -- offsets of every earlier member unchanged, struct_size larger), proxsdp_stats grew at its end
  * (proxsdp_result with it: it is the LAST member); a Krylov dimension beyond 255 is served by the dense eigensolver
  * instead of PROXSDP_E_INVALID; new proxsdp_state and
@@ -340,16 +340,8 @@ typedef struct proxsdp_options {
                                   * exp(v)) at the top of every iteration and the gradient steps start from there.  1 (default):
                                   * that arithmetic, line by line -- what the reference computes; 0: the iteration the code
                                   * evidently intends (u, v kept; E = exp(u), D = exp(v)): rounds 1-4 behaviour */
-    int32_t lanczos_device_restart; /* thick restart of a KrylovKit run without a host round trip: the K x K Rayleigh-quotient
-                                  * eigensolve, the convergence test, keep = (3K + 2 conv) / 5 and the rotation coefficients are
-                                  * computed by ONE workgroup on the device and the next cycle's launches are already enqueued
-                                  * (they turn into no-ops once the run has ended); the host reads one record per projection.
-                                  * -1 auto (krylovdim <= 40, several restarts expected), 0 off, 1 whenever krylovdim <= 40 */
-    int32_t full_eig_block;      /* the Lanczos-served full_eig! (full_eig_lanczos) warm-started by BLOCK subspace iteration:
-                                  * the previous projection's positive Ritz basis (+ guard columns) is pushed through a
-                                  * Chebyshev filter in ONE launch per operator application (block operator form) and
-                                  * Rayleigh-Ritz'ed; accepted under the same per-call certificate, single-vector run as the
-                                  * fall-back.  -1 auto, 0 off, 1 on */
+    int32_t reserved_i3[2];      /* zero (two designs of round 5 -- a device-side thick restart and a warm-started block filter for the
+                                  * Lanczos-served full_eig! -- were measured out before they got an option: DESIGN.md section 9) */
     int32_t block_batch_groups;  /* batched multi-block Lanczos (block_batch): equal-side blocks are split into this many groups that
                                   * run CONCURRENTLY (own stream + host thread each): one group's restart logic on the host overlaps
                                   * the other groups' cycles on the GPU.  -1 auto = 1 = one group (rounds 3-4 behaviour), k >= 2 = k
@@ -428,11 +420,7 @@ typedef struct proxsdp_stats {
     int64_t dense_truncated_projections;  /* Krylov-branch projections whose krylovdim = max(2 target_rank + 1, eigsolver_min_lanczos)
                                            * exceeds the step kernels' 255 columns: served by the dense eigensolver (top target_rank
                                            * pairs of dsyevd, the same truncated projection and min_eig); status_string says so */
-    int64_t device_restarts;              /* thick restarts done on the device (lanczos_device_restart), included in lanczos_restarts */
-    int64_t block_filter_projections;     /* Lanczos-served full_eig! calls answered by the warm-started block iteration (full_eig_block) */
-    int64_t block_filter_applies;         /* ... block operator applications they took (each counts its columns in lanczos_matvecs) */
-    int64_t block_filter_fallbacks;       /* ... attempts that did not pass their tests: the single-vector run served the call */
-    int64_t reserved_s[3];                /* zero */
+    int64_t reserved_s[7];                /* zero */
 } proxsdp_stats;
 
 /* Result (structs.jl:60-81).  Arrays are caller-allocated with the stated

@@ -117,11 +117,7 @@ struct Stats                     # proxsdp_stats
     full_eigs_lanczos_cert_failed::Int64
     cert_matvecs::Int64
     dense_truncated_projections::Int64
-    device_restarts::Int64
-    block_filter_projections::Int64
-    block_filter_applies::Int64
-    block_filter_fallbacks::Int64
-    reserved_s::NTuple{3,Int64}
+    reserved_s::NTuple{7,Int64}
 end
 
 mutable struct CResult           # proxsdp_result

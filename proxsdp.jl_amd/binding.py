@@ -112,7 +112,7 @@ def _opt_fields():
     a("host_eig_merge", i32); a("block_batch", i32); a("rocsolver_warmup", i32); a("debug_fail_iteration", i32); a("host_wait_spin", i32)
     a("sign_start_row", i32); a("general_batch", i32); a("full_eig_lanczos_certify", i32); a("host_merge_threads", i32); a("reserved_i", i32 * 1)
     a("full_eig_lanczos_tol", f64); a("reserved_d", f64 * 1)
-    a("equilibration_reference_aliasing", i32); a("lanczos_device_restart", i32); a("full_eig_block", i32)
+    a("equilibration_reference_aliasing", i32); a("reserved_i3", i32 * 2)
     a("block_batch_groups", i32); a("reserved_i2", i32 * 8); a("reserved_d2", f64 * 4)
     return F
 
@@ -140,8 +140,7 @@ class Stats(C.Structure):
                 ("batched_profiled_blocks", i64), ("host_eig_merges", i64),
                 ("host_eig_overlap_time", f64), ("sign_short_pass", i64), ("sign_short_fail", i64),
                 ("full_eigs_lanczos_certified", i64), ("full_eigs_lanczos_cert_failed", i64), ("cert_matvecs", i64),
-                ("dense_truncated_projections", i64), ("device_restarts", i64), ("block_filter_projections", i64),
-                ("block_filter_applies", i64), ("block_filter_fallbacks", i64), ("reserved_s", i64 * 3)]
+                ("dense_truncated_projections", i64), ("reserved_s", i64 * 7)]
 
 
 class Result(C.Structure):

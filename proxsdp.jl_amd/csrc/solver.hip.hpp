@@ -2138,8 +2138,7 @@ inline void Solver::merge_block_stats() {
         PX_MERGE(full_eig_solver_ms); PX_MERGE(full_eig_recon_ms);
         PX_MERGE(full_eigs_lanczos); PX_MERGE(full_eigs_lanczos_checks); PX_MERGE(full_eigs_lanczos_mismatches);
         PX_MERGE(full_eigs_lanczos_certified); PX_MERGE(full_eigs_lanczos_cert_failed); PX_MERGE(cert_matvecs);
-        PX_MERGE(dense_truncated_projections); PX_MERGE(device_restarts); PX_MERGE(block_filter_projections);
-        PX_MERGE(block_filter_applies); PX_MERGE(block_filter_fallbacks);
+        PX_MERGE(dense_truncated_projections);
         PX_MERGE(full_eigs_sign); PX_MERGE(sign_products); PX_MERGE(sign_short_pass); PX_MERGE(sign_short_fail);
         PX_MERGE(sign_engine_projections); PX_MERGE(sign_engine_rejected);
         PX_MERGE(sign_engine_checks); PX_MERGE(sign_engine_mismatches);

@@ -257,3 +257,42 @@ def test_config4_shape_two_shards_of_four_blocks_reproduce_the_single_process_so
     assert abs(mv - ref.stats["lanczos_matvecs"]) <= 0.01 * ref.stats["lanczos_matvecs"]
     assert np.allclose(x, ref.primal, rtol=0, atol=1e-5 * max(1.0, np.abs(ref.primal).max()))
     assert abs(ref.objval - gold["objval"]) <= 1e-4 * (1 + abs(gold["objval"]))
+
+
+def _abort_semantics_worker(q):
+    """world = 1, native RCCL: an ARGUMENT error raised before the first collective must leave the caller's communicator
+    alone (it used to be aborted, and the header told the caller to destroy an already-released handle)"""
+    from proxsdp_jl_amd import sharded
+    comm = sharded.make_native_comm(None, 0, 1, device_id=0)
+    pr = _coupled_model()
+    sub, maps = sharded.split_block_diagonal(pr, [0, 0], 0)
+    p_, m_ = sub.A.shape[0], sub.G.shape[0]
+    coupling = dict(rows=np.array([p_ - 1, p_ + m_ - 1], dtype=np.int64), owned=np.array([1, 1], dtype=np.int32))
+    out = {}
+    try:
+        Optimizer(max_iter=50, max_linsearch_steps=0).optimize(sub, coupling=coupling, nccl_comm=comm)
+        out["first"] = "returned"
+    except B.ProxSDPHipError as e:
+        out["first"] = (e.code, str(e))
+    # the communicator is still alive: the same handle serves a valid solve, then is destroyed normally
+    sol = Optimizer(max_iter=50).optimize(sub, coupling=coupling, nccl_comm=comm, trace_capacity=50)
+    out["second"] = (int(sol.iter), int(sol.stats["rccl_reductions"]))
+    B.rccl_comm_destroy(comm)
+    out["destroyed"] = True
+    q.put(out)
+
+
+def test_argument_error_before_any_collective_leaves_the_communicator_usable():
+    """PROXSDP_E_COMM_ABORTED is returned only when the library really called ncclCommAbort (a failure after its first
+    collective was enqueued, or a bounded wait that expired); an invalid option is PROXSDP_E_INVALID and the handle stays
+    valid: solve again on it, destroy it."""
+    assert B.device_count() > 0
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_abort_semantics_worker, args=(q,))
+    p.start()
+    out = q.get(timeout=600)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert out["first"][0] == -1 and "max_linsearch_steps" in out["first"][1] and "aborted" not in out["first"][1], out
+    assert out["second"][0] == 50 and out["second"][1] >= 100 and out["destroyed"]

@@ -183,7 +183,7 @@ def test_metric_instance_into_the_full_eig_regime_against_lapack_in_the_loop():
     from the library's state 12 iterations before the 16 -> 17 rank update and run through it into the implicit
     full_eig! regime with LAPACK dsyevr in the loop (prox_operators.jl:46-59,111-126; pdhg.jl:267-283) -- the regime
     that is 65 % of the default solve's time and that the library serves with its OWN algorithm (positive-part
-    Lanczos / block iteration + per-call certificate).  The library, resumed from the same state, must follow: same
+    Lanczos + per-call certificate).  The library, resumed from the same state, must follow: same
     rank schedule, same linesearch trials, same mat-vec counts while KrylovKit is in charge, trace to 1e-8, and the
     same current_rank at the end of the window; every Lanczos-served full_eig! certified."""
     W = _late()["kU"]
@@ -205,7 +205,7 @@ def test_metric_instance_into_the_full_eig_regime_against_lapack_in_the_loop():
     assert s["full_eigs"] == n_full == W["full_eigs"]
     served = s["full_eigs_lanczos"]
     assert served >= n_full - 2, "the library's own engine did not serve the regime"      # (first call: dense engine, by design)
-    assert s["full_eigs_lanczos_certified"] + s["block_filter_projections"] >= served and s["full_eigs_lanczos_cert_failed"] == 0
+    assert s["full_eigs_lanczos_certified"] >= served and s["full_eigs_lanczos_cert_failed"] == 0
 
 
 @gpu

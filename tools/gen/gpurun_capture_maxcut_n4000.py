@@ -5,6 +5,7 @@ compact fixtures (tests/helpers.compact_state):
     state_maxcut_n4000_k1000.npz    the steady window of SURVEY section 8d ("1000-1200 from a saved state")
     state_maxcut_n4000_kU.npz       U = 12 iterations before the 16 -> 17 rank update, i.e. before the solve leaves
                                     KrylovKit's range (max_target_rank_krylov_eigs = 16) for the implicit full_eig! regime
+    state_maxcut_n4000_kEnd.npz     31 iterations before the solve stops (OPTIMAL after 8651 iterations)
 
     gpurun -- python tools/gen/gpurun_capture_maxcut_n4000.py      -> gpurun_out/cap4000/
 The CPU half resumes the oracle from these states.  Also stores the library's own trace of the whole solve."""
@@ -59,4 +60,11 @@ if first17 is not None:
     info["deterministic"] = bool(same)
     store(sol2.state, "kU")
     info["U"] = U
+# third state: 31 iterations before the solve ends -- the oracle continues it to ITS stop (same iteration, same objective?)
+kE = int(sol.iter) - 31
+sol3 = Optimizer().optimize(pr, trace_capacity=20000, capture_iteration=kE)
+info["deterministic_3"] = bool(np.array_equal(sol3.trace[:, :12], tr[:, :12]))
+store(sol3.state, "kEnd")
+info["kEnd"]["final"] = dict(iterations=int(sol3.iter), status=int(sol3.status), objval=float(sol3.objval), gap=float(sol3.gap),
+                             final_rank=int(sol3.final_rank))
 json.dump(info, open(os.path.join(out, "info.json"), "w"), indent=1)
