@@ -60,7 +60,7 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--settle", type=int, default=200,
                     help="untimed iterations BEFORE the warm-up, inside the same solve: a rank-63 solve started cold needs "
@@ -197,6 +197,8 @@ def main():
     sync()
     wall = time.time() - t0
     # NWIN consecutive K-step windows of the same solve; the reported window is the MEDIAN one (its K steps, its time)
+    # (a pinned-rank solve converges after ~1050 iterations: long --steps get as many whole windows as the solve has)
+    NWIN = max(1, min(NWIN, (len(sol.trace) - W) // max(K, 1)))
     wins = sorted((window(sol, W + q * K, K) + (q,) for q in range(NWIN)), key=lambda w_: w_[0])
     t_steps, mv_step, trials_step, rank_end, q_med = wins[len(wins) // 2]
     win_rates = [K / w_[0] for w_ in wins]

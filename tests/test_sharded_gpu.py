@@ -222,7 +222,7 @@ def test_config4_shape_two_shards_of_four_blocks_reproduce_the_single_process_so
     iteration.  MIMO's iterates have repeated eigenvalues at the truncation rank: the ulp-level
     difference between 'sum over eight blocks' and 'sum over two shards of four' is amplified along the trajectory, exactly
     as between library and oracle in test_config4_... -- so the trace must agree to 1e-9 over the first 20 iterations and to
-    the measured 1e-5 over all 76, objective and solution within the solver's tolerance."""
+    1e-7 over all 76 (measured: 1.0e-10 / 9.3e-9), with IDENTICAL mat-vec and restart totals (107 628 / 9262)."""
     import json
     from conftest import GOLDEN
     gold = json.loads((GOLDEN / "solve_mimo_n512_x8.json").read_text())
@@ -248,13 +248,13 @@ def test_config4_shape_two_shards_of_four_blocks_reproduce_the_single_process_so
         R = ref.trace[:, [1, 2, 3, 4, 7]]
         rel = np.abs(tr[:, :5] - R) / np.maximum(1.0, np.abs(R))
         print("rank", rank, "max relative trace difference: first 20 iterations %.2e, all %d: %.2e" % (rel[:20].max(), len(R), rel.max()))
-        assert rel[:20].max() <= 1e-9 and rel.max() <= 1e-5
+        assert rel[:20].max() <= 1e-9 and rel.max() <= 1e-7            # measured: 1.0e-10 / 9.3e-9
         assert abs(obj - ref.objval) <= 1e-6 * (1 + abs(ref.objval)) and frank == ref.final_rank
         x[vars_] = primal
         mv += mv_r
         rs += rs_r
     print("mat-vecs", mv, ref.stats["lanczos_matvecs"], "restarts", rs, ref.stats["lanczos_restarts"])
-    assert abs(mv - ref.stats["lanczos_matvecs"]) <= 0.01 * ref.stats["lanczos_matvecs"]
+    assert mv == ref.stats["lanczos_matvecs"] and rs == ref.stats["lanczos_restarts"]      # measured: 107628 / 9262 on both
     assert np.allclose(x, ref.primal, rtol=0, atol=1e-5 * max(1.0, np.abs(ref.primal).max()))
     assert abs(ref.objval - gold["objval"]) <= 1e-4 * (1 + abs(gold["objval"]))
 

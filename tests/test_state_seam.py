@@ -244,3 +244,25 @@ def test_metric_instance_from_iteration_one_reaches_the_saved_states_and_follows
     for tag, tol in (("k1000", 1e-8), ("kU", 1e-7)):
         worst = _compare_window(L[tag]["rows"], lt, tol, tag + " from iteration 1")
         print(tag, "worst relative trace difference: %.2e" % worst)
+
+
+@gpu
+def test_metric_instance_last_iterations_and_the_stop_against_the_oracle():
+    """The END of the default-options solve: the library's state 31 iterations before its stop (iteration 8620 of 8651),
+    continued by the oracle with LAPACK in the loop until ITS stop rule fires (pdhg.jl:248-253), and by the library from
+    the same state: both stop OPTIMAL at the same iteration with the same objective; the rows in between agree to 1e-8."""
+    W = _late()["kEnd"]
+    rows, fin = W["rows"], W["final"]
+    st = expand_state(load_compact_state(GOLDEN / "state_maxcut_n4000_kEnd.npz"))
+    k0 = int(st["iteration"])
+    assert fin["status"] == 1 and rows[-1]["iter"] == fin["iterations"]
+    pr = P.maxcut(4000, seed=0)
+    opt = Optimizer()
+    sol = opt.optimize(pr, trace_capacity=len(rows) + 50, resume=st)
+    print("library: stop at", sol.iter, "objective", opt.objective_value(), "| oracle: stop at", fin["iterations"], "objective", fin["objval"])
+    assert sol.status == 1 and sol.iter == fin["iterations"] == 8651
+    assert abs(opt.objective_value() - fin["objval"]) <= 1e-9 * abs(fin["objval"])
+    assert abs(sol.gap - fin["gap"]) <= 1e-8 and sol.final_rank == fin["final_rank"]
+    worst = _compare_window(rows, _lib_trace(sol), 1e-8, "to the stop")
+    print("worst relative trace difference over the last %d iterations: %.2e" % (len(rows), worst))
+    assert sol.stats["full_eigs_lanczos_cert_failed"] == 0
