@@ -458,7 +458,8 @@ typedef struct proxsdp_result {
  * off-diagonals carrying sqrt(2)).  Test / measurement seam (oracle resume-from-state, steady-window baselines): the
  * eigensolver workspaces are not part of it -- the reference's KrylovKit start vector is fixed
  * (krylovkit_reset_resid = false) and the library's own caches (previous Ritz factors, engine statistics) are rebuilt.
- * Not available during a certificate search, for block-sharded solves or with equilibration. */
+ * Not available for block-sharded solves or with equilibration (PROXSDP_E_UNSUPP); an iteration inside a certificate
+ * search (pdhg.jl:639-676) is not captured (ints[3] stays 0, the solve goes on). */
 #define PROXSDP_STATE_NHIST 7
 typedef struct proxsdp_state {
     int64_t struct_size;       /* = sizeof(proxsdp_state) */
