@@ -351,7 +351,13 @@ typedef struct proxsdp_options {
                                   * the 200), kernels of different streams do not overlap enough to pay for twice the launches --
                                   * kept as an opt-in for models with many more blocks */
     int32_t reserved_i2[8];      /* zero */
-    double  reserved_d2[4];      /* zero */
+    double  full_eig_lanczos_warm_pow; /* start vector of a Lanczos-served full_eig! (positive-part run, the library's own engine): the
+                                  * previous projection's Ritz vectors are summed with weights (lam_0 / lam_c)^p -- the pairs with the SMALL
+                                  * eigenvalues are the ones such a run converges last, so they get the larger share.  Default 1.0
+                                  * (measured, default-options solves: n = 4000: 687 201 -> 666 808 mat-vecs, 11.3-11.4 -> 10.9-11.1 s; n = 2000:
+                                  * 323 250 -> 316 127; n = 3000: 492 988 -> 486 157; the same iteration counts and objectives; every p in
+                                  * 0.125 .. 3 tried was better than 0); 0 = the plain sum of rounds 3-4 */
+    double  reserved_d2[3];      /* zero */
 } proxsdp_options;
 
 #define PROXSDP_TRACE_COLS 14

@@ -113,7 +113,7 @@ def _opt_fields():
     a("sign_start_row", i32); a("general_batch", i32); a("full_eig_lanczos_certify", i32); a("host_merge_threads", i32); a("reserved_i", i32 * 1)
     a("full_eig_lanczos_tol", f64); a("reserved_d", f64 * 1)
     a("equilibration_reference_aliasing", i32); a("reserved_i3", i32 * 2)
-    a("block_batch_groups", i32); a("reserved_i2", i32 * 8); a("reserved_d2", f64 * 4)
+    a("block_batch_groups", i32); a("reserved_i2", i32 * 8); a("full_eig_lanczos_warm_pow", f64); a("reserved_d2", f64 * 3)
     return F
 
 

@@ -640,7 +640,7 @@ inline const std::vector<OptEntry>& option_table() {
         PX_OPT(host_eig_merge, OT_I32), PX_OPT(block_batch, OT_I32),
         PX_OPT(rocsolver_warmup, OT_I32), PX_OPT(debug_fail_iteration, OT_I32), PX_OPT(host_wait_spin, OT_I32), PX_OPT(sign_start_row, OT_I32), PX_OPT(general_batch, OT_I32),
         PX_OPT(full_eig_lanczos_certify, OT_I32), PX_OPT(full_eig_lanczos_tol, OT_F64), PX_OPT(host_merge_threads, OT_I32),
-        PX_OPT(equilibration_reference_aliasing, OT_I32), PX_OPT(block_batch_groups, OT_I32),
+        PX_OPT(equilibration_reference_aliasing, OT_I32), PX_OPT(block_batch_groups, OT_I32), PX_OPT(full_eig_lanczos_warm_pow, OT_F64),
     };
     return t;
 }
@@ -684,7 +684,7 @@ inline void default_options(proxsdp_options* o) {      // options.jl:1-132
     o->sign_small_tile_max = 3072; o->host_eig_threads = 0; o->block_threads = -1;
     o->host_eig_merge = -1; o->block_batch = -1; o->rocsolver_warmup = 0; o->host_wait_spin = -1; o->sign_start_row = -1; o->general_batch = -1;
     o->full_eig_lanczos_certify = -1; o->full_eig_lanczos_tol = 0.0; o->host_merge_threads = -1;
-    o->equilibration_reference_aliasing = 1; o->block_batch_groups = -1;
+    o->equilibration_reference_aliasing = 1; o->block_batch_groups = -1; o->full_eig_lanczos_warm_pow = 1.0;
 }
 
 inline int set_option(proxsdp_options* o, const char* name, double v) {

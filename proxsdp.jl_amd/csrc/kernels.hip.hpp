@@ -387,12 +387,21 @@ k_lz_begin(double* __restrict__ V0, const double* __restrict__ resid, int npad, 
 // rows + per-workgroup sums of squares, then every workgroup adds the partials in the same order.
 __global__ void __launch_bounds__(TPB)
 k_lz_warm_sum(double* __restrict__ V0, const double* __restrict__ F, int ldf, int rp, const double* __restrict__ resid,
-              int npad, double* __restrict__ part) {
+              int npad, double* __restrict__ part, const double* __restrict__ lam, double wpow) {
     __shared__ double sm[NWAVE];
+    __shared__ double sw[TPB];
+    // weights (wpow != 0, positive-part runs only): column c enters with (lam_0 / lam_c)^wpow -- the pairs with the SMALL
+    // eigenvalues are the ones the run converges last, so they get the larger share of the start vector
+    if (wpow != 0.0 && lam != nullptr) {
+        const int c = threadIdx.x;
+        sw[c] = (c < rp && lam[c] > 0.0 && lam[0] > 0.0) ? pow(lam[0] / lam[c], wpow) : 1.0;
+        __syncthreads();
+    }
     const int i = blockIdx.x * TPB + threadIdx.x;
     double v = 0.0;
     if (i < npad) {
-        for (int c = 0; c < rp; ++c) v += F[(long long)c * ldf + i];
+        if (wpow != 0.0 && lam != nullptr) { for (int c = 0; c < rp; ++c) v += sw[min(c, TPB - 1)] * F[(long long)c * ldf + i]; }
+        else for (int c = 0; c < rp; ++c) v += F[(long long)c * ldf + i];
         v += 1e-3 * resid[i];
         V0[i] = v;
     }

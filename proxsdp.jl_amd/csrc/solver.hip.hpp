@@ -1491,7 +1491,9 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive
         const int nb = ceil_div(W.npad, dev::TPB);
         hipLaunchKernelGGL(dev::k_lz_warm_sum, dim3(nb), dim3(dev::TPB), 0, stream,
                            W.V.p, (const double*)(W.F.p + (size_t)W.F_first * W.npad), W.npad, W.F_r,
-                           (const double*)W.resid.p, W.npad, W.warm_part.p);
+                           (const double*)W.resid.p, W.npad, W.warm_part.p,
+                           (const double*)(positive_part && W.F_r <= dev::TPB ? W.Flam.p : nullptr),
+                           positive_part ? opt.full_eig_lanczos_warm_pow : 0.0);
         hipLaunchKernelGGL(dev::k_lz_warm_scale, dim3(nb), dim3(dev::TPB), 0, stream,
                            W.V.p, W.npad, (const double*)W.warm_part.p, nb, W.ctl_p);
         W.lst.warm_starts++;
