@@ -296,3 +296,36 @@ def test_argument_error_before_any_collective_leaves_the_communicator_usable():
     assert p.exitcode == 0
     assert out["first"][0] == -1 and "max_linsearch_steps" in out["first"][1] and "aborted" not in out["first"][1], out
     assert out["second"][0] == 50 and out["second"][1] >= 100 and out["destroyed"]
+
+
+def _abort_after_collective_worker(q):
+    """world = 1, native RCCL, fault injected in iteration 7: the failure happens AFTER collectives of this solve were enqueued,
+    so the library aborts the communicator on the way out and says so"""
+    os.environ["PROXSDP_HIP_FAULT_INJECTION"] = "1"
+    from proxsdp_jl_amd import sharded
+    comm = sharded.make_native_comm(None, 0, 1, device_id=0)
+    pr = _coupled_model()
+    sub, maps = sharded.split_block_diagonal(pr, [0, 0], 0)
+    p_, m_ = sub.A.shape[0], sub.G.shape[0]
+    coupling = dict(rows=np.array([p_ - 1, p_ + m_ - 1], dtype=np.int64), owned=np.array([1, 1], dtype=np.int32))
+    try:
+        Optimizer(max_iter=50, debug_fail_iteration=7).optimize(sub, coupling=coupling, nccl_comm=comm)
+        q.put(("returned", ""))
+    except B.ProxSDPHipError as e:
+        q.put((e.code, str(e)))
+    # (no rccl_comm_destroy: PROXSDP_E_COMM_ABORTED means the handle is already released)
+
+
+def test_failure_after_a_collective_aborts_the_communicator_and_reports_it():
+    """the caller must be able to tell that ncclCommAbort ran -- PROXSDP_E_COMM_ABORTED (-6) and a note in the
+    error text -- because an aborted communicator is already released and must not be destroyed or reused."""
+    assert B.device_count() > 0
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_abort_after_collective_worker, args=(q,))
+    p.start()
+    code, msg = q.get(timeout=600)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert code == -6, (code, msg)
+    assert "injected projection failure" in msg and "aborted" in msg
