@@ -382,7 +382,10 @@ typedef struct proxsdp_stats {
     double  init_time;           /* s: preprocess + upload ("Init")                  */
     double  loop_time;           /* s: the PDHG loop ("CP loop")                     */
     double  exit_time;           /* s: cache_solution                                */
-    double  t_primal, t_psd, t_linesearch, t_residual;   /* s, host wall incl. syncs */
+    double  t_primal, t_psd, t_linesearch, t_residual;   /* s, host wall incl. syncs: the reference's TimerOutputs sections (pdhg.jl:150-164).
+                                  * t_primal = primal_step! incl. the projection (t_psd); on the fused paths the residual / gap REDUCTIONS
+                                  * ride in the linesearch candidates' batch and its one read-back (counted in t_linesearch), t_residual is
+                                  * what is left of compute_residual! / compute_gap!: the host scalars */
     int64_t dense_passes;        /* passes over a dense A (A x or batched A' y), 8*p*n bytes each */
     double  dense_ms;            /* their summed durations (HIP events on the solve stream)    */
     int64_t fop_projections;     /* projections whose Lanczos mat-vecs ran in operator form     */
