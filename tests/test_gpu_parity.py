@@ -1961,3 +1961,24 @@ def test_sdplib_multi_block_families_follow_the_oracle_trace(name, iters, golden
     if name == "truss2":
         assert sol.stats["batched_small_eigs"] > 0
     assert sol.final_rank == ref.final_rank
+
+
+def test_weighted_warm_start_of_the_lanczos_served_full_eig_changes_work_not_results():
+    """options.full_eig_lanczos_warm_pow (round 5): the start vector of a positive-part run weights the previous Ritz vectors
+    by (lam_0 / lam_c)^p.  It is the library's own engine, converged to the same tolerances and certified either way: p = 0
+    (rounds 3-4) and p = 1 (default) must give the same solve -- iterations, rank schedule, objective -- with different
+    mat-vec totals.  Max-Cut n = 600 with max_target_rank_krylov_eigs = 4 (the implicit full_eig! regime starts at rank 5)."""
+    pr = P.maxcut(600, seed=4)
+    out = {}
+    for p in (0.0, 1.0):
+        opt = Optimizer(max_target_rank_krylov_eigs=4, full_eig_lanczos_warm_pow=p)
+        sol = opt.optimize(pr, trace_capacity=20000)
+        out[p] = (sol, opt.objective_value())
+        assert sol.status == 1 and sol.stats["full_eigs_lanczos"] > 100
+        assert sol.stats["full_eigs_lanczos_cert_failed"] == 0
+    a, b = out[0.0][0], out[1.0][0]
+    print("p = 0:", a.iter, a.stats["lanczos_matvecs"], "| p = 1:", b.iter, b.stats["lanczos_matvecs"])
+    assert a.iter == b.iter and np.array_equal(a.trace[:, 10], b.trace[:, 10]) and np.array_equal(a.trace[:, 11], b.trace[:, 11])
+    assert abs(out[0.0][1] - out[1.0][1]) <= 1e-9 * abs(out[0.0][1])
+    assert np.allclose(a.trace[:, 1:8], b.trace[:, 1:8], rtol=1e-8, atol=1e-10)
+    assert a.stats["lanczos_matvecs"] != b.stats["lanczos_matvecs"]
