@@ -266,3 +266,39 @@ def test_metric_instance_last_iterations_and_the_stop_against_the_oracle():
     worst = _compare_window(rows, _lib_trace(sol), 1e-8, "to the stop")
     print("worst relative trace difference over the last %d iterations: %.2e" % (len(rows), worst))
     assert sol.stats["full_eigs_lanczos_cert_failed"] == 0
+
+
+@gpu
+@pytest.mark.parametrize("case", ["mixed_cones", "randsdp_dense", "multi_block_small"])
+def test_state_seam_on_other_model_classes(case):
+    """the seam beyond single-block Max-Cut: a model with PSD + SOC + free variables in shuffled user order (kat_problems.mixed_cones),
+    a dense-A randSDP (proxsdp_problem.M_dense, the dense vector path) and a multi-block SDPLIB model with batched small blocks
+    (truss1: six 2 x 2 blocks + a scalar).  Library capture -> library resume: the continuation is bit-identical; library
+    capture -> ORACLE resume: the oracle follows the library's trace (1e-8)."""
+    from kat_problems import mixed_cones
+    if case == "mixed_cones":
+        pr, iters, cap = mixed_cones(0), 300, 120
+    elif case == "randsdp_dense":
+        pr, iters, cap = P.randsdp(40, 30, seed=3, dense=True), 200, 80
+    else:
+        pr, iters, cap = P.sdplib_blocks(GOLDEN / "sdplib" / "truss1.dat-s"), 300, 150
+    full = Optimizer(max_iter=iters).optimize(pr, trace_capacity=iters, capture_iteration=cap)
+    st = full.state
+    assert st is not None and st["iteration"] == cap and full.iter > cap
+    res = Optimizer(max_iter=iters).optimize(pr, trace_capacity=iters, resume=st)
+    a, b = _lib_trace(full), _lib_trace(res)
+    assert sorted(b) == list(range(cap + 1, full.iter + 1)) and res.iter == full.iter and res.status == full.status
+    for k in sorted(b):
+        assert np.array_equal(a[k][1:12], b[k][1:12]), (case, k)
+    assert np.array_equal(res.primal, full.primal)
+    if case == "randsdp_dense":
+        return                                   # (the oracle has no dense-A entry: sparse twin below)
+    o = oracle.Options()
+    o.max_iter = iters
+    ora = oracle.solve(pr, o, trace=True, resume=st)
+    assert ora.iter == full.iter and ora.status == full.status
+    for t in ora.trace:
+        r = a[t["iter"]]
+        assert int(r[11]) == t["trials"], (case, t["iter"])
+        for col, key in ((1, "prim_obj"), (2, "dual_obj"), (3, "gap"), (4, "feas"), (7, "primal_step")):
+            assert abs(r[col] - t[key]) <= 1e-8 * max(1.0, abs(t[key])), (case, t["iter"], key, r[col], t[key])
