@@ -1,0 +1,373 @@
+"""The reference's own MOI tests, restated call by call through proxsdp_jl_amd.moi (MathOptInterface's vocabulary on this
+side of the C ABI): /root/reference/test/moi_proxsdp_unit.jl (all eight models + the eig-solver settings),
+test/moi_sensorloc.jl (both forms: vector and scalar constraints), test/moi_mimo.jl, test/test_terminationstatus.jl,
+test/moitest.jl:22-30,156-170 (solver name, unsupported argument, time limit attribute).
+
+Every test runs with two back ends behind the same model layer: the CPU oracle (test infrastructure; runs here) and the
+HIP library (`-m gpu`).  Assertions and tolerances are the reference's (atol 1e-2 on objective and primal values).
+Data the reference draws from Julia's MersenneTwister is drawn from NumPy here, so those tests assert the reference's
+PROPERTIES (statuses, constraint satisfaction, |X_ij| ~ 1), not its numbers."""
+import numpy as np
+import pytest
+
+import oracle
+from proxsdp_jl_amd import binding, moi
+from proxsdp_jl_amd.optimizer import Optimizer
+
+import kat_problems as K
+
+
+class OracleOptimizer(Optimizer):
+    """The Optimizer surface with the oracle's chambolle_pock behind it (CPU): same option names (copied out of the
+    ABI's options struct), same result fields, same objective fix-up (MOI_wrapper.jl:336-337)."""
+
+    def optimize(self, problem, **kw):
+        self.empty()
+        self.problem = problem
+        o = oracle.Options()
+        for f in oracle.options.fields(oracle.Options):
+            if hasattr(self.options, f.name):
+                setattr(o, f.name, type(getattr(o, f.name))(getattr(self.options, f.name)))
+        self.sol = oracle.solve(problem, o)
+        return self.sol
+
+
+BACKENDS = [pytest.param("oracle", id="oracle"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+
+
+def make(backend, **kw):
+    """optimizer_bridged of moitest.jl:16-24: tol 1e-6, time limit 30 s."""
+    opts = dict(tol_gap=1e-6, tol_feasibility=1e-6, time_limit=30.0, warn_on_limit=1)
+    opts.update(kw)
+    return moi.Model(OracleOptimizer(**opts) if backend == "oracle" else Optimizer(**opts))
+
+
+SAF, SAT, VAF, VAT, VOV = moi.ScalarAffineFunction, moi.ScalarAffineTerm, moi.VectorAffineFunction, moi.VectorAffineTerm, moi.VectorOfVariables
+
+
+def vaf1(coef, var, const):
+    return VAF([VAT(1, SAT(coef, var))], [const])
+
+
+def same_problem(a, b):
+    assert a.n == b.n and a.max_sense == b.max_sense
+    assert (abs(a.A - b.A)).nnz == 0 and (abs(a.G - b.G)).nnz == 0
+    assert np.array_equal(a.b, b.b) and np.array_equal(a.h, b.h) and np.array_equal(a.c, b.c)
+    assert len(a.psd) == len(b.psd) and all(np.array_equal(x, y) for x, y in zip(a.psd, b.psd))
+    assert len(a.soc) == len(b.soc) and all(np.array_equal(x, y) for x, y in zip(a.soc, b.soc))
+
+
+# ------------------------------------------------------------------ moi_proxsdp_unit.jl
+def build_simple_lp(m):
+    X = m.add_variables(2)
+    m.add_constraint(SAF([SAT(2.0, X[0]), SAT(1.0, X[1])], 0.0), moi.EqualTo(4.0))
+    m.add_constraint(SAF([SAT(1.0, X[0]), SAT(2.0, X[1])], 0.0), moi.EqualTo(4.0))
+    b1 = m.add_constraint(SAF([SAT(1.0, X[0])], 0.0), moi.GreaterThan(0.0))
+    m.add_constraint(SAF([SAT(1.0, X[1])], 0.0), moi.GreaterThan(0.0))
+    m.set_objective_function(SAF([SAT(-4.0, X[0]), SAT(-3.0, X[1])], 0.0))
+    m.set_objective_sense(moi.MIN_SENSE)
+    return X, b1
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_simple_lp(backend):
+    """moi_proxsdp_unit.jl:1-49."""
+    m = make(backend)
+    m.empty()
+    assert m.is_empty()
+    X, b1 = build_simple_lp(m)
+    same_problem(m.problem(), K.simple_lp())
+    m.optimize()
+    assert abs(m.objective_value() - (-9.33333)) <= 1e-2
+    assert np.allclose(m.variable_primal(X), [1.3333, 1.3333], atol=1e-2)
+    # through the bridges: the primal of x1 >= 0 is x1, its dual is >= 0
+    assert abs(m.constraint_primal(b1) - 1.3333) <= 1e-2 and m.constraint_dual(b1) >= -1e-4
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_simple_lp_2_1d_sdp(backend):
+    """moi_proxsdp_unit.jl:51-95: the bounds as two 1 x 1 PSD cones."""
+    m = make(backend)
+    X = m.add_variables(2)
+    m.add_constraint(VOV([X[0]]), moi.PositiveSemidefiniteConeTriangle(1))
+    m.add_constraint(VOV([X[1]]), moi.PositiveSemidefiniteConeTriangle(1))
+    m.add_constraint(SAF([SAT(2.0, X[0]), SAT(1.0, X[1])], 0.0), moi.EqualTo(4.0))
+    m.add_constraint(SAF([SAT(1.0, X[0]), SAT(2.0, X[1])], 0.0), moi.EqualTo(4.0))
+    m.set_objective_function(SAF([SAT(-4.0, X[0]), SAT(-3.0, X[1])], 0.0))
+    m.set_objective_sense(moi.MIN_SENSE)
+    same_problem(m.problem(), K.simple_lp_2_1d_sdp())
+    m.optimize()
+    assert abs(m.objective_value() - (-9.33333)) <= 1e-2
+    assert np.allclose(m.variable_primal(X), [1.3333, 1.3333], atol=1e-2)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_lp_in_SDP_equality_form(backend):
+    """moi_proxsdp_unit.jl:97-138."""
+    m = make(backend)
+    X = m.add_variables(10)
+    m.add_constraint(VOV(X), moi.PositiveSemidefiniteConeTriangle(4))
+    m.add_constraint(SAF([SAT(2.0, X[0]), SAT(1.0, X[2]), SAT(1.0, X[5])], 0.0), moi.EqualTo(4.0))
+    m.add_constraint(SAF([SAT(1.0, X[0]), SAT(2.0, X[2]), SAT(1.0, X[9])], 0.0), moi.EqualTo(4.0))
+    m.set_objective_function(SAF([SAT(-4.0, X[0]), SAT(-3.0, X[2])], 0.0))
+    m.set_objective_sense(moi.MIN_SENSE)
+    same_problem(m.problem(), K.lp_in_SDP_equality_form())
+    m.optimize()
+    assert abs(m.objective_value() - (-9.33333)) <= 1e-2
+    assert np.allclose(m.variable_primal(X), [1.3333, 0, 1.3333, 0, 0, 0, 0, 0, 0, 0], atol=1e-2)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_lp_in_SDP_inequality_form(backend):
+    """moi_proxsdp_unit.jl:140-182: MAX sense, <= constraints on a 2 x 2 block."""
+    m = make(backend)
+    X = m.add_variables(3)
+    m.add_constraint(VOV(X), moi.PositiveSemidefiniteConeTriangle(2))
+    m.add_constraint(VAF([VAT(1, SAT(2.0, X[0])), VAT(1, SAT(1.0, X[2]))], [-4.0]), moi.Nonpositives(1))
+    m.add_constraint(VAF([VAT(1, SAT(1.0, X[0])), VAT(1, SAT(2.0, X[2]))], [-4.0]), moi.Nonpositives(1))
+    m.set_objective_function(SAF([SAT(4.0, X[0]), SAT(3.0, X[2])], 0.0))
+    m.set_objective_sense(moi.MAX_SENSE)
+    same_problem(m.problem(), K.lp_in_SDP_inequality_form())
+    m.optimize()
+    assert abs(m.objective_value() - 9.33333) <= 1e-2
+    assert np.allclose(m.variable_primal(X), [1.3333, 0.0, 1.3333], atol=1e-2)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_sdp_from_moi(backend):
+    """moi_proxsdp_unit.jl:184-223."""
+    m = make(backend)
+    X = m.add_variables(3)
+    cX = m.add_constraint(VOV(X), moi.PositiveSemidefiniteConeTriangle(2))
+    c = m.add_constraint(vaf1(1.0, X[1], -1.0), moi.Zeros(1))
+    m.set_objective_function(SAF([SAT(1.0, X[0]), SAT(1.0, X[2])], 0.0))
+    m.set_objective_sense(moi.MIN_SENSE)
+    same_problem(m.problem(), K.sdp_from_moi())
+    m.optimize()
+    assert m.termination_status() == "OPTIMAL"
+    assert m.primal_status() == "FEASIBLE_POINT" and m.dual_status() == "FEASIBLE_POINT"
+    assert abs(m.objective_value() - 2) <= 1e-2
+    assert np.allclose(m.variable_primal(X), np.ones(3), atol=1e-2)
+    # the two assertions the reference keeps commented out hold here
+    assert np.allclose(m.constraint_primal(cX), np.ones(3), atol=1e-2)
+    assert np.allclose(m.constraint_dual(c), 2.0, atol=1e-2)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_double_sdp_from_moi(backend):
+    """moi_proxsdp_unit.jl:225-271."""
+    m = make(backend)
+    X = m.add_variables(3)
+    Y = m.add_variables(3)
+    m.add_constraint(VOV(X), moi.PositiveSemidefiniteConeTriangle(2))
+    m.add_constraint(VOV(Y), moi.PositiveSemidefiniteConeTriangle(2))
+    m.add_constraint(vaf1(1.0, X[1], -1.0), moi.Zeros(1))
+    m.add_constraint(vaf1(1.0, Y[1], -1.0), moi.Zeros(1))
+    m.set_objective_function(SAF([SAT(1.0, v) for v in (X[0], X[-1], Y[0], Y[-1])], 0.0))
+    m.set_objective_sense(moi.MIN_SENSE)
+    same_problem(m.problem(), K.double_sdp_from_moi())
+    m.optimize()
+    assert m.termination_status() == "OPTIMAL"
+    assert m.primal_status() == "FEASIBLE_POINT" and m.dual_status() == "FEASIBLE_POINT"
+    assert abs(m.objective_value() - 4) <= 1e-2
+    assert np.allclose(m.variable_primal(X), np.ones(3), atol=1e-2)
+    assert np.allclose(m.variable_primal(Y), np.ones(3), atol=1e-2)
+
+
+def test_double_sdp_with_duplicates_is_declined():
+    """moi_proxsdp_unit.jl:273-300 puts ONE variable three times into a cone; MOI answers with a bridge (slack variables
+    and equalities) that this layer does not restate -- it says so instead of assembling a wrong model."""
+    m = make("oracle")
+    x = m.add_variable()
+    with pytest.raises(NotImplementedError):
+        m.add_constraint(VOV([x, x, x]), moi.PositiveSemidefiniteConeTriangle(2))
+
+
+def build_sdp_wiki(m):
+    X = m.add_variables(6)
+    m.add_constraint(VOV(X), moi.PositiveSemidefiniteConeTriangle(3))
+    for v in (X[0], X[2], X[5]):
+        m.add_constraint(vaf1(1.0, v, -1.0), moi.Zeros(1))
+    m.add_constraint(vaf1(1.0, X[1], 0.1), moi.Nonpositives(1))       # x <= -0.1
+    m.add_constraint(vaf1(-1.0, X[1], -0.2), moi.Nonpositives(1))     # x >= -0.2
+    m.add_constraint(vaf1(1.0, X[4], -0.5), moi.Nonpositives(1))      # x <= 0.5
+    m.add_constraint(vaf1(-1.0, X[4], 0.4), moi.Nonpositives(1))      # x >= 0.4
+    m.set_objective_function(SAF([SAT(1.0, X[3])], 0.0))
+    return X
+
+
+@pytest.mark.parametrize("settings", [dict(), dict(eigsolver=1, min_size_krylov_eigs=1), dict(eigsolver=2, min_size_krylov_eigs=1),
+                                      dict(full_eig_decomp=1)],
+                         ids=["default", "arpack", "krylovkit", "full_eig"])
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_sdp_wiki(backend, settings):
+    """moi_proxsdp_unit.jl:302-338 and the eig-solver settings of :358-370: min, then MAX on the same model."""
+    m = make(backend, **settings)
+    build_sdp_wiki(m)
+    m.set_objective_sense(moi.MIN_SENSE)
+    same_problem(m.problem(), K.sdp_wiki(False))
+    m.optimize()
+    assert abs(m.objective_value() - (-0.978)) <= 1e-2
+    m.set_objective_sense(moi.MAX_SENSE)
+    same_problem(m.problem(), K.sdp_wiki(True))
+    m.optimize()
+    assert abs(m.objective_value() - 0.872) <= 1e-2
+
+
+# ------------------------------------------------------------------ moitest.jl
+def test_solver_name_and_unsupported_argument():
+    """moitest.jl:22-30, 156-159."""
+    assert Optimizer.SOLVER_NAME == "ProxSDP"
+    with pytest.raises(Exception):
+        Optimizer(unsupportedarg=10)
+
+
+def test_attribute_time_limit_sec():
+    """moitest.jl:163-170."""
+    o = Optimizer()
+    assert o.time_limit_sec() is None
+    o.set_time_limit_sec(0.0)
+    assert o.time_limit_sec() == 0.0
+    o.set_time_limit_sec(None)
+    assert o.time_limit_sec() is None
+    o.set_time_limit_sec(1.0)
+    assert o.time_limit_sec() == 1.0
+
+
+# ------------------------------------------------------------------ test_terminationstatus.jl
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_termination_status(backend):
+    """test_terminationstatus.jl:40-73: max_iter = 1 -> ITERATION_LIMIT, time_limit = 0 -> TIME_LIMIT."""
+    m = make(backend, max_iter=1)
+    build_simple_lp(m)
+    m.optimize()
+    assert m.termination_status() == "ITERATION_LIMIT"
+    m = make(backend, time_limit=0.0)
+    build_simple_lp(m)
+    m.optimize()
+    assert m.termination_status() == "TIME_LIMIT"
+
+
+# ------------------------------------------------------------------ moi_mimo.jl
+@pytest.mark.parametrize("n", [2, 3, 4, 5])
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_moi_mimo(backend, n):
+    """moi_mimo.jl:1-78 (moitest.jl:90-98: n = 2 .. 5): min <L, X>, diag X = 1, -1 <= X_ij <= 1 written with
+    VectorAffineFunction rows; test: every |X_ij| in (0.99, 1.01)."""
+    rng = np.random.default_rng(123 + n)
+    H = rng.standard_normal((10 * n, n)); s = np.sign(rng.standard_normal(n)); s[s == 0] = 1.0
+    y = H @ s + 1e-4 * rng.standard_normal(10 * n)
+    L = np.block([[H.T @ H, -(H.T @ y)[:, None]], [-(y @ H)[None, :], np.array([[y @ y]])]])
+    m = make(backend)
+    X = m.add_variables(moi.sympackedlen(n + 1))
+    Xsq = moi.ivech(X)
+    m.add_constraint(VOV(X), moi.PositiveSemidefiniteConeTriangle(n + 1))
+    for j in range(n + 1):
+        for i in range(j):
+            m.add_constraint(vaf1(1.0, int(Xsq[i, j]), -1.0), moi.Nonpositives(1))      # X_ij <= 1
+            m.add_constraint(vaf1(-1.0, int(Xsq[i, j]), -1.0), moi.Nonpositives(1))     # X_ij >= -1
+    for i in range(n + 1):
+        m.add_constraint(vaf1(1.0, int(Xsq[i, i]), -1.0), moi.Zeros(1))
+    m.set_objective_function(SAF([SAT(float(L[i, j]), int(Xsq[i, j])) for j in range(n + 1) for i in range(n + 1)], 0.0))
+    m.set_objective_sense(moi.MIN_SENSE)
+    m.optimize()
+    assert m.termination_status() == "OPTIMAL"
+    Xs = m.variable_primal(Xsq.ravel()).reshape(n + 1, n + 1)
+    assert np.all((np.abs(Xs) > 0.99) & (np.abs(Xs) < 1.01))
+    assert np.array_equal(np.sign(Xs[:n, n]), s) or np.array_equal(np.sign(Xs[:n, n]), -s)   # the detected symbols
+
+
+# ------------------------------------------------------------------ moi_sensorloc.jl
+def sensorloc_data(seed, n):
+    """base_sensorloc.jl:2-22 with NumPy's generator."""
+    rng = np.random.default_rng(seed)
+    mm = int(np.floor(0.1 * n))
+    x_true = rng.random((2, n))
+    d = {(i, j): np.linalg.norm(x_true[:, i] - x_true[:, j]) for i in range(n) for j in range(i + 1)}
+    a = [rng.random(2) for _ in range(mm)]
+    d_bar = {(k, j): np.linalg.norm(x_true[:, j] - a[k]) for k in range(mm) for j in range(n)}
+    return mm, x_true, a, d, d_bar
+
+
+@pytest.mark.parametrize("scalar", [False, True], ids=["vector", "scalar"])
+@pytest.mark.parametrize("n", [5, 10, 20])
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_moi_sensorloc(backend, n, scalar):
+    """moi_sensorloc.jl:1-146 (moitest.jl:147-153 runs n = 5, 10): a FEASIBILITY SDP (zero objective) on an (n + 2)
+    block: anchor-to-sensor and a random tenth of the sensor-to-sensor distance equations, X[1:2, 1:2] = I.  The
+    reference's test only requires that it solves; here also: OPTIMAL, every equation satisfied to the tolerance, and
+    both constraint forms (VectorAffineFunction-in-Zeros rows / bridged scalar EqualTo) assemble the same arrays."""
+    mm, x_true, a, d, d_bar = sensorloc_data(0, n)
+    rng = np.random.default_rng(0)
+    picks = [(i, j) for i in range(n) for j in range(i) if rng.random() > 0.9]
+
+    def build(m, scalar):
+        X = m.add_variables(moi.sympackedlen(n + 2))
+        Xsq = moi.ivech(X)
+        m.add_constraint(VOV(X), moi.PositiveSemidefiniteConeTriangle(n + 2))
+        eqs = []
+
+        def eq(terms, rhs):
+            eqs.append((terms, rhs))
+            if scalar:
+                m.add_constraint(SAF([SAT(c, int(v)) for c, v in terms], 0.0), moi.EqualTo(rhs))
+            else:
+                m.add_constraint(VAF([VAT(1, SAT(c, int(v))) for c, v in terms], [-rhs]), moi.Zeros(1))
+        for j in range(n):
+            for k in range(mm):
+                eq([(a[k][0] * a[k][0], Xsq[0, 0]), (a[k][1] * a[k][1], Xsq[1, 1]), (-2 * a[k][0], Xsq[0, j + 2]),
+                    (-2 * a[k][1], Xsq[1, j + 2]), (1.0, Xsq[j + 2, j + 2])], d_bar[k, j] ** 2)
+        for (i, j) in picks:
+            eq([(1.0, Xsq[i + 2, i + 2]), (1.0, Xsq[j + 2, j + 2]), (-2.0, Xsq[i + 2, j + 2])], d[i, j] ** 2)
+        for (i, j, v) in ((0, 0, 1.0), (0, 1, 0.0), (1, 0, 0.0), (1, 1, 1.0)):
+            if scalar:
+                m.add_constraint(int(Xsq[i, j]), moi.EqualTo(v))               # MOI.SingleVariable-in-EqualTo
+            else:
+                m.add_constraint(vaf1(1.0, int(Xsq[i, j]), -v), moi.Zeros(1))
+            eqs.append(([(1.0, Xsq[i, j])], v))
+        m.set_objective_function(SAF([SAT(0.0, int(Xsq[0, 0]))], 0.0))
+        m.set_objective_sense(moi.MIN_SENSE)
+        return X, eqs
+
+    m = make(backend, tol_gap=1e-4, tol_feasibility=1e-4)
+    X, eqs = build(m, scalar)
+    other = make("oracle")
+    build(other, not scalar)
+    same_problem(m.problem(), other.problem())
+    m.optimize()
+    assert m.termination_status() == "OPTIMAL"
+    assert abs(m.objective_value()) <= 1e-8
+    x = m.variable_primal(X)
+    bnorm = np.linalg.norm([rhs for _, rhs in eqs])
+    viol = max(abs(sum(c * x[int(v) - 1] for c, v in terms) - rhs) for terms, rhs in eqs)
+    assert viol <= 1e-4 * (1.0 + bnorm)                      # the solver's own criterion (residuals.jl:5-9)
+    Xs = m.variable_primal(moi.ivech(X).ravel()).reshape(n + 2, n + 2)
+    assert np.linalg.eigvalsh(Xs).min() >= -1e-4             # (the check moi_sdplib.jl:53-56 makes on its solutions)
+
+
+def test_bridged_constraints_report_primal_and_dual_in_the_users_terms():
+    """The maps the bridges apply on the way back (VectorizeBridge: + set constant; NonnegToNonpos: sign flip): a bound
+    x >= 1 written four ways gives the same primal value x and the same multiplier."""
+    vals = []
+    for form in range(4):
+        m = make("oracle")
+        x = m.add_variable()
+        if form == 0:
+            c = m.add_constraint(SAF([SAT(1.0, x)], 0.0), moi.GreaterThan(1.0))
+        elif form == 1:
+            c = m.add_constraint(x, moi.GreaterThan(1.0))
+        elif form == 2:
+            c = m.add_constraint(vaf1(1.0, x, -1.0), moi.Nonnegatives(1))
+        else:
+            c = m.add_constraint(SAF([SAT(-1.0, x)], 0.0), moi.LessThan(-1.0))
+        m.set_objective_function(SAF([SAT(2.0, x)], 0.5))
+        m.set_objective_sense(moi.MIN_SENSE)
+        m.optimize()
+        assert m.termination_status() == "OPTIMAL"
+        assert abs(m.objective_value() - 2.5) <= 1e-4                      # objective constant (MOI_wrapper.jl:336)
+        assert abs(m.variable_primal(x) - 1.0) <= 1e-4
+        vals.append((np.ravel(m.constraint_primal(c))[0], np.ravel(m.constraint_dual(c))[0]))
+    prim = [v[0] for v in vals]
+    dual = [v[1] for v in vals]
+    assert np.allclose(prim[:2], 1.0, atol=1e-4) and abs(prim[2] - 0.0) <= 1e-4 and abs(prim[3] + 1.0) <= 1e-4
+    assert np.allclose(dual[:3], 2.0, atol=1e-3) and abs(dual[3] + 2.0) <= 1e-3
