@@ -25,6 +25,26 @@ __device__ __forceinline__ double get_all(const double* buf, int slot, int G, in
     return a;
 }
 
+// the same read with 16 loads IN FLIGHT per thread (get_all above adds every value to one accumulator in a loop: the compiler
+// waits for each relaxed atomic load before it issues the next -- 32 dependent round trips at G = 63, which is most of the
+// 10 us the first variants show; this is the variant that says what the exchange itself costs)
+__device__ __forceinline__ double get_all_batched(const double* buf, int slot, int G, int t) {
+    double a = 0.0;
+    const double* bp = buf + (size_t)slot * G * REC;
+    const int tot = G * REC;
+    for (int q0 = t; q0 < tot; q0 += 256 * 16) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int q = q0 + 256 * u;
+            v[u] = __hip_atomic_load(&bp[q < tot ? q : t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) if (q0 + 256 * u < tot) a += v[u];
+    }
+    return a;
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(256) k_flag(double* buf, int iters, double* out, unsigned* ctr, unsigned* go) {
     const int g = blockIdx.x, G = gridDim.x, t = threadIdx.x;
@@ -66,7 +86,8 @@ __global__ void __launch_bounds__(256) k_flag(double* buf, int iters, double* ou
             double a = 0.0;
             for (int q = t; q < G * REC; q += 256) a += __builtin_nontemporal_load(&buf[(size_t)slot * G * REC + q]);
             acc += a;
-        } else acc += get_all(buf, slot, G, t);
+        } else if (MODE == 5) acc += get_all_batched(buf, slot, G, t);
+        else acc += get_all(buf, slot, G, t);
     }
     out[g * 256 + t] = acc;
 }
@@ -84,20 +105,20 @@ __global__ void __launch_bounds__(256) k_read(const double* buf, int slot, doubl
 }
 
 int main() {
-    const char* names[5] = {"poll (one counter)", "poll + s_sleep", "last arriver broadcasts per-WG go words", "plain stores + __threadfence, nontemporal loads",
-                            "plain stores + release | acquire + plain loads"};
+    const char* names[6] = {"poll (one counter)", "poll + s_sleep", "last arriver broadcasts per-WG go words", "plain stores + __threadfence, nontemporal loads",
+                            "plain stores + release | acquire + plain loads", "poll (one counter), 16 record loads in flight"};
     for (int G : {63, 126}) {
         for (int pass = 0; pass < 1; ++pass) {}
         const int iters = 4000;
         double *buf, *out; unsigned *ctr, *go;
         hipMalloc(&buf, sizeof(double) * 2 * G * REC); hipMalloc(&out, sizeof(double) * G * 256); hipMalloc(&ctr, 4); hipMalloc(&go, 4 * 32 * G);
         hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-        for (int mode = 0; mode < 5; ++mode) {
+        for (int mode = 0; mode < 6; ++mode) {
             for (int rep = 0; rep < 2; ++rep) {
                 hipMemset(ctr, 0, 4); hipMemset(go, 0, 4 * 32 * G); hipMemset(buf, 0, sizeof(double) * 2 * G * REC);
                 int it = iters;
                 void* args[] = {&buf, &it, &out, &ctr, &go};
-                void* fn = mode == 0 ? (void*)k_flag<0> : mode == 1 ? (void*)k_flag<1> : mode == 2 ? (void*)k_flag<2> : mode == 3 ? (void*)k_flag<3> : (void*)k_flag<4>;
+                void* fn = mode == 0 ? (void*)k_flag<0> : mode == 1 ? (void*)k_flag<1> : mode == 2 ? (void*)k_flag<2> : mode == 3 ? (void*)k_flag<3> : mode == 4 ? (void*)k_flag<4> : (void*)k_flag<5>;
                 hipEventRecord(a);
                 hipError_t e = hipLaunchCooperativeKernel(fn, dim3(G), dim3(256), args, 0, 0);     // (cooperative only for co-residency)
                 hipEventRecord(b); hipEventSynchronize(b);
