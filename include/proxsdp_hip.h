@@ -242,9 +242,13 @@ typedef struct proxsdp_options {
                                   * 1; -1 = fixed start vector there too. */
     int32_t reconstruct_mfma;    /* rank-r reconstruction V Lam+ V': -1 auto, 0 scalar-FMA kernel, 1 fp64 MFMA
                                   * (v_mfma_f64_16x16x4_f64) kernel */
-    int32_t small_block_batch;   /* project the small PSD blocks in ONE batched Jacobi launch instead of one dense
-                                  * eigensolver call each: -1 auto (>= 2 blocks of side 2..32), 1 = every block of side
-                                  * 2..64, 0 off */
+    int32_t small_block_batch;   /* project the small PSD blocks (never on the Krylov path: side <= min_size_krylov_eigs) in
+                                  * ONE launch instead of one dense eigensolver call each: -1 auto = blocks of side 2..8 by
+                                  * the batched Jacobi kernel and blocks of side 9..64 by the one-workgroup, LDS-resident
+                                  * sign-function projection (csrc/small_sign.hip.hpp; needs full_eig_sign != 0 and every
+                                  * requested tolerance >= 1e-8 -- otherwise auto is ">= 2 blocks of side 2..32, Jacobi");
+                                  * 1 = Jacobi for every block of side 2..64; 2 = the sign kernel for every block of
+                                  * side 2..64; 0 off */
     int32_t full_eig_sign;       /* full_eig! of a dense block without an eigendecomposition: X+ = (X + X sign(X)) / 2
                                   * with sign(X) from an odd-polynomial iteration of fp64 MFMA products (34 .. 64 products of
                                   * n x n symmetric matrices, see sign_start_row; every |eigenvalue| >= 1e-10 ||X|| is resolved to 1e-15,
@@ -533,6 +537,8 @@ int  proxsdp_hip_rccl_comm_destroy(void* comm);
  * mode 2: full_eig! served by the Lanczos engine (every positive eigenpair), target_rank = estimate
  *         of the number of positive eigenvalues; *out_fell_back = 1 if the dense solver had to run;
  * mode 3: full_eig! by the batched small-block Jacobi kernel (2 <= n <= 64); *out_converged = #{lambda > 0}.
+ * mode 5: full_eig! by the one-workgroup, LDS-resident sign projection of small blocks (csrc/small_sign.hip.hpp; 2 <= n <= 64);
+ *         *out_converged = #{lambda > 0} as in mode 3.
  * mode 4: full_eig! by the sign-function projection (options.full_eig_sign = 1): fp64 MFMA products, no eigenpairs;
  *         *out_rank = #{lambda > 0};
  * resid: start vector (n) or NULL.  out_*: rank (current_rank), min_eig,

@@ -211,17 +211,31 @@ int proxsdp_hip_psd_project(const double* packed_in, int64_t n, int32_t target_r
         x.upload(packed_in, N, S.stream);
         S.P.blocks.push_back({(int)n, N, 0});
         if (mode == 2) S.eig[0].last_npos = target_rank;
-        if (mode == 3) {                                    // batched small-block Jacobi kernel on this one block
-            if (n < 2 || n > 64) throw std::invalid_argument("mode 3: 2 <= n <= 64");
+        if (mode == 3 || mode == 5) {                       // the small-block kernels on this one block: 3 batched Jacobi, 5 LDS-resident sign projection
+            if (n < 2 || n > 64) throw std::invalid_argument("mode 3 / 5: 2 <= n <= 64");
             proxsdp::DevBuf<long long> off(1); proxsdp::DevBuf<int> side(1), rk(2);
             const long long o0 = 0; const int s0 = (int)n;
             off.upload(&o0, 1, S.stream); side.upload(&s0, 1, S.stream);
-            const size_t lds = ((size_t)2 * n * (n | 1) + 64) * sizeof(double) + 64 * sizeof(int);
-            if (lds > 48 * 1024)
-                PX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(proxsdp::dev::k_small_psd_project),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(proxsdp::dev::k_small_psd_project, dim3(1), dim3(proxsdp::dev::TPB), lds, S.stream,
-                               x.p, (const long long*)off.p, (const int*)side.p, o.tol_psd, rk.p, rk.p + 1);
+            if (mode == 3) {
+                const size_t lds = ((size_t)2 * n * (n | 1) + 64) * sizeof(double) + 64 * sizeof(int);
+                if (lds > 48 * 1024)
+                    PX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(proxsdp::dev::k_small_psd_project),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(proxsdp::dev::k_small_psd_project, dim3(1), dim3(proxsdp::dev::TPB), lds, S.stream,
+                                   x.p, (const long long*)off.p, (const int*)side.p, o.tol_psd, rk.p, rk.p + 1, 2, 64);
+            } else {
+                const size_t lds = proxsdp::dev::small_sign_lds_bytes((int)n);
+                if (lds > 48 * 1024)
+                    PX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(proxsdp::dev::k_small_sign_project),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                // target_rank doubles as the start row of the schedule here (1 = full table ... 9 = row 8, the solver's default)
+                static const proxsdp::dev::SignSchedule sched;
+                const int j0 = std::max(0, std::min(target_rank - 1, proxsdp::dev::SIGN_STEPS - 3));
+                int rfail = 0;
+                for (int k = 0; k < proxsdp::dev::SIGN_STEPS; ++k) if (sched.l[k] <= 1e-10 * sched.gain[j0]) rfail = k;
+                hipLaunchKernelGGL(proxsdp::dev::k_small_sign_project, dim3(1), dim3(proxsdp::dev::SS_TPB), lds, S.stream,
+                                   x.p, (const long long*)off.p, (const int*)side.p, 2, 64, rk.p, rk.p + 1, j0, rfail, (int*)nullptr);
+            }
             int hr[2] = {0, 0};
             rk.download(hr, 2, S.stream);
             x.download(packed_out, N, S.stream);

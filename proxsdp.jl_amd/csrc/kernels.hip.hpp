@@ -1506,11 +1506,12 @@ k_lz_rotate_mfma(const double* __restrict__ V, int ldv, int K, const double* __r
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(TPB)
 k_small_psd_project(double* __restrict__ x, const long long* __restrict__ offs, const int* __restrict__ sides,
-                    double tol_psd, int* __restrict__ rank_out, int* __restrict__ npos_out) {
+                    double tol_psd, int* __restrict__ rank_out, int* __restrict__ npos_out, int nmin, int nmax) {
     extern __shared__ __attribute__((aligned(16))) double sj_mem[];
     __shared__ double s_red[NWAVE];
     __shared__ int s_cnt[2];
     const int n = sides[blockIdx.x];
+    if (n < nmin || n > nmax) return;                  // (sides outside the range belong to k_small_sign_project, small_sign.hip.hpp)
     double* __restrict__ xp = x + offs[blockIdx.x];
     const int ld = n | 1;                              // odd stride: conflict-free row and column walks
     double* A = sj_mem;                                // n x ld

@@ -475,10 +475,30 @@ inline void Solver::psd_projection(double* x) {
 inline void Solver::project_small_blocks(double* x) {
     harvest_small_ranks();
     const int nb = (int)small_blocks.size();
-    const int ld = small_maxn | 1;
-    const size_t lds = ((size_t)2 * small_maxn * ld + 64) * sizeof(double) + 64 * sizeof(int);
-    hipLaunchKernelGGL(dev::k_small_psd_project, dim3(nb), dim3(dev::TPB), lds, stream,
-                       x, (const long long*)small_off.p, (const int*)small_side.p, opt.tol_psd, small_rank.p, small_rank.p + nb);
+    bool any_jacobi = false;
+    int jac_maxn = 0;
+    for (int idx : small_blocks) if (P.blocks[idx].n <= small_jacobi_max) { any_jacobi = true; jac_maxn = std::max(jac_maxn, P.blocks[idx].n); }
+    if (any_jacobi) {
+        const int ld = jac_maxn | 1;
+        const size_t lds = ((size_t)2 * jac_maxn * ld + 64) * sizeof(double) + 64 * sizeof(int);
+        hipLaunchKernelGGL(dev::k_small_psd_project, dim3(nb), dim3(dev::TPB), lds, stream,
+                           x, (const long long*)small_off.p, (const int*)small_side.p, opt.tol_psd, small_rank.p, small_rank.p + nb,
+                           2, small_jacobi_max);
+    }
+    if (small_sign_maxn > 0) {
+        // shortened, tested schedule as Solver::full_eig_by_sign: start at row 8 (sign_start_row overrides), fall back inside the kernel
+        static const dev::SignSchedule sched;
+        int jmax = 0;
+        for (int j = 1; j + 2 < dev::SIGN_STEPS; ++j) if (std::sqrt(4e-13 * (double)dev::SS_MAXN) / sched.gain[j] <= 1e-10) jmax = j;   // (the test's tau at the largest side)
+        const int j0 = std::max(0, std::min(opt.sign_start_row < 0 ? 8 : (int)opt.sign_start_row, jmax));
+        int rfail = 0;
+        for (int k = 0; k < dev::SIGN_STEPS; ++k) if (sched.l[k] <= 1e-10 * sched.gain[j0]) rfail = k;
+        hipLaunchKernelGGL(dev::k_small_sign_project, dim3(nb), dim3(dev::SS_TPB), dev::small_sign_lds_bytes(small_sign_maxn), stream,
+                           x, (const long long*)small_off.p, (const int*)small_side.p, small_jacobi_max + 1, dev::SS_MAXN,
+                           small_rank.p, small_rank.p + nb, j0, rfail, (int*)nullptr);
+        st.full_eigs_sign += nb; st.sign_products += 57LL * nb;      // (counted per block below for the Jacobi ones)
+        for (int idx : small_blocks) if (P.blocks[idx].n <= small_jacobi_max) { st.full_eigs_sign--; st.sign_products -= 57; }
+    }
     PX_HIP(hipMemcpyAsync(small_rank_host.p, small_rank.p, (size_t)2 * nb * sizeof(int), hipMemcpyDeviceToHost, stream));
     small_pending = true;
     st.full_eigs += nb; st.batched_small_eigs += nb;
@@ -489,7 +509,10 @@ inline void Solver::harvest_small_ranks() {
     if (!small_pending) return;
     small_pending = false;
     const int* r = reinterpret_cast<const int*>(small_rank_host.p);
-    for (size_t q = 0; q < small_blocks.size(); ++q) current_rank[small_blocks[q]] = r[q];
+    for (size_t q = 0; q < small_blocks.size(); ++q) {
+        if (r[q] < 0) throw HipError("sign-function projection of a small block produced non-finite values");
+        current_rank[small_blocks[q]] = r[q];
+    }
 }
 
 // primal_step! (pdhg.jl:611-637)
@@ -1629,6 +1652,12 @@ inline void Solver::run() {
         setup_long_rows(rp);
     }
     eig.resize(nb);
+    // small blocks by the sign function in one launch: auto (and small_block_batch = 2) unless the tiled sign projection is
+    // switched off or the solve asks for tolerances below that engine's 1e-10-of-the-scale floor (as full_eig_by_sign)
+    const bool small_sign = opt.small_block_batch == 2 ||
+        (opt.small_block_batch < 0 && opt.full_eig_sign != 0 &&
+         std::min({opt.tol_gap, opt.tol_feasibility, opt.tol_primal, opt.tol_dual}) >= 1e-8);
+    small_jacobi_max = small_sign ? (opt.small_block_batch == 2 ? 1 : 8) : 64;
     {
         std::vector<long long> offs;
         const double* ur = user_resid;
@@ -1637,10 +1666,11 @@ inline void Solver::run() {
             if (B.n == 1) { one_blocks.push_back((int)idx); offs.push_back(B.off); if (ur) ur += 1; continue; }
             EigWork& W = eig[idx];
             big_blocks.push_back((int)idx);
-            // side 2..64 and never on the Krylov path: batched Jacobi projection (dense vector path)
-            // (auto: side <= 32 -- measured: at side 50 the single-workgroup Jacobi takes 5.9 ms against 1.1 ms
-            // for one rocSOLVER call; two blocks of side 10 and 5: 1.4x faster batched; seven of side 2: 6.4x)
-            if (opt.small_block_batch != 0 && B.n <= (opt.small_block_batch > 0 ? 64 : 32) &&
+            // side 2..64 and never on the Krylov path: ONE launch for all of them (dense vector path): batched Jacobi
+            // (auto: side <= 8 -- measured: at side 22 the single-workgroup Jacobi takes 950 us, at side 50 5.9 ms against
+            // 1.1 ms for one rocSOLVER call; two blocks of side 10 and 5: 1.4x faster batched; seven of side 2: 6.4x) and,
+            // round 5, the one-workgroup LDS-resident sign projection (small_sign.hip.hpp) for sides 9 .. 64
+            if (opt.small_block_batch != 0 && B.n <= (opt.small_block_batch > 0 || small_sign ? 64 : 32) &&
                 B.n <= opt.min_size_krylov_eigs && !sharded())
                 small_blocks.push_back((int)idx);
             else
@@ -1661,7 +1691,7 @@ inline void Solver::run() {
             for (int i = 0; i < B.n; ++i) W.resid_host[i] /= nr;
             W.resid.upload(W.resid_host.data(), W.npad, stream);
         }
-        if (small_blocks.size() < 2 && opt.small_block_batch < 0) {          // auto: a batch needs several blocks
+        if (small_blocks.size() < 2 && opt.small_block_batch < 0 && !small_sign) {   // auto, Jacobi only: a batch needs several blocks
             large_blocks = big_blocks; small_blocks.clear();
         }
         // several eigensolver-sized blocks: project them concurrently, one worker thread and one
@@ -1689,10 +1719,16 @@ inline void Solver::run() {
             small_off.alloc(so.size()); small_side.alloc(ss.size()); small_rank.alloc(2 * ss.size());
             small_off.upload(so.data(), so.size(), stream); small_side.upload(ss.data(), ss.size(), stream);
             small_rank_host.alloc(ss.size() + 1);
-            const size_t lds = ((size_t)2 * small_maxn * (small_maxn | 1) + 64) * sizeof(double) + 64 * sizeof(int);
+            small_sign_maxn = 0;
+            int jac_maxn = 0;
+            for (int sd : ss) { if (sd > small_jacobi_max) small_sign_maxn = std::max(small_sign_maxn, sd); else jac_maxn = std::max(jac_maxn, sd); }
+            const size_t lds = ((size_t)2 * jac_maxn * (jac_maxn | 1) + 64) * sizeof(double) + 64 * sizeof(int);
             if (lds > 48 * 1024)
                 PX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_small_psd_project),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (small_sign_maxn > 0 && dev::small_sign_lds_bytes(small_sign_maxn) > 48 * 1024)
+                PX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_small_sign_project),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev::small_sign_lds_bytes(small_sign_maxn)));
             PX_HIP(hipStreamSynchronize(stream));
         }
         if (!offs.empty()) {

@@ -32,6 +32,7 @@
 #include "host_util.hpp"
 #include "kernels.hip.hpp"
 #include "lanczos_cycle.hip.hpp"
+#include "small_sign.hip.hpp"
 #include "sign_project.hip.hpp"
 #include "rccl_dl.hpp"
 #include "prep.hpp"
@@ -535,6 +536,8 @@ private:
     DevBuf<int> small_side, small_rank;        // small_rank: [rank | npos] per block
     PinnedBuf small_rank_host;
     int small_maxn = 0;
+    int small_jacobi_max = 64;                 // small blocks up to this side: batched Jacobi; above: k_small_sign_project
+    int small_sign_maxn = 0;                   // largest side served by k_small_sign_project (0: none)
     bool small_pending = false;
     void project_small_blocks(double* x);
     void harvest_small_ranks();

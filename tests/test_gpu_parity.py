@@ -1294,6 +1294,56 @@ def test_sdplib_multiblock_instances_with_batched_small_blocks(fname, lit, budge
     assert sols[0][1].stats["batched_small_eigs"] == 0
 
 
+@pytest.mark.parametrize("n", [2, 3, 9, 16, 17, 22, 31, 33, 48, 50, 64])
+def test_small_block_sign_projection_against_lapack(n):
+    """k_small_sign_project (csrc/small_sign.hip.hpp: the whole sign-function projection of a block of side <= 64 in ONE
+    launch, one workgroup, iterates in LDS, fp64 MFMA products) through psd_project mode 5: == LAPACK's projection to
+    1e-10 of the spectral scale (the floor of the iteration, as for the tiled sign projection), the count of positive
+    eigenvalues exact; indefinite, definite (both signs), low-rank and zero inputs; spectra spread over eight decades."""
+    rng = np.random.default_rng(100 + n)
+    cases = []
+    M = rng.standard_normal((n, n)); cases.append((M + M.T) / 2)
+    cases.append(cases[0] @ cases[0].T)                                   # positive definite: X+ = X
+    cases.append(-(cases[0] @ cases[0].T))                                # negative definite: X+ = 0
+    U, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    lam = np.concatenate([10.0 ** rng.uniform(-6, 2, n // 2), -10.0 ** rng.uniform(-6, 2, n - n // 2)])
+    cases.append((U * lam) @ U.T)                                         # eight decades, both signs
+    k = max(1, n // 3)
+    cases.append((U[:, :k] * np.linspace(1.0, 2.0, k)) @ U[:, :k].T - (U[:, k:2 * k] * 0.5) @ U[:, k:2 * k].T)   # low rank
+    cases.append(np.zeros((n, n)))
+    for X in cases:
+        X = (X + X.T) / 2
+        w, Q = np.linalg.eigh(X)
+        ref = (Q * np.maximum(w, 0.0)) @ Q.T
+        scale = max(np.abs(w).max(), 1e-300)
+        resolved = np.abs(w) > 1e-9 * scale
+        for start_row in (0, 8):                  # the full table | the shortened, tested schedule the solver uses (with its in-kernel fall-back)
+            out, info = B.psd_project(svec(X), n, start_row + 1, mode=5)
+            assert np.abs(out - svec(ref)).max() <= 1e-10 * scale + 1e-300, (n, start_row, np.abs(out - svec(ref)).max() / scale)
+            assert info["rank"] >= int((w[resolved] > 0).sum()) and info["rank"] <= int((w > 0).sum()) + int((~resolved).sum())
+
+
+def test_small_models_take_the_one_launch_projections_and_follow_the_oracle():
+    """Models whose PSD blocks never take the Krylov path (side <= min_size_krylov_eigs): one launch per iteration for
+    all of them -- Jacobi up to side 8, the LDS-resident sign projection from 9 to 64 (auto) -- against the oracle's
+    LAPACK full_eig!: same iteration counts and traces on a 22 x 22 sensor-localisation-shaped block (MIMO 21),
+    Max-Cut 60 and a mixed model; and the same solves with the batch switched off (rocSOLVER / tiled sign)."""
+    import oracle
+    for pr, iters in ((P.mimo(21, seed=3), 150), (P.maxcut(60, seed=2), 150), (P.maxcut(33, seed=1), 150)):
+        o = oracle.Options(); o.max_iter = iters
+        ref = oracle.solve(pr, o, trace=True)
+        exp = np.array([t["prim_obj"] for t in ref.trace])
+        a = Optimizer(max_iter=iters).optimize(pr, trace_capacity=iters)
+        b = Optimizer(max_iter=iters, small_block_batch=0).optimize(pr, trace_capacity=iters)
+        assert a.stats["batched_small_eigs"] == a.iter and a.stats["full_eigs_sign"] == a.iter and b.stats["batched_small_eigs"] == 0
+        for sol in (a, b):
+            assert sol.iter == ref.iter and sol.status == ref.status
+            got = np.array([r[1] for r in sol.trace])
+            # (the sign projections resolve X+ to 1e-10 of its spectral scale: the objective <c, x> sees that times |c|)
+            atol = 1e-9 * (1.0 + float(np.linalg.norm(pr.c)) * np.sqrt(pr.n))
+            assert np.allclose(got, exp, rtol=1e-7, atol=atol), (float(np.abs(got - exp).max()), atol)
+
+
 @pytest.mark.parametrize("n", [2, 3, 7, 16, 31, 50, 64])
 def test_batched_small_block_projection_against_lapack(n):
     """k_small_psd_project (parallel-order cyclic Jacobi in LDS) on many random blocks of one size in a

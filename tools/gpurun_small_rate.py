@@ -26,7 +26,7 @@ def sensorloc(n):
     m.set_objective_function(T.SAF([T.SAT(0.0, int(Xsq[0,0]))], 0.0)); m.set_objective_sense(moi.MIN_SENSE)
     return m.problem("sensorloc%d" % n)
 
-tight = dict(tol_gap=1e-12, tol_feasibility=1e-12)
+tight = dict(tol_gap=1e-8, tol_feasibility=1e-8, min_iter=10**9)   # (1e-8: the loosest setting the sign engines accept; never stops)
 cases = [("sdp_wiki 3x3", K.sdp_wiki(False), dict(max_iter=3000, **tight)),
          ("sensorloc 22x22", sensorloc(20), dict(max_iter=20000, **tight)),
          ("mixed_cones (1,3,104,1,5)", K.mixed_cones(), dict(max_iter=3000, **tight)),
@@ -34,7 +34,7 @@ cases = [("sdp_wiki 3x3", K.sdp_wiki(False), dict(max_iter=3000, **tight)),
          ("maxcut150 (Lanczos)", P.maxcut(150, seed=0), dict(max_iter=3000, **tight)),
          ("mimo32", P.mimo(32, seed=0), dict(max_iter=3000, **tight))]
 for name, pr, kw in cases:
-    for sbb in (0, -1, 1):
+    for sbb in (0, -1, 1, 2):
         s = Optimizer(small_block_batch=sbb, **kw).optimize(pr)
         st = s.stats
         print(f"{name}: small_block_batch {sbb:2d}: iter {s.iter} status {s.status} {s.iter/st['loop_time']:.0f} it/s, {1e6*st['loop_time']/s.iter:.1f} us/iter "
