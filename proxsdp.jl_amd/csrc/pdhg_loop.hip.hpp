@@ -495,11 +495,11 @@ inline void Solver::project_small_blocks(double* x) {
         for (int k = 0; k < dev::SIGN_STEPS; ++k) if (sched.l[k] <= 1e-10 * sched.gain[j0]) rfail = k;
         hipLaunchKernelGGL(dev::k_small_sign_project, dim3(nb), dim3(dev::SS_TPB), dev::small_sign_lds_bytes(small_sign_maxn), stream,
                            x, (const long long*)small_off.p, (const int*)small_side.p, small_jacobi_max + 1, dev::SS_MAXN,
-                           small_rank.p, small_rank.p + nb, j0, rfail, (int*)nullptr);
+                           small_rank.p, small_rank.p + nb, j0, rfail, j0 > 0 ? small_rank.p + 2 * nb : (int*)nullptr);
         st.full_eigs_sign += nb; st.sign_products += 57LL * nb;      // (counted per block below for the Jacobi ones)
         for (int idx : small_blocks) if (P.blocks[idx].n <= small_jacobi_max) { st.full_eigs_sign--; st.sign_products -= 57; }
     }
-    PX_HIP(hipMemcpyAsync(small_rank_host.p, small_rank.p, (size_t)2 * nb * sizeof(int), hipMemcpyDeviceToHost, stream));
+    PX_HIP(hipMemcpyAsync(small_rank_host.p, small_rank.p, ((size_t)2 * nb + 2) * sizeof(int), hipMemcpyDeviceToHost, stream));
     small_pending = true;
     st.full_eigs += nb; st.batched_small_eigs += nb;
     for (int idx : small_blocks) { current_rank[idx] = 0; min_eig[idx] = 0.0; }
@@ -513,6 +513,10 @@ inline void Solver::harvest_small_ranks() {
         if (r[q] < 0) throw HipError("sign-function projection of a small block produced non-finite values");
         current_rank[small_blocks[q]] = r[q];
     }
+    // the shortened schedule's tests made inside k_small_sign_project (cumulative counters behind the ranks)
+    const int* cnt = r + 2 * small_blocks.size();
+    st.sign_short_pass += cnt[0] - small_short_seen[0]; st.sign_short_fail += cnt[1] - small_short_seen[1];
+    small_short_seen[0] = cnt[0]; small_short_seen[1] = cnt[1];
 }
 
 // primal_step! (pdhg.jl:611-637)
@@ -1716,9 +1720,9 @@ inline void Solver::run() {
         if (!small_blocks.empty()) {
             std::vector<long long> so; std::vector<int> ss;
             for (int idx : small_blocks) { so.push_back(P.blocks[idx].off); ss.push_back(P.blocks[idx].n); small_maxn = std::max(small_maxn, P.blocks[idx].n); }
-            small_off.alloc(so.size()); small_side.alloc(ss.size()); small_rank.alloc(2 * ss.size());
+            small_off.alloc(so.size()); small_side.alloc(ss.size()); small_rank.alloc(2 * ss.size() + 2); small_rank.zero(stream);   // [rank | npos] per block, then the sign kernel's cumulative [pass, fail] counters
             small_off.upload(so.data(), so.size(), stream); small_side.upload(ss.data(), ss.size(), stream);
-            small_rank_host.alloc(ss.size() + 1);
+            small_rank_host.alloc(ss.size() + 2);
             small_sign_maxn = 0;
             int jac_maxn = 0;
             for (int sd : ss) { if (sd > small_jacobi_max) small_sign_maxn = std::max(small_sign_maxn, sd); else jac_maxn = std::max(jac_maxn, sd); }

@@ -538,6 +538,7 @@ private:
     int small_maxn = 0;
     int small_jacobi_max = 64;                 // small blocks up to this side: batched Jacobi; above: k_small_sign_project
     int small_sign_maxn = 0;                   // largest side served by k_small_sign_project (0: none)
+    int small_short_seen[2] = {0, 0};          // its cumulative [pass, fail] test counters as of the last harvest
     bool small_pending = false;
     void project_small_blocks(double* x);
     void harvest_small_ranks();
