@@ -124,7 +124,10 @@ k_small_sign_project(double* __restrict__ x, const long long* __restrict__ offs,
     const int N = n * (n + 1) / 2;
     if (!(f2 > 0.0)) {                                       // the zero matrix (or non-finite input: left alone)
         if (f2 == 0.0) for (int t = tid; t < N; t += SS_TPB) xp[t] = 0.0;
-        if (tid == 0) { rank_out[blockIdx.x] = 0; npos_out[blockIdx.x] = 0; }
+        if (tid == 0) {
+            rank_out[blockIdx.x] = 0; npos_out[blockIdx.x] = 0;
+            if (short_stats != nullptr && j0 > 0) atomicAdd(short_stats, 1);     // (the first PDHG iterate is exactly zero: counted as resolved)
+        }
         return;
     }
     const double f = sqrt(f2);

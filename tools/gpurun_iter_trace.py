@@ -12,6 +12,8 @@ if sys.argv[1] == "run":
     kw = {}
     if name.startswith("maxcut"):
         pr = P.maxcut(int(name[6:]), seed=0)
+    elif name.startswith("mimo1x"):
+        pr = P.mimo(int(name[6:]), seed=0)                      # ONE small block (side n + 1): the small-model regime
     elif name.startswith("mimo"):
         pr = P.block_diag_problems([P.mimo(512, seed=s) for s in range(8)], name="mimo8")
     else:
