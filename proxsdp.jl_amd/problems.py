@@ -246,6 +246,58 @@ def mimo(n, seed=0):
                    psd=[np.arange(N, dtype=np.int64)], name=f"mimo-n{n}-s{seed}")
 
 
+# --------------------------------------------------------------------------- sensor localisation
+def sensorloc_data(n, seed):
+    """test/base_sensorloc.jl:2-22 (own RNG): n sensors and m = n // 10 anchors in the unit square, all pairwise distances."""
+    rng = np.random.default_rng(seed)
+    m = int(np.floor(0.1 * n))
+    x_true = rng.random((2, n))
+    a = rng.random((m, 2))
+    return m, x_true, a
+
+
+def sensorloc(n, seed=0, keep=0.1):
+    """test/moi_sensorloc.jl / test/jump_sensorloc.jl (the SENSORLOC set of the reference's benchmark, test/runbench.jl:
+    n = 100 .. 400): a FEASIBILITY SDP on one (n + 2) x (n + 2) block Z = [I X; X' Y]:
+        anchor k - sensor j:  a_k1^2 Z11 + a_k2^2 Z22 - 2 a_k1 Z[1, j+2] - 2 a_k2 Z[2, j+2] + Z[j+2, j+2] = dbar_kj^2   (all k, j)
+        sensor i - sensor j:  Z[i+2, i+2] + Z[j+2, j+2] - 2 Z[i+2, j+2] = d_ij^2       (a random tenth of the pairs)
+        Z11 = 1, Z12 = 0, Z21 = 0, Z22 = 1
+    zero objective; rows in the reference's order (VectorAffineFunction-in-Zeros, one row each; Z12 appears twice as the
+    reference writes it)."""
+    m, x_true, a = sensorloc_data(n, seed)
+    rng = np.random.default_rng(seed + 1)
+    side = n + 2
+    N = sympackedlen(side)
+    T = lambda i, j: int(tri_index(min(i, j), max(i, j)))
+    rows, cols, vals, b = [], [], [], []
+
+    def eq(terms, rhs):
+        r = len(b)
+        acc = {}
+        for coef, col in terms:
+            acc[col] = acc.get(col, 0.0) + coef
+        for col, coef in acc.items():
+            rows.append(r); cols.append(col); vals.append(coef)
+        b.append(rhs)
+    for j in range(n):
+        for k in range(m):
+            dbar2 = float(np.sum((x_true[:, j] - a[k]) ** 2))
+            eq([(a[k, 0] ** 2, T(0, 0)), (a[k, 1] ** 2, T(1, 1)), (-2 * a[k, 0], T(0, j + 2)), (-2 * a[k, 1], T(1, j + 2)),
+                (1.0, T(j + 2, j + 2))], dbar2)
+    for i in range(n):
+        for j in range(i):
+            if rng.random() > 1.0 - keep:
+                d2 = float(np.sum((x_true[:, i] - x_true[:, j]) ** 2))
+                eq([(1.0, T(i + 2, i + 2)), (1.0, T(j + 2, j + 2)), (-2.0, T(i + 2, j + 2))], d2)
+    for (i, j, v) in ((0, 0, 1.0), (0, 1, 0.0), (1, 0, 0.0), (1, 1, 1.0)):
+        eq([(1.0, T(i, j))], v)
+    A = sp.csc_matrix((vals, (rows, cols)), shape=(len(b), N))
+    pr = Problem(n=N, A=A, b=np.array(b), G=_empty(N), h=np.zeros(0), c=np.zeros(N),
+                 psd=[np.arange(N, dtype=np.int64)], name=f"sensorloc-n{n}-s{seed}")
+    pr.x_true = x_true
+    return pr
+
+
 def block_diag_problems(probs, name="blockdiag"):
     """Several independent models in one (what "8 blocks" means for the MIMO
     config: one block-diagonal model)."""
