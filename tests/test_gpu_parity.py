@@ -1344,6 +1344,24 @@ def test_small_models_take_the_one_launch_projections_and_follow_the_oracle():
             assert np.allclose(got, exp, rtol=1e-7, atol=atol), (float(np.abs(got - exp).max()), atol)
 
 
+@pytest.mark.parametrize("n", [50, 100])
+def test_sensorloc_benchmark_family_takes_the_oracles_iterations(n):
+    """The SENSORLOC set of the reference's benchmark (test/runbench.jl:103-108, test/jump_sensorloc.jl; problems.sensorloc):
+    a feasibility SDP on one (n + 2) block.  n = 50 (side 52: the one-launch sign projection of small blocks) and n = 100
+    (side 102: the Krylov path, ~70 mat-vecs per iteration) with reference default options against the oracle's solve:
+    OPTIMAL after the SAME number of iterations, zero objective, the sensors' positions recovered."""
+    import oracle
+    pr = P.sensorloc(n, seed=0)
+    ref = oracle.solve(pr, oracle.Options())
+    sol = Optimizer().optimize(pr)
+    print("sensorloc", n, "gpu", sol.status, sol.iter, sol.time, "oracle", ref.status, ref.iter)
+    assert sol.status == ref.status == 1 and sol.iter == ref.iter
+    assert abs(sol.objval) <= 1e-10 and sol.primal_feasible_user_tol
+    X = P.unpack_psd(sol.primal, n + 2)
+    assert np.abs(X[:2, 2:] - pr.x_true).max() <= 1e-3 and np.linalg.eigvalsh(X).min() >= -1e-6
+    assert np.allclose(sol.primal, ref.primal, atol=1e-6)
+
+
 @pytest.mark.parametrize("n", [2, 3, 7, 16, 31, 50, 64])
 def test_batched_small_block_projection_against_lapack(n):
     """k_small_psd_project (parallel-order cyclic Jacobi in LDS) on many random blocks of one size in a

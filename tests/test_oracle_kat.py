@@ -300,3 +300,16 @@ def test_metric_instance_end_state_is_pinned(golden_dir):
     for name, obj in g["tol1e-4_legs"].items():
         rel = abs(obj - g["objective"]) / (1 + abs(g["objective"]))
         assert rel <= 2e-3, (name, rel)           # the stop rule's own slack; see the docstring
+
+
+def test_sensorloc_generator_and_oracle_solve():
+    """problems.sensorloc (test/base_sensorloc.jl, test/moi_sensorloc.jl): row counts, the four Z[1:2,1:2] = I rows, and the oracle
+    localises 30 sensors from 3 anchors + a tenth of the pairwise distances."""
+    from proxsdp_jl_amd import problems as P
+    pr = P.sensorloc(30, seed=0)
+    assert pr.n == 32 * 33 // 2 and pr.m == 0 and len(pr.psd) == 1 and pr.p >= 30 * 3 + 4
+    assert np.allclose(pr.b[-4:], [1.0, 0.0, 0.0, 1.0]) and not pr.c.any()
+    r = oracle.solve(pr, Options())
+    assert r.status == 1 and abs(r.objval) <= 1e-12
+    X = P.unpack_psd(r.primal, 32)
+    assert np.abs(X[:2, 2:] - pr.x_true).max() <= 1e-2
