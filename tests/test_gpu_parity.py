@@ -1344,6 +1344,21 @@ def test_small_models_take_the_one_launch_projections_and_follow_the_oracle():
             assert np.allclose(got, exp, rtol=1e-7, atol=atol), (float(np.abs(got - exp).max()), atol)
 
 
+@pytest.mark.parametrize("name,build", [("randsdp-5x5", lambda: P.randsdp(5, 5, seed=1)), ("mimo-60", lambda: P.mimo(60, seed=0)),
+                                        ("mimo-100", lambda: P.mimo(100, seed=0))])
+def test_reference_benchmark_small_instances_take_the_oracles_iterations(name, build):
+    """The small ends of the reference's benchmark sets (test/runbench.jl: RANDSDP 5 x 5, MIMO 100; MIMO 60 for the one-launch
+    small-block projection) with reference default options: the library stops OPTIMAL after the oracle's iteration count
+    (1216 / 45 / 52) at the oracle's objective."""
+    import oracle
+    pr = build()
+    ref = oracle.solve(pr, oracle.Options())
+    sol = Optimizer().optimize(pr)
+    print(name, "gpu", sol.status, sol.iter, sol.objval, "oracle", ref.status, ref.iter, ref.objval)
+    assert sol.status == ref.status == 1 and sol.iter == ref.iter
+    assert abs(sol.objval - ref.objval) <= 1e-6 * (1 + abs(ref.objval))
+
+
 @pytest.mark.parametrize("n", [50, 100])
 def test_sensorloc_benchmark_family_takes_the_oracles_iterations(n):
     """The SENSORLOC set of the reference's benchmark (test/runbench.jl:103-108, test/jump_sensorloc.jl; problems.sensorloc):
