@@ -243,8 +243,8 @@ typedef struct proxsdp_options {
     int32_t reconstruct_mfma;    /* rank-r reconstruction V Lam+ V': -1 auto, 0 scalar-FMA kernel, 1 fp64 MFMA
                                   * (v_mfma_f64_16x16x4_f64) kernel */
     int32_t small_block_batch;   /* project the small PSD blocks (never on the Krylov path: side <= min_size_krylov_eigs) in
-                                  * ONE launch instead of one dense eigensolver call each: -1 auto = blocks of side 2..8 by
-                                  * the batched Jacobi kernel and blocks of side 9..64 by the one-workgroup, LDS-resident
+                                  * ONE launch instead of one dense eigensolver call each: -1 auto = blocks of side 2 by
+                                  * the batched Jacobi kernel and blocks of side 3..64 by the one-workgroup, LDS-resident
                                   * sign-function projection (csrc/small_sign.hip.hpp; needs full_eig_sign != 0 and every
                                   * requested tolerance >= 1e-8 -- otherwise auto is ">= 2 blocks of side 2..32, Jacobi");
                                   * 1 = Jacobi for every block of side 2..64; 2 = the sign kernel for every block of

@@ -1661,7 +1661,7 @@ inline void Solver::run() {
     const bool small_sign = opt.small_block_batch == 2 ||
         (opt.small_block_batch < 0 && opt.full_eig_sign != 0 &&
          std::min({opt.tol_gap, opt.tol_feasibility, opt.tol_primal, opt.tol_dual}) >= 1e-8);
-    small_jacobi_max = small_sign ? (opt.small_block_batch == 2 ? 1 : 8) : 64;
+    small_jacobi_max = small_sign ? (opt.small_block_batch == 2 ? 1 : 2) : 64;   // (measured, tools/gpurun_jacobi_vs_sign.py: from side 3 on the sign kernel wins)
     {
         std::vector<long long> offs;
         const double* ur = user_resid;
@@ -1671,9 +1671,10 @@ inline void Solver::run() {
             EigWork& W = eig[idx];
             big_blocks.push_back((int)idx);
             // side 2..64 and never on the Krylov path: ONE launch for all of them (dense vector path): batched Jacobi
-            // (auto: side <= 8 -- measured: at side 22 the single-workgroup Jacobi takes 950 us, at side 50 5.9 ms against
+            // (auto: side 2 only -- measured: 80 / 140 / 370 us per iteration at side 3 / 8 / 16 where the sign kernel stays at 60; at side 22 the
+            // single-workgroup Jacobi takes 950 us, at side 50 5.9 ms against
             // 1.1 ms for one rocSOLVER call; two blocks of side 10 and 5: 1.4x faster batched; seven of side 2: 6.4x) and,
-            // round 5, the one-workgroup LDS-resident sign projection (small_sign.hip.hpp) for sides 9 .. 64
+            // round 5, the one-workgroup LDS-resident sign projection (small_sign.hip.hpp) for sides 3 .. 64
             if (opt.small_block_batch != 0 && B.n <= (opt.small_block_batch > 0 || small_sign ? 64 : 32) &&
                 B.n <= opt.min_size_krylov_eigs && !sharded())
                 small_blocks.push_back((int)idx);

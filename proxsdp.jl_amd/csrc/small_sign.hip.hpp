@@ -1,4 +1,4 @@
-// PSD projection of a SMALL dense block (side 9 .. 64) by the matrix sign function in ONE launch, one workgroup per block,
+// PSD projection of a SMALL dense block (side 3 .. 64) by the matrix sign function in ONE launch, one workgroup per block,
 // all iterates in LDS.
 //
 // Replaces full_eig! (prox_operators.jl:111-126: eigen!(Symmetric(X)) + the rank-1 loop) for blocks that never take the
