@@ -19,8 +19,8 @@ the rest into (with_bridge_type = Float64, as the tests instantiate it):
 
 Variable indices are 1-based integers (`VariableIndex.value`).  Rows keep the order in which the
 constraints were added, per native set, as `MOI.Utilities.MatrixOfConstraints` does.  A variable that
-appears twice in one cone (moi_proxsdp_unit.jl `double_sdp_with_duplicates`) is rejected here: the
-bridge that handles it in MOI (slack variables + equalities) is not restated.
+appears twice in one cone (moi_proxsdp_unit.jl `double_sdp_with_duplicates`) gets what MOI's bridges give it:
+fresh slack variables in the cone and equality rows tying them to the user's variable.
 """
 from dataclasses import dataclass, field
 
@@ -208,7 +208,14 @@ class Model:
         if isinstance(f, VectorOfVariables):
             v = [int(x) for x in f.variables]
             if len(set(v)) != len(v):
-                raise NotImplementedError("a variable twice in one cone needs MOI's slack-variable bridge")
+                # a variable more than once in one cone (moi_proxsdp_unit.jl double_sdp_with_duplicates): what MOI's bridges do --
+                # VectorFunctionize + VectorSlack: fresh variables y in the cone and the rows f(x) - y = 0 in Zeros
+                y = self.add_variables(len(v))
+                first = len(self._zeros)
+                for xi, yi in zip(v, y):
+                    self._zeros.append(({xi: 1.0, yi: -1.0}, 0.0))
+                self._slack_rows = getattr(self, "_slack_rows", []) + list(range(first, first + len(v)))
+                v = y
             if isinstance(s, PositiveSemidefiniteConeTriangle):
                 if len(v) != sympackedlen(s.side_dimension):
                     raise ValueError("dimension mismatch")

@@ -1,5 +1,5 @@
 """The reference's own MOI tests, restated call by call through proxsdp_jl_amd.moi (MathOptInterface's vocabulary on this
-side of the C ABI): /root/reference/test/moi_proxsdp_unit.jl (all eight models + the eig-solver settings),
+side of the C ABI): /root/reference/test/moi_proxsdp_unit.jl (all eight models, incl. the duplicated-variable one through the slack bridge, + the eig-solver settings),
 test/moi_sensorloc.jl (both forms: vector and scalar constraints; n = 5, 10 as moitest.jl:147-153), test/moi_mimo.jl, test/test_terminationstatus.jl,
 test/moitest.jl:22-30,156-170 (solver name, unsupported argument, time limit attribute).
 
@@ -174,13 +174,24 @@ def test_double_sdp_from_moi(backend):
     assert np.allclose(m.variable_primal(Y), np.ones(3), atol=1e-2)
 
 
-def test_double_sdp_with_duplicates_is_declined():
-    """moi_proxsdp_unit.jl:273-300 puts ONE variable three times into a cone; MOI answers with a bridge (slack variables
-    and equalities) that this layer does not restate -- it says so instead of assembling a wrong model."""
-    m = make("oracle")
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_double_sdp_with_duplicates(backend):
+    """moi_proxsdp_unit.jl:273-300: ONE variable three times in a 2 x 2 cone, X = [x, x, x]: MOI's bridges add slack variables
+    in the cone and the rows x - y_i = 0; min X1 + X3 with X2 = 1 -> 2, x = 1."""
+    m = make(backend)
     x = m.add_variable()
-    with pytest.raises(NotImplementedError):
-        m.add_constraint(VOV([x, x, x]), moi.PositiveSemidefiniteConeTriangle(2))
+    X = [x, x, x]
+    m.add_constraint(VOV(X), moi.PositiveSemidefiniteConeTriangle(2))
+    m.add_constraint(vaf1(1.0, X[1], -1.0), moi.Zeros(1))
+    m.set_objective_function(SAF([SAT(1.0, X[0]), SAT(1.0, X[2])], 0.0))
+    m.set_objective_sense(moi.MIN_SENSE)
+    pr = m.problem()
+    assert pr.n == 4 and pr.p == 4 and [list(v) for v in pr.psd] == [[1, 2, 3]]
+    m.optimize()
+    assert m.termination_status() == "OPTIMAL"
+    assert m.primal_status() == "FEASIBLE_POINT" and m.dual_status() == "FEASIBLE_POINT"
+    assert abs(m.objective_value() - 2) <= 1e-2
+    assert np.allclose(m.variable_primal(X), np.ones(3), atol=1e-2)
 
 
 def build_sdp_wiki(m):
