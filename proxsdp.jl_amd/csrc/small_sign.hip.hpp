@@ -125,7 +125,8 @@ k_small_sign_project(double* __restrict__ x, const long long* __restrict__ offs,
     if (!(f2 > 0.0)) {                                       // the zero matrix (or non-finite input: left alone)
         if (f2 == 0.0) for (int t = tid; t < N; t += SS_TPB) xp[t] = 0.0;
         if (tid == 0) {
-            rank_out[blockIdx.x] = 0; npos_out[blockIdx.x] = 0;
+            const int rk = (f2 == 0.0) ? 0 : -1;             // -1: non-finite input -- the host raises the error the tiled path raises
+            rank_out[blockIdx.x] = rk; npos_out[blockIdx.x] = rk;
             if (short_stats != nullptr && j0 > 0) atomicAdd(short_stats, 1);     // (the first PDHG iterate is exactly zero: counted as resolved)
         }
         return;
