@@ -1383,7 +1383,7 @@ def test_sensorloc_benchmark_family_takes_the_oracles_iterations(n):
 @pytest.mark.parametrize("n", [150, 200, 300])
 def test_sensorloc_larger_sizes_take_the_committed_oracle_counts(n, golden_dir):
     """SENSORLOC at sizes where the oracle takes minutes to an hour (tests/golden/sensorloc_oracle.json, made by
-    tests/golden/make_golden_sensorloc.py): OPTIMAL after the oracle's iteration count, with the oracle's Lanczos mat-vec total."""
+    tests/golden/make_golden_sensorloc.py): OPTIMAL after the oracle's iteration count, with the oracle's Lanczos mat-vec total where it was recorded."""
     gold = json.loads((golden_dir / "sensorloc_oracle.json").read_text())
     if str(n) not in gold:
         pytest.skip("no committed oracle solve at this size")
@@ -1391,7 +1391,8 @@ def test_sensorloc_larger_sizes_take_the_committed_oracle_counts(n, golden_dir):
     sol = Optimizer().optimize(P.sensorloc(n, seed=0))
     print("sensorloc", n, sol.status, sol.iter, sol.stats["lanczos_matvecs"], "oracle", g)
     assert sol.status == g["status"] == 1 and sol.iter == g["iterations"]
-    assert sol.stats["lanczos_matvecs"] == g["lanczos_matvecs"]
+    if "lanczos_matvecs" in g:
+        assert sol.stats["lanczos_matvecs"] == g["lanczos_matvecs"]
 
 
 @pytest.mark.parametrize("n", [2, 3, 7, 16, 31, 50, 64])
