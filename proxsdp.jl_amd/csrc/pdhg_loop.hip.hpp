@@ -475,6 +475,12 @@ inline void Solver::psd_projection(double* x) {
 inline void Solver::project_small_blocks(double* x) {
     harvest_small_ranks();
     const int nb = (int)small_blocks.size();
+    // ranks, positive counts and the schedule-test outcomes [nb each] go STRAIGHT into pinned host memory (no copy launch)
+    // (small models only, as the scalars of the linesearch: zero_copy_small; otherwise through the device buffer and one copy)
+    const bool zc = zero_copy_small();
+    int* rk_host = zc ? reinterpret_cast<int*>(small_rank_host.p) : small_rank.p;
+    if (zc) for (int q = 0; q < nb; ++q) rk_host[2 * nb + q] = 0;          // (the previous launch's values were harvested above)
+    else PX_HIP(hipMemsetAsync(small_rank.p + 2 * nb, 0, (size_t)nb * sizeof(int), stream));
     bool any_jacobi = false;
     int jac_maxn = 0;
     for (int idx : small_blocks) if (P.blocks[idx].n <= small_jacobi_max) { any_jacobi = true; jac_maxn = std::max(jac_maxn, P.blocks[idx].n); }
@@ -482,7 +488,7 @@ inline void Solver::project_small_blocks(double* x) {
         const int ld = jac_maxn | 1;
         const size_t lds = ((size_t)2 * jac_maxn * ld + 64) * sizeof(double) + 64 * sizeof(int);
         hipLaunchKernelGGL(dev::k_small_psd_project, dim3(nb), dim3(dev::TPB), lds, stream,
-                           x, (const long long*)small_off.p, (const int*)small_side.p, opt.tol_psd, small_rank.p, small_rank.p + nb,
+                           x, (const long long*)small_off.p, (const int*)small_side.p, opt.tol_psd, rk_host, rk_host + nb,
                            2, small_jacobi_max);
     }
     if (small_sign_maxn > 0) {
@@ -495,11 +501,11 @@ inline void Solver::project_small_blocks(double* x) {
         for (int k = 0; k < dev::SIGN_STEPS; ++k) if (sched.l[k] <= 1e-10 * sched.gain[j0]) rfail = k;
         hipLaunchKernelGGL(dev::k_small_sign_project, dim3(nb), dim3(dev::SS_TPB), dev::small_sign_lds_bytes(small_sign_maxn), stream,
                            x, (const long long*)small_off.p, (const int*)small_side.p, small_jacobi_max + 1, dev::SS_MAXN,
-                           small_rank.p, small_rank.p + nb, j0, rfail, j0 > 0 ? small_rank.p + 2 * nb : (int*)nullptr);
+                           rk_host, rk_host + nb, j0, rfail, j0 > 0 ? rk_host + 2 * nb : (int*)nullptr);
         st.full_eigs_sign += nb; st.sign_products += 57LL * nb;      // (counted per block below for the Jacobi ones)
         for (int idx : small_blocks) if (P.blocks[idx].n <= small_jacobi_max) { st.full_eigs_sign--; st.sign_products -= 57; }
     }
-    PX_HIP(hipMemcpyAsync(small_rank_host.p, small_rank.p, ((size_t)2 * nb + 2) * sizeof(int), hipMemcpyDeviceToHost, stream));
+    if (!zc) PX_HIP(hipMemcpyAsync(small_rank_host.p, small_rank.p, (size_t)3 * nb * sizeof(int), hipMemcpyDeviceToHost, stream));
     small_pending = true;
     st.full_eigs += nb; st.batched_small_eigs += nb;
     for (int idx : small_blocks) { current_rank[idx] = 0; min_eig[idx] = 0.0; }
@@ -514,9 +520,8 @@ inline void Solver::harvest_small_ranks() {
         current_rank[small_blocks[q]] = r[q];
     }
     // the shortened schedule's tests made inside k_small_sign_project (cumulative counters behind the ranks)
-    const int* cnt = r + 2 * small_blocks.size();
-    st.sign_short_pass += cnt[0] - small_short_seen[0]; st.sign_short_fail += cnt[1] - small_short_seen[1];
-    small_short_seen[0] = cnt[0]; small_short_seen[1] = cnt[1];
+    const int* flag = r + 2 * small_blocks.size();            // per block: 1 = test passed, 2 = failed (fall-back rows ran), 0 = no test
+    for (size_t q = 0; q < small_blocks.size(); ++q) { st.sign_short_pass += flag[q] == 1; st.sign_short_fail += flag[q] == 2; }
 }
 
 // primal_step! (pdhg.jl:611-637)
@@ -1244,6 +1249,9 @@ inline int Solver::linesearch_residual_support() {
         // per candidate: q0,q1 sums | q2,q3 max, q4 sum | q5..q8 max, q9,q10 sum
         unsigned long long ismax = 0;
         for (int c = 0; c < nc; ++c) ismax |= 0x1ECull << (11 * c);      // bits 2,3,5,6,7,8
+        // (measured, tools/_ab in round 5: letting this kernel write its scalars straight into pinned host memory -- as the small-model
+        // path does -- costs the rank-63 iteration 3 %: a kernel that stores to host memory ends with a system-scope release, and
+        // behind the reconstruction that means writing 64 MB of dirty L2 lines back first)
         hipLaunchKernelGGL(dev::k_combine_multi, dim3(nc * 11 + 2), dim3(dev::TPB), 0, stream,
                            (const double*)bpart.p, PSTRIDE, std::max(gq, gs), ismax, bscal.p, nc * 11,
                            (const double*)respart_d.p, rstride, n_res_wg, bscal.p + NC * 11);
@@ -1352,10 +1360,12 @@ inline int Solver::linesearch_residual_general() {
     auto read_back = [&](int nc) {
         unsigned long long ismax = 0;
         for (int c = 0; c < nc; ++c) ismax |= 0x1ECull << (11 * c);      // bits 2,3,5,6,7,8 of every candidate
+        // small models: the scalars go STRAIGHT into pinned host memory (no copy launch: 6 us of a 60 us iteration); larger ones keep
+        // the copy (a kernel that stores to host memory ends with a system-scope release of everything the iteration left dirty)
         hipLaunchKernelGGL(dev::k_combine_multi, dim3(nc * 11), dim3(dev::TPB), 0, stream,
-                           (const double*)bpart.p, PSTRIDE, std::max(gq, gx), ismax, bscal.p, nc * 11,
+                           (const double*)bpart.p, PSTRIDE, std::max(gq, gx), ismax, zero_copy_small() ? hscal_pin.p : bscal.p, nc * 11,
                            (const double*)nullptr, 0, 0, (double*)nullptr);
-        PX_HIP(hipMemcpyAsync(hscal_pin.p, bscal.p, NC * 11 * sizeof(double), hipMemcpyDeviceToHost, stream));
+        if (!zero_copy_small()) PX_HIP(hipMemcpyAsync(hscal_pin.p, bscal.p, NC * 11 * sizeof(double), hipMemcpyDeviceToHost, stream));
         wait_stream();
         std::copy(hscal_pin.p, hscal_pin.p + NC * 11, hbscal.begin());
     };
@@ -1721,9 +1731,9 @@ inline void Solver::run() {
         if (!small_blocks.empty()) {
             std::vector<long long> so; std::vector<int> ss;
             for (int idx : small_blocks) { so.push_back(P.blocks[idx].off); ss.push_back(P.blocks[idx].n); small_maxn = std::max(small_maxn, P.blocks[idx].n); }
-            small_off.alloc(so.size()); small_side.alloc(ss.size()); small_rank.alloc(2 * ss.size() + 2); small_rank.zero(stream);   // [rank | npos] per block, then the sign kernel's cumulative [pass, fail] counters
+            small_off.alloc(so.size()); small_side.alloc(ss.size()); small_rank.alloc(3 * ss.size() + 2); small_rank.zero(stream);   // [rank | npos] per block, then the sign kernel's cumulative [pass, fail] counters
             small_off.upload(so.data(), so.size(), stream); small_side.upload(ss.data(), ss.size(), stream);
-            small_rank_host.alloc(ss.size() + 2);
+            small_rank_host.alloc(2 * ss.size() + 2);      // (ints: rank | positive count | schedule-test outcome per block)
             small_sign_maxn = 0;
             int jac_maxn = 0;
             for (int sd : ss) { if (sd > small_jacobi_max) small_sign_maxn = std::max(small_sign_maxn, sd); else jac_maxn = std::max(jac_maxn, sd); }

@@ -89,7 +89,7 @@ __device__ __forceinline__ double ss_fro2(const double* __restrict__ M, int np, 
 __global__ void __launch_bounds__(SS_TPB)
 k_small_sign_project(double* __restrict__ x, const long long* __restrict__ offs, const int* __restrict__ sides,
                      int nmin, int nmax, int* __restrict__ rank_out, int* __restrict__ npos_out, int j0, int r_fail,
-                     int* __restrict__ short_stats /* [pass, fail] counters, or null */) {
+                     int* __restrict__ short_stats /* per block: 1 = schedule test passed, 2 = failed; or null */) {
     extern __shared__ __attribute__((aligned(16))) double ss_mem[];
     __shared__ double s_red[SS_TPB / 64];
     __shared__ double s_sc[4];
@@ -127,7 +127,7 @@ k_small_sign_project(double* __restrict__ x, const long long* __restrict__ offs,
         if (tid == 0) {
             const int rk = (f2 == 0.0) ? 0 : -1;             // -1: non-finite input -- the host raises the error the tiled path raises
             rank_out[blockIdx.x] = rk; npos_out[blockIdx.x] = rk;
-            if (short_stats != nullptr && j0 > 0) atomicAdd(short_stats, 1);     // (the first PDHG iterate is exactly zero: counted as resolved)
+            if (short_stats != nullptr && j0 > 0) short_stats[blockIdx.x] = 1;     // (the first PDHG iterate is exactly zero: counted as resolved)
         }
         return;
     }
@@ -170,7 +170,7 @@ k_small_sign_project(double* __restrict__ x, const long long* __restrict__ offs,
         __syncthreads();
         const double m4 = ss_fro2(Y, np, ld, s_red, &s_sc[3]);
         const bool ok = (fro2 == fro2) && (m4 == m4) && fabs(fro2 - m4) <= 4e-13 * (double)n;
-        if (tid == 0 && short_stats != nullptr) atomicAdd(short_stats + (ok ? 0 : 1), 1);
+        if (tid == 0 && short_stats != nullptr) short_stats[blockIdx.x] = ok ? 1 : 2;
         if (!ok) {                                           // (uniform over the workgroup)
             run_rows(r_fail, false);
             fro2 = ss_fro2(X, np, ld, s_red, &s_sc[2]);

@@ -538,7 +538,9 @@ private:
     int small_maxn = 0;
     int small_jacobi_max = 64;                 // small blocks up to this side: batched Jacobi; above: k_small_sign_project
     int small_sign_maxn = 0;                   // largest side served by k_small_sign_project (0: none)
-    int small_short_seen[2] = {0, 0};          // its cumulative [pass, fail] test counters as of the last harvest
+    // per-iteration read-backs written by the kernels straight into pinned host memory: only where the iteration leaves little
+    // dirty data behind (a kernel that stores to host memory ends with a system-scope release)
+    bool zero_copy_small() const { return P.n <= (1 << 16); }
     bool small_pending = false;
     void project_small_blocks(double* x);
     void harvest_small_ranks();
