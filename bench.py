@@ -587,7 +587,7 @@ def step_roofline(st, n, N, rank, krylovdim, mv_step, ms_step):
             if krylovdim > 64:
                 traffic = rec["bytes_per_step_K_gt_64"]
                 tnote = ("bytes behind the L2s per step pair (k_fop_finish<1,2> + k_lz_orth<2,1>), 2*FETCH_SIZE + WRITE_SIZE: "
-                         "profiles/r04_pmc_traffic.md <- " + rec["source"])
+                         + rec.get("file", "profiles/r04_pmc_traffic.md") + " <- " + rec["source"])
         except (OSError, KeyError, ValueError):
             tnote = "no PMC record for the step kernels at n=%d under profiles/ (profiles/r04_pmc_traffic.md has n = 2000 and 4000)" % n
     return {"bound": "latency" if fop else "hbm", "kernel": kern, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
