@@ -15,6 +15,8 @@ the rest into (with_bridge_type = Float64, as the tests instantiate it):
     ScalarAffineFunction-in-LessThan(u)    VectorizeBridge:  f - u in Nonpositives(1)
     ScalarAffineFunction-in-GreaterThan(l) Vectorize + NonnegToNonpos:  -f + l in Nonpositives(1)
     VectorAffineFunction-in-Nonnegatives   NonnegToNonpos:  -f in Nonpositives
+    VectorOfVariables-in-{Zeros, Nonpositives, Nonnegatives}   VectorFunctionize: the identity as an affine function
+    VectorAffineFunction-in-{SecondOrderCone, PositiveSemidefiniteConeTriangle}   VectorSlack: y in the cone, f(x) - y in Zeros
     VariableIndex-in-{EqualTo, LessThan, GreaterThan}   as the scalar affine function 1.0 x
 
 Variable indices are 1-based integers (`VariableIndex.value`).  Rows keep the order in which the
@@ -204,9 +206,23 @@ class Model:
                 for k in range(d):
                     self._nonpos.append((self._row(rows[k], sign), sign * float(f.constants[k])))
                 return ConstraintIndex("nonpos", first + 1, tuple(range(first, first + d)), sign)
+            if isinstance(s, (PositiveSemidefiniteConeTriangle, SecondOrderCone)):
+                # VectorSlackBridge: fresh variables y in the cone and the rows f(x) - y = 0 in Zeros
+                y = self.add_variables(d)
+                first = len(self._zeros)
+                for k in range(d):
+                    r = self._row(rows[k])
+                    r[y[k]] = r.get(y[k], 0.0) - 1.0
+                    self._zeros.append((r, float(f.constants[k])))
+                self._slack_rows = getattr(self, "_slack_rows", []) + list(range(first, first + d))
+                return self.add_constraint(VectorOfVariables(y), s)
             raise TypeError(f"unsupported vector set {type(s).__name__}")
         if isinstance(f, VectorOfVariables):
             v = [int(x) for x in f.variables]
+            if isinstance(s, (Zeros, Nonpositives, Nonnegatives)):
+                # VectorFunctionizeBridge: the identity as a VectorAffineFunction
+                return self.add_constraint(VectorAffineFunction([VectorAffineTerm(k + 1, ScalarAffineTerm(1.0, x)) for k, x in enumerate(v)],
+                                                                [0.0] * len(v)), s)
             if len(set(v)) != len(v):
                 # a variable more than once in one cone (moi_proxsdp_unit.jl double_sdp_with_duplicates): what MOI's bridges do --
                 # VectorFunctionize + VectorSlack: fresh variables y in the cone and the rows f(x) - y = 0 in Zeros
