@@ -712,14 +712,21 @@ def bench_sdplib(args, torch, dist, rank, world, dev_id, backend):
         out = {"instance": fname, "n": n, "value": K / t, "unit": "iterations/s", "ms_per_step": 1e3 * t / K,
                "full_eigs": int(st["full_eigs"]), "positive_eigenvalues_last": int(sol.final_rank)}
         if st["full_eigs_sign"] > 0:
-            # executed MFMA flops of one projection: products on 32 x 32 tiles of the block upper triangle
+            # executed MFMA flops of one projection: products on 32 x 32 or 48 x 48 tiles of the block upper triangle
             # (side <= 3072; 64 x 64 above and for the final product), K = the padded side
             ld = 64 * ((n + 63) // 64)
             nprod = st["sign_products"] / st["full_eigs_sign"]
-            t32, t64 = ld // 32, ld // 64
+            t32, t64, t48 = ld // 32, ld // 64, (n + 47) // 48
             f32 = (t32 * (t32 + 1) // 2) * 2.0 * 32 * 32 * ld
             f64_ = (t64 * (t64 + 1) // 2) * 2.0 * 64 * 64 * ld
-            flops = (nprod - 1) * (f32 if ld <= 3072 else f64_) + f64_
+            f48 = (t48 * (t48 + 1) // 2) * 2.0 * 48 * 48 * ld
+            # the library's tile rule (Solver::full_eig_by_sign): 48 x 48 tiles where they shorten the busiest CU's queue
+            knob = int(os.environ.get("PROXSDP_HIP_SIGN_TILE48", "-1"))
+            c32 = -(-(t32 * (t32 + 1) // 2) // 256) * 1024
+            c48 = -(-(t48 * (t48 + 1) // 2) // 256) * 2304
+            use48 = ld <= 3072 and knob != 0 and 48 * t48 <= ld and (knob == 1 or c48 <= c32)
+            tiles = "k_sym_gemm48" if use48 else ("k_sym_gemm32" if ld <= 3072 else "k_sym_gemm")
+            flops = (nprod - 1) * (f48 if use48 else f32 if ld <= 3072 else f64_) + f64_
             ach = flops / (eig_ms * 1e-3) / 1e12 if eig_ms > 0 else None
             out.update({"projection": "matrix sign function, fp64 MFMA products (full_eig_sign auto)",
                         "projection_ms_per_step": eig_ms, "products_per_projection": nprod,
@@ -727,7 +734,8 @@ def bench_sdplib(args, torch, dist, rank, world, dev_id, backend):
                         "avg_product_launch_ms": eig_ms / nprod if nprod else None,
                         "projection_share": eig_ms / (1e3 * t / K),
                         "dsyevd_equivalent_TFLOPs": (10.0 / 3.0) * n ** 3 / (eig_ms * 1e-3) / 1e12 if eig_ms > 0 else None,
-                        "roofline": {"bound": "mfma", "kernel": "k_sym_gemm32 / k_sym_gemm (v_mfma_f64_16x16x4_f64): "
+                        "product_tiles": tiles,
+                        "roofline": {"bound": "mfma", "kernel": tiles + " + the final k_sym_gemm (v_mfma_f64_16x16x4_f64): "
                                      "executed MFMA flops of the %d products of one projection / event time of the "
                                      "whole projection (incl. unpack and scalar kernels)" % round(nprod),
                                      "achieved": ach, "peak": 78.6, "unit": "TFLOP/s",

@@ -233,6 +233,7 @@ struct EigWork {
     int sg_row = -1, sg_ok = 16, sg_idle = 0, sg_hold = 0;   // shortened schedule of the sign iteration (full_eig_by_sign)
     hipEvent_t sg_ev = nullptr;
     bool sg_small = false;                         // products on 32 x 32 tiles (blocks up to side 3072)
+    int sg_nt48 = 0;                               // > 0: products on 48 x 48 tiles, this many per side (chosen by makespan)
     bool sg_pending = false;                       // fe[] hold a sign projection's events (all of it is "solver")
     // cost-based engine choice on the Krylov branch (psd_sign_engine): wall-clock averages of this block's
     // Lanczos and sign projections, projections since the last Lanczos probe, scratch for in-place calls
@@ -359,6 +360,7 @@ public:
     bool cycle_plan(const EigWork& W, int krylovdim, int& R, int& G, bool& f_in_lds) const;
     void launch_cycle(EigWork& W, int kfirst, int krylovdim, double tol, int R, int G, bool f_in_lds);
     int cycle_lds_cap = 0;                        // dynamic LDS granted to k_lz_cycle (setup_device)
+    bool sg48_ok = false;                         // 72 KiB of dynamic LDS granted to k_sym_gemm48 (setup_device)
     DevBuf<long long> cy_dbg;                     // PROXSDP_HIP_DEBUG_CYCLE: per-phase tick sums
     void launch_symv(EigWork& W, const double* xp, const double* v, bool use_ctl);
     void launch_symv_finish(EigWork& W, const double* xp, int kclose, double tol, bool use_carry);
@@ -708,6 +710,11 @@ inline void Solver::setup_device() {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kb * 1024) == hipSuccess) { rotate_mfma_lds_cap = kb * 1024; break; }
         (void)hipGetLastError();
     }
+    sg48_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_sym_gemm48<dev::SG_PLAIN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev::SG48_LDS_BYTES) == hipSuccess &&
+              hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_sym_gemm48<dev::SG_POLY>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev::SG48_LDS_BYTES) == hipSuccess;
+    if (!sg48_ok) (void)hipGetLastError();
     if (std::getenv("PROXSDP_HIP_DEBUG_CYCLE") != nullptr) { cy_dbg.alloc(16); cy_dbg.zero(stream); }
     cycle_lds_cap = 0;
     for (int kb : {160, 156, 152, 144, 128, 96, 64}) {
@@ -1824,6 +1831,12 @@ inline void Solver::sym_gemm(EigWork& W, const double* Pm, const double* Qm, dou
                              const double* xp_old, int blk) {
     W.lst.sign_products++;
     if constexpr (EPI != dev::SG_FINAL) {
+        if (W.sg_nt48 > 0) {                                // 48 x 48 tiles: fewer, larger tiles where that shortens the busiest CU's queue
+            const int grid48 = 8 * ceil_div(W.sg_nt48 * (W.sg_nt48 + 1) / 2, 8);
+            hipLaunchKernelGGL((dev::k_sym_gemm48<EPI>), dim3(grid48), dim3(dev::TPB), dev::SG48_LDS_BYTES, stream, Pm, Qm, W.sg_ld,
+                               W.sg_nt48, T, Y, ca, cb, cc, dsc, part);
+            return;
+        }
         if (W.sg_small) {                                   // 32 x 32 tiles: small blocks need the workgroups
             const int nt32 = 2 * W.nt;
             const int grid32 = 8 * ceil_div(nt32 * (nt32 + 1) / 2, 8);
@@ -1880,6 +1893,28 @@ inline bool Solver::full_eig_by_sign(int idx, const double* xp_in, double* xp_ou
         W.sg_small = ld <= small_max;
         const int nt32 = 2 * W.nt;
         W.sg_npart = W.sg_small ? 8 * ceil_div(nt32 * (nt32 + 1) / 2, 8) : grid;
+        // tile shape by makespan: the busiest of the 256 CUs runs ceil(tiles / 256) tiles of T x T entries each.  n = 1000: 528 tiles of
+        // 32 x 32 (3 x 1024) against 231 of 48 x 48 (1 x 2304); n = 800: 325 (2 x 1024) against 153 (2304) -- the 32-tiles stay.  Measured
+        // (tools/gpurun_tile48_sizes.sh, ms per projection 32 / 48): 700: 0.44 / 0.44, 800: 0.77 / 0.83, 1000: 1.21 / 1.00, 1200: 1.57 / 2.0,
+        // 1500: 2.9 / ~3.6, 2000 (a tie of the rule): 6.6 / 6.4, 2500: 12.9 / 13.2 -- the rule picks the faster one each time.
+        // PROXSDP_HIP_SIGN_TILE48 = 0 / 1: never / whenever the tiles fit (measurement)
+        W.sg_nt48 = 0;
+        {
+            const int nb48 = ceil_div(n, dev::SG_T48);
+            const char* env = std::getenv("PROXSDP_HIP_SIGN_TILE48");
+            const int knob = env != nullptr ? std::atoi(env) : -1;
+            if (W.sg_small && sg48_ok && knob != 0 && nb48 * dev::SG_T48 <= ld) {
+                const int cus = 256;
+                const long long c32 = (long long)ceil_div(nt32 * (nt32 + 1) / 2, cus) * 32 * 32;
+                const long long c48 = (long long)ceil_div(nb48 * (nb48 + 1) / 2, cus) * 48 * 48;
+                if (knob == 1 || c48 <= c32) {
+                    W.sg_nt48 = nb48;
+                    W.sg_npart = 8 * ceil_div(nb48 * (nb48 + 1) / 2, 8);
+                    // rows / columns [48 nb48, ld) are never written by these tiles and are read by every product's K loop
+                    W.sgX.zero(stream); W.sgX2.zero(stream); W.sgY.zero(stream); W.sgQ.zero(stream);
+                }
+            }
+        }
         W.sg_part.alloc(W.sg_npart); W.sg_part2.alloc(W.sg_npart); W.sg_sc.alloc(16); W.sg_host.alloc(16);
         W.sg_sc.zero(stream);
         W.sg_ld = ld;

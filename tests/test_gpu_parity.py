@@ -1749,13 +1749,14 @@ def _spectrum_cases(n, rng):
     return lam
 
 
-@pytest.mark.parametrize("n", [33, 64, 100, 257, 501, 1000])
+@pytest.mark.parametrize("n", [33, 64, 100, 257, 501, 1000, 1001, 1430])
 def test_sign_function_projection_against_lapack(n):
     """full_eig! by the matrix sign function (sign_project.hip.hpp; psd_project mode 4): X+ = (X + X sign X)/2
     from fp64 MFMA products (34 .. 64, see the shortened-schedule test below), no eigenpairs.  Against LAPACK's projection: every |eigenvalue| >= 1e-10 ||X||
     is resolved, smaller ones cost at most their own size; the count of positive eigenvalues comes from
     tr S and tr S^2.  Cases: generic, low-rank positive part, a 25 % null space, repeated eigenvalues with
-    tiny ones next to zero, definite matrices, the zero matrix; sides that are not multiples of 32 / 64."""
+    tiny ones next to zero, definite matrices, the zero matrix; sides that are not multiples of 32 / 64; 1000 / 1001 / 1430:
+    the products run on 48 x 48 tiles (k_sym_gemm48, chosen by makespan)."""
     rng = np.random.default_rng(n)
     Qm, _ = np.linalg.qr(rng.standard_normal((n, n)))
     for name, lam in _spectrum_cases(n, rng).items():
@@ -1774,6 +1775,25 @@ def test_sign_function_projection_against_lapack(n):
             assert info["rank"] == int((lam > 1e-7).sum()), name       # the exact null space counts as zero
         dense, _ = B.psd_project(svec(X), n, 1, mode=1)
         assert np.abs(out - dense).max() / sc <= 1e-9
+
+
+@pytest.mark.parametrize("n", [1000, 1430, 2000])
+def test_sign_projection_tile_shapes_agree(n, monkeypatch):
+    """The product kernels on 32 x 32 and on 48 x 48 tiles (PROXSDP_HIP_SIGN_TILE48 = 0 / 1; auto = by makespan: 48 at these
+    sides) are the same iteration with another grouping of the K sums: projections agree to rounding, same positive count."""
+    rng = np.random.default_rng(7 * n)
+    M = rng.standard_normal((n, n)); X = (M + M.T) / 2
+    outs = []
+    for knob in ("0", "1", None):
+        if knob is None:
+            monkeypatch.delenv("PROXSDP_HIP_SIGN_TILE48", raising=False)
+        else:
+            monkeypatch.setenv("PROXSDP_HIP_SIGN_TILE48", knob)
+        out, info = B.psd_project(svec(X), n, 1, mode=4)
+        outs.append((out, info["rank"]))
+    sc = np.abs(np.linalg.eigvalsh(X)).max()
+    assert np.abs(outs[0][0] - outs[1][0]).max() <= 1e-12 * sc and outs[0][1] == outs[1][1]
+    assert np.array_equal(outs[1][0], outs[2][0])                  # auto picks the 48-tiles here
 
 
 @pytest.mark.parametrize("n", [100, 501, 1000])
