@@ -1912,6 +1912,9 @@ inline bool Solver::full_eig_by_sign(int idx, const double* xp_in, double* xp_ou
                     W.sg_npart = 8 * ceil_div(nb48 * (nb48 + 1) / 2, 8);
                     // rows / columns [48 nb48, ld) are never written by these tiles and are read by every product's K loop
                     W.sgX.zero(stream); W.sgX2.zero(stream); W.sgY.zero(stream); W.sgQ.zero(stream);
+                    // (measured and dropped: walking the tiles in S x S patches per XCD instead of column-major ranges -- half the
+                    // operand blocks per XCD's L2 -- changes nothing, 0.95 - 0.98 ms per projection either way: the Infinity Cache
+                    // serves the misses under the 24 loads in flight; eight k-steps per group instead of four: slower, 1.01 ms)
                 }
             }
         }
