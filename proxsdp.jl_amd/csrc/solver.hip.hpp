@@ -1840,14 +1840,8 @@ inline void Solver::sym_gemm(EigWork& W, const double* Pm, const double* Qm, dou
         if (W.sg_small) {                                   // 32 x 32 tiles: small blocks need the workgroups
             const int nt32 = 2 * W.nt;
             const int grid32 = 8 * ceil_div(nt32 * (nt32 + 1) / 2, 8);
-            // at most one workgroup per CU and a K range that splits into steps of 32: the deeper operand pipeline
-            static const bool deep_ok = std::getenv("PROXSDP_HIP_SIGN_DEEP") == nullptr || std::atoi(std::getenv("PROXSDP_HIP_SIGN_DEEP")) != 0;
-            if (deep_ok && nt32 * (nt32 + 1) / 2 <= 256 && W.sg_ld % 128 == 0)
-                hipLaunchKernelGGL((dev::k_sym_gemm32<EPI, 8>), dim3(grid32), dim3(dev::TPB), 0, stream, Pm, Qm, W.sg_ld, nt32, T, Y,
-                                   ca, cb, cc, dsc, part);
-            else
-                hipLaunchKernelGGL((dev::k_sym_gemm32<EPI, 4>), dim3(grid32), dim3(dev::TPB), 0, stream, Pm, Qm, W.sg_ld, nt32, T, Y,
-                                   ca, cb, cc, dsc, part);
+            hipLaunchKernelGGL((dev::k_sym_gemm32<EPI>), dim3(grid32), dim3(dev::TPB), 0, stream, Pm, Qm, W.sg_ld, nt32, T, Y,
+                               ca, cb, cc, dsc, part);
             return;
         }
     }
