@@ -17,6 +17,7 @@ the rest into (with_bridge_type = Float64, as the tests instantiate it):
     VectorAffineFunction-in-Nonnegatives   NonnegToNonpos:  -f in Nonpositives
     VectorOfVariables-in-{Zeros, Nonpositives, Nonnegatives}   VectorFunctionize: the identity as an affine function
     VectorAffineFunction-in-{SecondOrderCone, PositiveSemidefiniteConeTriangle}   VectorSlack: y in the cone, f(x) - y in Zeros
+    {VectorOfVariables, VectorAffineFunction}-in-RotatedSecondOrderCone   RSOCtoSOC: ((t + u) / sqrt 2, (t - u) / sqrt 2, x) in SecondOrderCone
     VariableIndex-in-{EqualTo, LessThan, GreaterThan}   as the scalar affine function 1.0 x
 
 Variable indices are 1-based integers (`VariableIndex.value`).  Rows keep the order in which the
@@ -106,6 +107,11 @@ class SecondOrderCone:
     dimension: int
 
 
+@dataclass
+class RotatedSecondOrderCone:
+    dimension: int                 # (t, u, x): 2 t u >= |x|^2, t, u >= 0
+
+
 @dataclass(frozen=True)
 class ConstraintIndex:
     kind: str        # "zeros" | "nonpos" | "psd" | "soc"  (the native set the rows live in)
@@ -177,6 +183,28 @@ class Model:
     def add_constraint(self, f, s):
         if isinstance(f, (int, np.integer)):                       # VariableIndex
             f = ScalarAffineFunction([ScalarAffineTerm(1.0, int(f))], 0.0)
+        if isinstance(s, RotatedSecondOrderCone):
+            # RSOCtoSOCBridge: (t, u, x) in RSOC  <=>  ((t + u) / sqrt 2, (t - u) / sqrt 2, x) in SOC (the map is its own inverse);
+            # the constraint index returned is the SOC constraint's: primal / dual values come back in ITS coordinates
+            if isinstance(f, VectorOfVariables):
+                f = VectorAffineFunction([VectorAffineTerm(k + 1, ScalarAffineTerm(1.0, int(x))) for k, x in enumerate(f.variables)],
+                                         [0.0] * len(f.variables))
+            d = len(f.constants)
+            if d != s.dimension or d < 2:
+                raise ValueError("dimension mismatch")
+            r = 1.0 / np.sqrt(2.0)
+            terms = []
+            for t in f.terms:
+                c, v = float(t.scalar_term.coefficient), t.scalar_term.variable
+                if t.output_index == 1:
+                    terms += [VectorAffineTerm(1, ScalarAffineTerm(r * c, v)), VectorAffineTerm(2, ScalarAffineTerm(r * c, v))]
+                elif t.output_index == 2:
+                    terms += [VectorAffineTerm(1, ScalarAffineTerm(r * c, v)), VectorAffineTerm(2, ScalarAffineTerm(-r * c, v))]
+                else:
+                    terms.append(t)
+            k = [float(x) for x in f.constants]
+            consts = [r * (k[0] + k[1]), r * (k[0] - k[1])] + k[2:]
+            return self.add_constraint(VectorAffineFunction(terms, consts), SecondOrderCone(d))
         if isinstance(f, ScalarAffineFunction):
             if isinstance(s, EqualTo):
                 self._zeros.append((self._row(f.terms), f.constant - s.value))

@@ -186,6 +186,29 @@ def test_conic_SecondOrderCone_out_of_order(backend):
     assert close(m.constraint_dual(c1), [-r5, -2, -1]) and close(m.constraint_dual(c2), [r5, -2, -1])
 
 
+# ------------------------------------------------------------------ rotated SOC
+@pytest.mark.parametrize("form", ["VectorOfVariables", "VectorAffineFunction"])
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_conic_RotatedSecondOrderCone(backend, form):
+    """SOCRotated1: min -x - y, a = 1/2, b = 1, 2 a b >= x^2 + y^2 (through the RSOC-to-SOC bridge and the slack bridge, as the
+    reference gets it from MathOptInterface).  Optimum -sqrt 2 at x = y = 1/sqrt 2."""
+    m = make(backend)
+    a, b, x, y = m.add_variables(4)
+    m.add_constraint(VAF([VAT(1, SAT(1.0, a))], [-0.5]), moi.Zeros(1))
+    m.add_constraint(VAF([VAT(1, SAT(1.0, b))], [-1.0]), moi.Zeros(1))
+    c = m.add_constraint(VOV([a, b, x, y]) if form == "VectorOfVariables" else identity_vaf([a, b, x, y]), moi.RotatedSecondOrderCone(4))
+    m.set_objective_function(SAF([SAT(0.0, a), SAT(0.0, b), SAT(-1.0, x), SAT(-1.0, y)], 0.0))
+    m.set_objective_sense(moi.MIN_SENSE)
+    m.optimize()
+    r2 = np.sqrt(2.0)
+    assert m.termination_status() == "OPTIMAL"
+    assert close(m.objective_value(), -r2) and close(m.dual_objective_value(), -r2)
+    assert close(m.variable_primal([a, b, x, y]), [0.5, 1.0, 1 / r2, 1 / r2])
+    # the bridged constraint's value in the SOC's coordinates: ((a + b) / sqrt 2, (a - b) / sqrt 2, x, y), on the cone's boundary
+    v = m.constraint_primal(c)
+    assert close(v, [1.5 / r2, -0.5 / r2, 1 / r2, 1 / r2]) and abs(v[0] - np.linalg.norm(v[1:])) <= 1e-3
+
+
 # ------------------------------------------------------------------ SDP0, SDP1
 @pytest.mark.parametrize("form", ["VectorOfVariables", "VectorAffineFunction"])
 @pytest.mark.parametrize("backend", BACKENDS)
