@@ -710,10 +710,9 @@ inline void Solver::setup_device() {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kb * 1024) == hipSuccess) { rotate_mfma_lds_cap = kb * 1024; break; }
         (void)hipGetLastError();
     }
-    sg48_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_sym_gemm48<dev::SG_PLAIN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev::SG48_LDS_BYTES) == hipSuccess &&
-              hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_sym_gemm48<dev::SG_POLY>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev::SG48_LDS_BYTES) == hipSuccess;
+    sg48_ok = true;
+    for (const void* f : {reinterpret_cast<const void*>(dev::k_sym_gemm48<dev::SG_PLAIN, 4>), reinterpret_cast<const void*>(dev::k_sym_gemm48<dev::SG_POLY, 4>)})
+        sg48_ok = sg48_ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev::sg48_lds_bytes(4)) == hipSuccess;
     if (!sg48_ok) (void)hipGetLastError();
     if (std::getenv("PROXSDP_HIP_DEBUG_CYCLE") != nullptr) { cy_dbg.alloc(16); cy_dbg.zero(stream); }
     cycle_lds_cap = 0;
@@ -1833,7 +1832,7 @@ inline void Solver::sym_gemm(EigWork& W, const double* Pm, const double* Qm, dou
     if constexpr (EPI != dev::SG_FINAL) {
         if (W.sg_nt48 > 0) {                                // 48 x 48 tiles: fewer, larger tiles where that shortens the busiest CU's queue
             const int grid48 = 8 * ceil_div(W.sg_nt48 * (W.sg_nt48 + 1) / 2, 8);
-            hipLaunchKernelGGL((dev::k_sym_gemm48<EPI>), dim3(grid48), dim3(dev::TPB), dev::SG48_LDS_BYTES, stream, Pm, Qm, W.sg_ld,
+            hipLaunchKernelGGL((dev::k_sym_gemm48<EPI, 4>), dim3(grid48), dim3(dev::TPB), dev::sg48_lds_bytes(4), stream, Pm, Qm, W.sg_ld,
                                W.sg_nt48, T, Y, ca, cb, cc, dsc, part);
             return;
         }
