@@ -114,7 +114,7 @@ def main():
                     help="library-only: equal-side PSD blocks in one launch per Lanczos step (-1 auto, 0 off = stream per block)")
     ap.add_argument("--block-threads", dest="block_threads", type=int, default=None)
     ap.add_argument("--block-batch-groups", dest="block_batch_groups", type=int, default=None,
-                    help="library-only: concurrent groups of the batched multi-block Lanczos (-1 auto = 2, 1 = one group)")
+                    help="library-only: concurrent groups of the batched multi-block Lanczos (-1 auto = 1 = one group after the other, k >= 2 = k groups side by side)")
     ap.add_argument("--host-eig-merge", dest="host_eig_merge", type=int, default=None,
                     help="library-only: K x K Rayleigh-quotient eigensolves by split + rank-one merge (-1 auto, 0 = implicit QL)")
     ap.add_argument("--rand-n", type=int, default=2000)

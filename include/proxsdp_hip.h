@@ -348,7 +348,8 @@ typedef struct proxsdp_options {
                                   * Lanczos-served full_eig! -- were measured out before they got an option: DESIGN.md section 9) */
     int32_t block_batch_groups;  /* batched multi-block Lanczos (block_batch): equal-side blocks are split into this many groups that
                                   * run CONCURRENTLY (own stream + host thread each): one group's restart logic on the host overlaps
-                                  * the other groups' cycles on the GPU.  -1 auto = 1 = one group (rounds 3-4 behaviour), k >= 2 = k
+                                  * the other groups' cycles on the GPU.  -1 auto = 1 = groups run ONE AFTER THE OTHER (rounds 3-4 behaviour; also when more than 8 equal-side
+                                  * blocks force several groups), k >= 2 = k
                                   * groups (from 4 blocks on, when the block worker pool is up: block_threads != 0).  Per block
                                   * nothing changes.  MEASURED NEGATIVE on MIMO 8 x 513 (same session: 313 / 303 / 217 it/s with
                                   * 1 / 2 / 4 groups): a cycle is bound by its chain of dependent launches on the GPU (135 us of

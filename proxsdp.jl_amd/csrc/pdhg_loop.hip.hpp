@@ -130,7 +130,10 @@ inline void Solver::project_blocks(const std::vector<int>& blocks, const double*
         for (size_t q = have; q < groups.size(); ++q) batch_ctx[q].reset(new BatchCtx());
     }
     for (const std::vector<int>& g : groups) for (int idx : g) current_rank[idx] = 0;
-    bool leaders_have_streams = parallel_blocks && groups.size() >= 2;
+    // (groups run side by side only ON REQUEST -- block_batch_groups >= 2; a model with more than LZB_MAX equal-side
+    // blocks splits into several groups by necessity, and those run one after the other as in rounds 3-4: auto = sequential)
+    const int want_groups = opt.block_batch_groups < 0 ? 1 : (int)opt.block_batch_groups;
+    bool leaders_have_streams = parallel_blocks && groups.size() >= 2 && want_groups >= 2;
     for (const std::vector<int>& g : groups) leaders_have_streams = leaders_have_streams && eig[g[0]].stream != nullptr;
     if (leaders_have_streams) {
         std::vector<int> leaders;

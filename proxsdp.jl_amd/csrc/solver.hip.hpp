@@ -32,6 +32,7 @@
 #include "host_util.hpp"
 #include "kernels.hip.hpp"
 #include "lanczos_cycle.hip.hpp"
+#include "lanczos_block1.hip.hpp"
 #include "small_sign.hip.hpp"
 #include "sign_project.hip.hpp"
 #include "rccl_dl.hpp"
@@ -360,6 +361,9 @@ public:
     bool cycle_plan(const EigWork& W, int krylovdim, int& R, int& G, bool& f_in_lds) const;
     void launch_cycle(EigWork& W, int kfirst, int krylovdim, double tol, int R, int G, bool f_in_lds);
     int cycle_lds_cap = 0;                        // dynamic LDS granted to k_lz_cycle (setup_device)
+    int block1_lds_cap = 0;                       // dynamic LDS granted to k_lz_block1 (setup_device)
+    bool block1_plan(const EigWork& W, int krylovdim, bool split_wanted) const;
+    void launch_block1(EigWork& W, const double* xp, int kfirst, int krylovdim, double tol);
     bool sg48_ok = false;                         // 72 KiB of dynamic LDS granted to k_sym_gemm48 (setup_device)
     DevBuf<long long> cy_dbg;                     // PROXSDP_HIP_DEBUG_CYCLE: per-phase tick sums
     void launch_symv(EigWork& W, const double* xp, const double* v, bool use_ctl);
@@ -726,8 +730,56 @@ inline void Solver::setup_device() {
         }
         (void)hipGetLastError();
     }
+    block1_lds_cap = 0;
+    for (int kb : {160, 144, 128, 112, 96}) {
+        bool ok = true;
+        for (const void* f : {reinterpret_cast<const void*>(dev::k_lz_block1<1, false>), reinterpret_cast<const void*>(dev::k_lz_block1<2, false>),
+                              reinterpret_cast<const void*>(dev::k_lz_block1<1, true>), reinterpret_cast<const void*>(dev::k_lz_block1<2, true>)})
+            ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kb * 1024) == hipSuccess;
+        if (ok) { block1_lds_cap = kb * 1024; break; }
+        (void)hipGetLastError();
+    }
     PX_ROC(rocblas_create_handle(&blas));
     PX_ROC(rocblas_set_stream(blas, stream));
+}
+
+// one-workgroup cycle kernel for medium blocks (lanczos_block1.hip.hpp): the step kernels' arithmetic bit for bit, one launch
+// per Lanczos cycle.  lanczos_cycle_kernel: 2 = on, -1 (auto) = on where it applies, 0 / 1 = off.
+inline bool Solver::block1_plan(const EigWork& W, int krylovdim, bool split_wanted) const {
+    if (!(opt.lanczos_cycle_kernel == 2 || opt.lanczos_cycle_kernel < 0) || block1_lds_cap == 0) return false;
+    if (W.nt > dev::B1_MAXNT || krylovdim > dev::B1_KMAX || split_wanted) return false;
+    if (W.use_fop && (W.F_r > 4 * dev::B1_NPV || W.ov.wr_ptr != nullptr || W.ell_w < 1)) return false;
+    const dev::B1Lds L = dev::b1_lds_plan(W.nt, W.npad, W.use_fop);
+    return (size_t)L.total * sizeof(double) <= (size_t)block1_lds_cap;
+}
+
+inline void Solver::launch_block1(EigWork& W, const double* xp, int kfirst, int krylovdim, double tol) {
+    dev::Block1Args a{};
+    a.xp = xp; a.n = W.n; a.nt = W.nt; a.npad = W.npad;
+    a.V = W.V.p; a.ldv = W.npad; a.kfirst = kfirst; a.kd = krylovdim; a.tol = tol;
+    if (W.use_fop) {
+        a.Vp = W.F.p + (size_t)W.F_first * W.npad; a.lam = W.Flam.p; a.rp = W.F_r;
+        a.ell_col = W.ell_col.p; a.ell_sidx = W.ell_sidx.p; a.ell_w = W.ell_w; a.esv = W.esv;
+    }
+    a.arrow = W.arrow_p;
+    a.alphas = W.alphas_p; a.betas = W.betas_p; a.ctl = W.ctl_p;
+    const dev::B1Lds L = dev::b1_lds_plan(W.nt, W.npad, W.use_fop);
+    const size_t lds = (size_t)L.total * sizeof(double);
+    const bool two = W.nt > dev::B1_NV;
+    auto kern = W.use_fop ? (two ? dev::k_lz_block1<2, true> : dev::k_lz_block1<1, true>)
+                          : (two ? dev::k_lz_block1<2, false> : dev::k_lz_block1<1, false>);
+    const bool prof = opt.profile_symv_every > 0;
+    if (prof) {
+        if (W.cye[0] == nullptr) { PX_HIP(hipEventCreate(&W.cye[0])); PX_HIP(hipEventCreate(&W.cye[1])); }
+        hipExtLaunchKernelGGL(kern, dim3(1), dim3(dev::B1_TPB), lds, stream, W.cye[0], W.cye[1], 0, a);
+        W.cye_pending = true;
+    } else {
+        hipLaunchKernelGGL(kern, dim3(1), dim3(dev::B1_TPB), lds, stream, a);
+    }
+    W.lst.cycle_launches++;
+    W.lst.cycle_steps += krylovdim - kfirst;
+    W.lst.symv_launches += krylovdim - kfirst;
+    W.lst.symv_bytes += (double)(krylovdim - kfirst) * (8.0 * (double)W.N + 16.0 * (double)W.n);
 }
 
 // persistent cycle kernel: rows per workgroup, grid and whether the previous factors fit in LDS
@@ -1521,7 +1573,10 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive
     // split + rank-one merge of the K x K eigensolve (options.host_eig_merge): not for the dsaupd rule (its
     // wanted set is re-ordered afterwards) and not under the persistent cycle kernel
     const int merge_from = opt.host_eig_merge == 0 ? (1 << 30) : (opt.host_eig_merge == 1 ? 24 : 64);
-    const bool use_split = !cyc && !R.arpack && krylovdim >= merge_from;
+    // one-workgroup cycle kernel (medium blocks): where the split eigensolve would want a mid-cycle read-back the step
+    // kernels stay in charge, so that either engine hands the host the same work
+    const bool blk1 = !cyc && block1_plan(W, krylovdim, !R.arpack && krylovdim >= merge_from);
+    const bool use_split = !cyc && !blk1 && !R.arpack && krylovdim >= merge_from;
     struct PoolGuard { SpinPool* p; ~PoolGuard() { if (p) p->disarm(); } } pool_guard{nullptr};
     W.split.M.par = nullptr;
     if (use_split && merge_helpers() > 0 && StreamRef::tl == nullptr) {      // (not from a block worker thread: one pool per solver)
@@ -1551,6 +1606,9 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive
         if (cyc) {
             launch_cycle(W, kfirst, krylovdim, step_tol, cyR, cyG, cyF);
             PX_HIP(hipMemcpyAsync(W.cy_err_host.p, W.cy_err.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+        } else if (blk1) {
+            launch_block1(W, xp, kfirst, krylovdim, step_tol);
+            R.presymv = false;
         } else {
         for (int k = kfirst; k < krylovdim; ++k) {
             lz_launch_step(W, xp, k, kfirst, step_tol, R.presymv);
@@ -1571,7 +1629,7 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive
         // final now: enqueue it before the host round trip so the GPU works during the K x K
         // eigensolve (wasted only when this cycle turns out to be the last one)
         // -- speculated only when this block's previous projection needed a restart too
-        const bool speculate = !cyc && (W.prev_numiter > 1 || R.numiter > 1);
+        const bool speculate = !cyc && !blk1 && (W.prev_numiter > 1 || R.numiter > 1);
         if (speculate) {
             launch_symv(W, xp, W.V.p + (size_t)krylovdim * W.npad, true);
             W.lst.symv_launches--; W.lst.symv_bytes -= 8.0 * (double)W.N + 16.0 * (double)W.n;   // counted when used

@@ -1325,7 +1325,7 @@ def test_small_block_sign_projection_against_lapack(n):
 
 def test_small_models_take_the_one_launch_projections_and_follow_the_oracle():
     """Models whose PSD blocks never take the Krylov path (side <= min_size_krylov_eigs): one launch per iteration for
-    all of them -- Jacobi up to side 8, the LDS-resident sign projection from 9 to 64 (auto) -- against the oracle's
+    all of them -- Jacobi at side 2, the LDS-resident sign projection for sides 3 .. 64 (auto) -- against the oracle's
     LAPACK full_eig!: same iteration counts and traces on a 22 x 22 sensor-localisation-shaped block (MIMO 21),
     Max-Cut 60 and a mixed model; and the same solves with the batch switched off (rocSOLVER / tiled sign)."""
     import oracle
@@ -1444,6 +1444,29 @@ def test_persistent_cycle_kernel_matches_the_step_kernels(n, maxrank, rank0):
     assert a.stats["lanczos_restarts"] == b.stats["lanczos_restarts"]
     for col in (1, 2, 7):
         assert np.allclose(a.trace[:, col], b.trace[:, col], rtol=1e-9, atol=1e-12), col
+
+
+@pytest.mark.parametrize("name", ["maxcut150", "maxcut300", "maxcut500", "sensorloc100", "sensorloc200", "mcp124-1", "mcp250-1", "gpp124-2"])
+def test_block_cycle_kernel_reproduces_the_step_kernels_bit_for_bit(name, golden_dir):
+    """Round 6: blocks of side <= 512 run a whole Lanczos cycle in ONE launch of ONE workgroup (lanczos_block1.hip.hpp;
+    lanczos_cycle_kernel = 2, and auto where it applies) -- the step kernels' arithmetic term by term, with LDS and registers
+    in place of the global records and a workgroup barrier in place of a kernel boundary.  Both operators (packed triangle:
+    sensor localisation / gpp, operator form: Max-Cut / mcp), one and two row groups per virtual workgroup, with thick
+    restarts: the traces are EQUAL, bit for bit, and so are the mat-vec and restart counts."""
+    pr = {"maxcut150": lambda: P.maxcut(150, seed=2), "maxcut300": lambda: P.maxcut(300, seed=3), "maxcut500": lambda: P.maxcut(500, seed=4),
+          "sensorloc100": lambda: P.sensorloc(100, seed=0), "sensorloc200": lambda: P.sensorloc(200, seed=0),
+          "mcp124-1": lambda: P.sdplib(golden_dir / "sdplib" / "mcp124-1.dat-s"), "mcp250-1": lambda: P.sdplib(golden_dir / "sdplib" / "mcp250-1.dat-s"),
+          "gpp124-2": lambda: P.sdplib(golden_dir / "sdplib" / "gpp124-2.dat-s")}[name]()
+    kw = dict(max_iter=400)
+    a = Optimizer(lanczos_cycle_kernel=0, **kw).optimize(pr, trace_capacity=400)
+    b = Optimizer(lanczos_cycle_kernel=2, **kw).optimize(pr, trace_capacity=400)
+    c = Optimizer(**kw).optimize(pr, trace_capacity=400)                           # auto
+    assert a.stats["cycle_launches"] == 0 and b.stats["cycle_launches"] > 300 and c.stats["cycle_launches"] == b.stats["cycle_launches"]
+    assert b.stats["cycle_steps"] == b.stats["symv_launches"] >= b.stats["lanczos_matvecs"] > 0
+    assert a.iter == b.iter == c.iter and a.status == b.status == c.status
+    assert a.stats["lanczos_matvecs"] == b.stats["lanczos_matvecs"] and a.stats["lanczos_restarts"] == b.stats["lanczos_restarts"] > 0
+    assert np.array_equal(a.trace, b.trace) and np.array_equal(a.trace, c.trace), np.abs(a.trace - b.trace).max(axis=0)
+    assert np.array_equal(a.primal, b.primal) and np.array_equal(a.dual_eq, b.dual_eq)
 
 
 def test_warm_start_knob_reaches_the_same_optimum_with_fewer_restarts():
