@@ -1778,6 +1778,111 @@ k_dual_trial(const double* __restrict__ y, const double* __restrict__ Mx, const 
 // no-linesearch variant (dual_step!, pdhg.jl:584-609): ybar = y + sigma(2Mx - Mx_old)
 // is the same kernel with theta = 1, bt = sigma.
 
+// ---- long columns of M (round 6).  The transposed products below give every column to ONE thread, which walks its entries
+// with two dependent memory round trips per entry (row index, then y[row]): ~250 ns per entry.  Sensor localisation has three
+// columns -- the entries of the identity block, present in every anchor constraint -- with thousands of entries: ONE launch of
+// k_spmvT_S_batch took 2.07 ms, 88 % of the GPU time of the reference's SENSORLOC benchmark family (profiles/r06a_kernel_stats_
+// sensorloc400.md).  Columns longer than LONGCOL entries are now summed by a whole wave: the products val[k] * y[row[k]] of 64
+// entries are formed in parallel (FP contraction is off here: the product is rounded on its own in the scalar loop too) and
+// ADDED IN THE SCALAR LOOP'S ORDER by a serial chain over the lanes -- the same bits, ~7 ns per entry instead of ~250.
+constexpr int LONGCOL = 192;         // entries from which a column goes to a wave
+constexpr int LC_CAP = 64;           // long columns one workgroup can take per launch (the rest stay with their threads)
+constexpr int LC_GROUP = 4 * WAVE;   // entries a wave stages per round (four per lane)
+struct LongCols { int n; int key[LC_CAP]; double acc[LC_CAP]; double stage[NWAVE][LC_GROUP]; };
+// One wave, one column: rounds of 256 entries.  Row indices / values are loaded two rounds ahead, the y gathers one round
+// ahead (both stay in flight under the additions of the current round), the products go through the wave's LDS stage and
+// are read back as BROADCAST loads, 16 at a time, for a chain of dependent additions in the scalar loop's order.
+__device__ __forceinline__ double wave_col_dot_inorder(const int* __restrict__ row, const double* __restrict__ val,
+                                                       const double* __restrict__ y, int k0, int k1, int lane,
+                                                       double* __restrict__ stage) {
+    double acc = 0.0;
+    int rA[4]; double vA[4];                 // round r + 2: row, val
+    double vB[4], yB[4];                     // round r + 1: val, y[row]
+    double pC[4];                            // round r: products
+    auto loadA = [&](int kb) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = min(kb + u * WAVE + lane, k1 - 1);
+            rA[u] = row[k]; vA[u] = val[k];
+        }
+    };
+    auto gatherB = [&]() {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { vB[u] = vA[u]; yB[u] = y[rA[u]]; }
+    };
+    auto mulC = [&]() {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pC[u] = vB[u] * yB[u];
+    };
+    loadA(k0); gatherB();
+    if (k0 + LC_GROUP < k1) loadA(k0 + LC_GROUP);
+    for (int kb = k0; kb < k1; kb += LC_GROUP) {
+        mulC();                                                   // products of this round (its gathers were issued a round ago)
+        if (kb + LC_GROUP < k1) gatherB();                        // next round's gathers
+        if (kb + 2 * LC_GROUP < k1) loadA(kb + 2 * LC_GROUP);     // row / val of the round after
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) stage[u * WAVE + lane] = pC[u];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const int cnt = min(LC_GROUP, k1 - kb);
+        int e = 0;
+        for (; e + 16 <= cnt; e += 16) {
+            double q[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) q[t] = stage[e + t];     // the same address in every lane: LDS broadcast
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc = acc + q[t];
+        }
+        for (; e < cnt; ++e) acc = acc + stage[e];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    return acc;
+}
+// the workgroup's long columns, summed by its waves; colof(s) = column of loop index s.  Must be called by every thread.
+template <class ColOf>
+__device__ __forceinline__ void long_cols_collect(LongCols& L, const int* __restrict__ colptr, const int* __restrict__ row,
+                                                  const double* __restrict__ val, const double* __restrict__ y,
+                                                  long long first, long long stride, long long count, ColOf colof) {
+    if (threadIdx.x == 0) L.n = 0;
+    __syncthreads();
+    for (long long s = first; s < count; s += stride) {
+        const int col = colof(s);
+        if (colptr[col + 1] - colptr[col] > LONGCOL) {
+            const int at = atomicAdd(&L.n, 1);
+            if (at < LC_CAP) L.key[at] = col;
+        }
+    }
+    __syncthreads();
+    const int n = min(L.n, LC_CAP);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int q = wv; q < n; q += NWAVE) {
+        const int col = L.key[q];
+        const double a = wave_col_dot_inorder(row, val, y, colptr[col], colptr[col + 1], lane, L.stage[wv]);
+        if (lane == 0) L.acc[q] = a;
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ double col_dot(const LongCols& L, int col, const int* __restrict__ colptr, const int* __restrict__ row,
+                                          const double* __restrict__ val, const double* __restrict__ y) {
+    const int k0 = colptr[col], k1 = colptr[col + 1];
+    if (k1 - k0 > LONGCOL) {
+        const int n = min(L.n, LC_CAP);
+        for (int q = 0; q < n; ++q) if (L.key[q] == col) return L.acc[q];
+    }
+    // (four entries' loads in flight at a time; the additions keep the scalar loop's order)
+    double acc = 0.0;
+    int k = k0;
+    for (; k + 4 <= k1; k += 4) {
+        const int r0 = row[k], r1 = row[k + 1], r2 = row[k + 2], r3 = row[k + 3];
+        const double v0 = val[k], v1 = val[k + 1], v2 = val[k + 2], v3 = val[k + 3];
+        const double y0 = y[r0], y1 = y[r1], y2 = y[r2], y3 = y[r3];
+        acc += v0 * y0; acc += v1 * y1; acc += v2 * y2; acc += v3 * y3;
+    }
+    for (; k < k1; ++k) acc += val[k] * y[row[k]];
+    return acc;
+}
+
 // Mty = M' y (M in CSC: one dot per column) fused with |Mty - Mty_old|^2
 // pdhg.jl:556-563.  Thread per column; columns are mostly empty or short.
 __global__ void __launch_bounds__(TPB)
@@ -1785,13 +1890,13 @@ k_spmv_csc_norm(const int* __restrict__ colptr, const int* __restrict__ row, con
                 const double* __restrict__ y, double* __restrict__ Mty, const double* __restrict__ Mty_old,
                 long long ncols, double* __restrict__ part, int addback) {
     __shared__ double sm[NWAVE];
+    __shared__ LongCols lc;
     double ss = 0.0;
     long long j = (long long)blockIdx.x * TPB + threadIdx.x;
     const long long stride = (long long)gridDim.x * TPB;
+    long_cols_collect(lc, colptr, row, val, y, j, stride, ncols, [](long long s) { return (int)s; });
     for (; j < ncols; j += stride) {
-        double acc = 0.0;
-        const int k0 = colptr[j], k1 = colptr[j + 1];
-        for (int k = k0; k < k1; ++k) acc += val[k] * y[row[k]];
+        const double acc = col_dot(lc, (int)j, colptr, row, val, y);
         const double o = Mty_old[j];
         const double d = acc - o;
         Mty[j] = addback ? d + o : acc;       // pdhg.jl:560,574 (a.Mty .-= a.Mty_old ... a.Mty .+= a.Mty_old)
@@ -1931,14 +2036,16 @@ k_spmvT_S_batch(const int* __restrict__ colptr, const int* __restrict__ row, con
                 double* __restrict__ MtyScand, long long mstride, const double* __restrict__ MtyS_old,
                 double* __restrict__ part, long long cstride) {
     __shared__ double sm[NWAVE];
+    __shared__ LongCols lc;
     const int c = blockIdx.y;
     const double* y = ycand + (long long)c * ystride;
     double* out = MtyScand + (long long)c * mstride;
     double ss = 0.0;
+    long_cols_collect(lc, colptr, row, val, y, (long long)blockIdx.x * TPB + threadIdx.x, (long long)gridDim.x * TPB, (long long)ns,
+                      [supp](long long s) { return supp[s]; });
     for (int s = blockIdx.x * TPB + threadIdx.x; s < ns; s += gridDim.x * TPB) {
         const int col = supp[s];
-        double acc = 0.0;
-        for (int k = colptr[col]; k < colptr[col + 1]; ++k) acc += val[k] * y[row[k]];
+        const double acc = col_dot(lc, col, colptr, row, val, y);
         const double o = MtyS_old[s];
         const double d = acc - o;
         out[s] = d + o;                        // pdhg.jl:560,574
@@ -2039,13 +2146,13 @@ k_spmv_csc_norm_batch(const int* __restrict__ colptr, const int* __restrict__ ro
     const int c = blockIdx.y;
     const double* y = ycand + (long long)c * ystride;
     double* out = Mtycand + (long long)c * mstride;
+    __shared__ LongCols lc;
     double ss = 0.0;
     long long j = (long long)blockIdx.x * TPB + threadIdx.x;
     const long long stride = (long long)gridDim.x * TPB;
+    long_cols_collect(lc, colptr, row, val, y, j, stride, ncols, [](long long s) { return (int)s; });
     for (; j < ncols; j += stride) {
-        double acc = 0.0;
-        const int k0 = colptr[j], k1 = colptr[j + 1];
-        for (int k = k0; k < k1; ++k) acc += val[k] * y[row[k]];
+        const double acc = col_dot(lc, (int)j, colptr, row, val, y);
         const double o = Mty_old[j];
         const double d = acc - o;
         out[j] = d + o;                        // pdhg.jl:560,574

@@ -2053,6 +2053,14 @@ inline void Solver::run() {
         std::fprintf(stderr, "[proxsdp] single-block Lanczos: %.0f cycles; per cycle: wait for the GPU %.1f us | after-cycle host logic (eigensolve, "
                      "convergence, restart rotation staging) %.1f us; per projection: results (Ritz coefficients + rotation staging) %.1f us\n",
                      dbg_lz[5], 1e6 * dbg_lz[0] / dbg_lz[5], 1e6 * dbg_lz[1] / dbg_lz[5], 1e6 * dbg_lz[3] / std::max(1.0, (double)st.lanczos_calls));
+    if (b1_dbg.p != nullptr) {
+        long long t[8] = {0};
+        b1_dbg.download(t, 8, stream);
+        PX_HIP(hipStreamSynchronize(stream));
+        if (t[4] > 0)
+            std::fprintf(stderr, "[proxsdp] k_lz_block1: %lld launches, %lld steps; per launch: prologue %.2f us | step loop %.2f us (%.2f us per step) | "
+                         "epilogue %.2f us\n", t[4], t[3], 0.01 * t[0] / t[4], 0.01 * t[1] / t[4], 0.01 * t[1] / std::max(1LL, t[3]), 0.01 * t[2] / t[4]);
+    }
     if (debug && dbg_batch[4] > 0)
         std::fprintf(stderr, "[dbg] batched Lanczos: %.0f cycles; per cycle enqueue %.1f us, wait %.1f us, restart logic %.1f us, flush %.1f us\n",
                      dbg_batch[4], 1e6 * dbg_batch[0] / dbg_batch[4], 1e6 * dbg_batch[1] / dbg_batch[4],

@@ -204,6 +204,10 @@ struct EigWork {
     PinnedBuf rec_early;
     SplitEig split;
     int batch_slot = 0;                            // position of this block in the batched run in progress
+    // one-workgroup cycle kernel (lanczos_block1.hip.hpp): the restart rotation is deferred into the next cycle's launch
+    bool b1_defer = false;                         // Solver::rotate stages U and returns (set around lz_after_cycle)
+    int b1_rot_K = 0;                              // > 0: a rotation is pending, U (K x kfirst, compact) at b1_rot_U (pinned staging)
+    const double* b1_rot_U = nullptr;
     LzRun lzrun;                                   // host state of the run in progress (buffers reused across projections)
     long long fel_served = 0;                      // full_eig! calls of this block served by the Lanczos engine
     bool fel_disabled = false;                     // ... switched off after a failed verification (full_eig_lanczos_verify)
@@ -362,6 +366,7 @@ public:
     void launch_cycle(EigWork& W, int kfirst, int krylovdim, double tol, int R, int G, bool f_in_lds);
     int cycle_lds_cap = 0;                        // dynamic LDS granted to k_lz_cycle (setup_device)
     int block1_lds_cap = 0;                       // dynamic LDS granted to k_lz_block1 (setup_device)
+    DevBuf<long long> b1_dbg;                     // PROXSDP_HIP_DEBUG_B1: tick sums of k_lz_block1 (prologue | loop | epilogue | steps | launches)
     bool block1_plan(const EigWork& W, int krylovdim, bool split_wanted) const;
     void launch_block1(EigWork& W, const double* xp, int kfirst, int krylovdim, double tol);
     bool sg48_ok = false;                         // 72 KiB of dynamic LDS granted to k_sym_gemm48 (setup_device)
@@ -730,6 +735,7 @@ inline void Solver::setup_device() {
         }
         (void)hipGetLastError();
     }
+    if (std::getenv("PROXSDP_HIP_DEBUG_B1") != nullptr) { b1_dbg.alloc(8); b1_dbg.zero(stream); }
     block1_lds_cap = 0;
     for (int kb : {160, 144, 128, 112, 96}) {
         bool ok = true;
@@ -747,23 +753,41 @@ inline void Solver::setup_device() {
 // per Lanczos cycle.  lanczos_cycle_kernel: 2 = on, -1 (auto) = on where it applies, 0 / 1 = off.
 inline bool Solver::block1_plan(const EigWork& W, int krylovdim, bool split_wanted) const {
     if (!(opt.lanczos_cycle_kernel == 2 || opt.lanczos_cycle_kernel < 0) || block1_lds_cap == 0) return false;
-    if (W.nt > dev::B1_MAXNT || krylovdim > dev::B1_KMAX || split_wanted) return false;
+    if (W.nt > dev::B1_MAXNT || krylovdim > dev::B1_KMAX || split_wanted || rot_sink != nullptr) return false;
+    // auto: one row group per virtual workgroup (side <= 256).  Measured (profiles/r06_medium_blocks.md): one CU issues ~700
+    // instructions per wave and step for 16 waves -- 4.6-5.3 us per step against the step kernels' ~12 at side <= 192 -- but
+    // with two row groups per wave (side 257 .. 512) it is 8-12 us per step: no gain, so those sides stay with the step kernels
+    if (opt.lanczos_cycle_kernel < 0 && W.nt > dev::B1_NV) return false;
     if (W.use_fop && (W.F_r > 4 * dev::B1_NPV || W.ov.wr_ptr != nullptr || W.ell_w < 1)) return false;
-    const dev::B1Lds L = dev::b1_lds_plan(W.nt, W.npad, W.use_fop);
+    // the packed triangle must be resident in LDS (one CU cannot stream it from L2 once per step fast enough: measured,
+    // profiles/r06_medium_blocks.md); the operator form's E goes there too when it fits, else it is read through L2
+    const dev::B1Lds L = dev::b1_lds_plan(W.nt, W.npad, W.use_fop, W.use_fop ? 0 : W.N, 0);
     return (size_t)L.total * sizeof(double) <= (size_t)block1_lds_cap;
 }
 
 inline void Solver::launch_block1(EigWork& W, const double* xp, int kfirst, int krylovdim, double tol) {
     dev::Block1Args a{};
     a.xp = xp; a.n = W.n; a.nt = W.nt; a.npad = W.npad;
-    a.V = W.V.p; a.ldv = W.npad; a.kfirst = kfirst; a.kd = krylovdim; a.tol = tol;
+    a.ldv = W.npad; a.kfirst = kfirst; a.kd = krylovdim; a.tol = tol;
+    a.Vout = W.V.p;
+    if (W.b1_rot_K > 0) {                        // restart rotation deferred by Solver::rotate: old basis in Z (the pointers were swapped)
+        a.Vin = W.Z.p; a.U = W.b1_rot_U; a.rotK = W.b1_rot_K;
+        W.b1_rot_K = 0;
+    } else {
+        a.Vin = W.V.p; a.U = nullptr; a.rotK = 0;
+    }
+    bool ell_lds = false;
     if (W.use_fop) {
         a.Vp = W.F.p + (size_t)W.F_first * W.npad; a.lam = W.Flam.p; a.rp = W.F_r;
         a.ell_col = W.ell_col.p; a.ell_sidx = W.ell_sidx.p; a.ell_w = W.ell_w; a.esv = W.esv;
+        const dev::B1Lds Le = dev::b1_lds_plan(W.nt, W.npad, true, 0, W.ell_w);
+        ell_lds = (size_t)Le.total * sizeof(double) <= (size_t)block1_lds_cap;
     }
+    a.ell_in_lds = ell_lds ? 1 : 0;
     a.arrow = W.arrow_p;
     a.alphas = W.alphas_p; a.betas = W.betas_p; a.ctl = W.ctl_p;
-    const dev::B1Lds L = dev::b1_lds_plan(W.nt, W.npad, W.use_fop);
+    a.dbg = b1_dbg.p;
+    const dev::B1Lds L = dev::b1_lds_plan(W.nt, W.npad, W.use_fop, W.use_fop ? 0 : W.N, ell_lds ? W.ell_w : 0);
     const size_t lds = (size_t)L.total * sizeof(double);
     const bool two = W.nt > dev::B1_NV;
     auto kern = W.use_fop ? (two ? dev::k_lz_block1<2, true> : dev::k_lz_block1<1, true>)
@@ -1007,6 +1031,12 @@ inline void Solver::rotate(EigWork& W, int K, const std::vector<double>& U, int 
     for (int c = 0; c < ncols; ++c)
         for (int j = 0; j < K; ++j) tmp[(size_t)c * K + j] = U[(size_t)c * ldu + j];
     for (int q = 0; q < nextra; ++q) tmp[(size_t)K * ncols + q] = extra[q];
+    if (W.b1_defer && nextra > 0 && K < 32 && copy_src == K && copy_dst == ncols && out == W.Z.p) {
+        // the next cycle's launch (k_lz_block1) rotates in its prologue, reading U and the arrow part from this pinned buffer
+        W.b1_rot_K = K; W.b1_rot_U = tmp;
+        W.arrow_p = tmp + (size_t)K * ncols;
+        return;
+    }
     W.U.upload(tmp, (size_t)K * ncols + (size_t)std::max(nextra, 0), stream);
     if (nextra > 0) W.arrow_p = W.U.p + (size_t)K * ncols;
     // fp64 MFMA form from K = 32 / 16 columns on (skinny GEMM); grid = row tiles x groups of 16 columns; LDS: V tile + one U group
@@ -1672,7 +1702,9 @@ inline void Solver::lanczos(EigWork& W, const double* xp, int nev, bool positive
         }
         W.evo.used = 0;
         const double tdbg1 = debug ? now_s() : 0.0;
+        W.b1_defer = blk1;
         const bool go_on = lz_after_cycle(W, R, speculate);
+        W.b1_defer = false;
         if (debug) dbg_lz[1] += now_s() - tdbg1;
         if (!go_on) break;
     }

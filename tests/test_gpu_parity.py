@@ -1461,11 +1461,19 @@ def test_block_cycle_kernel_reproduces_the_step_kernels_bit_for_bit(name, golden
     a = Optimizer(lanczos_cycle_kernel=0, **kw).optimize(pr, trace_capacity=400)
     b = Optimizer(lanczos_cycle_kernel=2, **kw).optimize(pr, trace_capacity=400)
     c = Optimizer(**kw).optimize(pr, trace_capacity=400)                           # auto
-    assert a.stats["cycle_launches"] == 0 and b.stats["cycle_launches"] > 300 and c.stats["cycle_launches"] == b.stats["cycle_launches"]
-    assert b.stats["cycle_steps"] == b.stats["symv_launches"] >= b.stats["lanczos_matvecs"] > 0
+    side = pr.psd_sides()[0]
+    packed_fits = side <= 140                                                      # (the packed triangle must be resident in LDS)
+    fop = name.startswith("maxcut") or name.startswith("mcp")
+    assert a.stats["cycle_launches"] == 0
+    if fop or packed_fits:
+        assert b.stats["cycle_launches"] > 300 and b.stats["cycle_steps"] >= b.stats["symv_launches"] >= b.stats["lanczos_matvecs"] > 0
+        assert c.stats["cycle_launches"] == (b.stats["cycle_launches"] if side <= 256 else 0)     # auto: one row group per virtual workgroup
+    else:
+        assert b.stats["cycle_launches"] == 0 == c.stats["cycle_launches"]
     assert a.iter == b.iter == c.iter and a.status == b.status == c.status
     assert a.stats["lanczos_matvecs"] == b.stats["lanczos_matvecs"] and a.stats["lanczos_restarts"] == b.stats["lanczos_restarts"] > 0
-    assert np.array_equal(a.trace, b.trace) and np.array_equal(a.trace, c.trace), np.abs(a.trace - b.trace).max(axis=0)
+    cols = [c_ for c_ in range(a.trace.shape[1]) if c_ != 12]                         # (column 12 is the wall clock)
+    assert np.array_equal(a.trace[:, cols], b.trace[:, cols]) and np.array_equal(a.trace[:, cols], c.trace[:, cols]), np.abs(a.trace - b.trace).max(axis=0)
     assert np.array_equal(a.primal, b.primal) and np.array_equal(a.dual_eq, b.dual_eq)
 
 
