@@ -409,8 +409,7 @@ def main():
         # default-options solve's own clock over the SAME iterations
         sp_ = os.path.join(ROOT, "tests", "golden", "state_maxcut_n%d_k1000.npz" % n)
         if args.cpu_steady_seconds > 0 and os.path.exists(sp_) and args.seed == 0:
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            from helpers import expand_state, load_compact_state          # fixture container (tests/helpers.py)
+            from proxsdp_jl_amd.state_io import expand_state, load_compact_state      # fixture container
             st0 = expand_state(load_compact_state(sp_))
             k0 = int(st0["iteration"])
             o = oracle.Options()
@@ -482,11 +481,41 @@ def main():
                 out["config_randsdp"] = {"skipped": "needs %.0f GB of free HBM, %.0f GB free" % (need / 1e9, free_b / 1e9)}
         except Exception as e:                                  # a side leg must not take the headline line with it
             out["config_legs_error"] = "%s: %s" % (type(e).__name__, e)
+        try:
+            out["medium_blocks"] = medium_blocks_leg(dev_id)
+        except Exception as e:
+            out["medium_blocks"] = {"error": "%s: %s" % (type(e).__name__, e)}
         out["config_legs_wall_s"] = time.time() - t_legs
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def medium_blocks_leg(dev_id):
+    """PSD sides 101 .. 500 -- the window that holds all but three instances of the reference's own benchmark script
+    (test/runbench.jl): reference default options, microseconds per PDHG iteration.  Round 6: sensor localisation was bound by
+    ONE kernel (M'y on the support: three columns with thousands of entries walked by one thread each), operator-form blocks up to
+    side 256 run a Lanczos cycle in one launch of one workgroup (lanczos_block1.hip.hpp).  Whole runbench: profiles/r06_runbench.md."""
+    from proxsdp_jl_amd import problems
+    from proxsdp_jl_amd.optimizer import Optimizer
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "sdplib")
+    rows = {}
+    for name, pr, iters in (("sensorloc_n200", problems.sensorloc(200, seed=0), 1500), ("sensorloc_n400", problems.sensorloc(400, seed=0), 600),
+                            ("mcp124-1", problems.sdplib(os.path.join(gold, "mcp124-1.dat-s")), 0),
+                            ("mcp250-1", problems.sdplib(os.path.join(gold, "mcp250-1.dat-s")), 0)):
+        kw = dict(max_iter=iters) if iters else {}
+        o = Optimizer(device_id=dev_id, **kw)
+        s = o.optimize(pr)
+        st = s.stats
+        rows[name] = {"psd_side": int(pr.psd_sides()[0]), "iterations": int(s.iter), "status": o.termination_status(),
+                      "us_per_iteration": 1e6 * st["loop_time"] / max(1, int(s.iter)), "matvecs_per_iteration": st["lanczos_matvecs"] / max(1, int(s.iter)),
+                      "restarts_per_iteration": st["lanczos_restarts"] / max(1, int(s.iter)),
+                      "one_workgroup_cycle_launches": int(st["cycle_launches"]), "linesearch_us_per_iteration": 1e6 * st["t_linesearch"] / max(1, int(s.iter)),
+                      "objective": float(s.objval)}
+    rows["round5_us_per_iteration"] = {"sensorloc_n200": 1715, "sensorloc_n400": 3283, "mcp124-1": 368, "mcp250-1": 336,
+                                       "source": "profiles/r05_cycle_medium.md, profiles/r05_runbench.md"}
+    return rows
 
 
 def compact(line):

@@ -102,6 +102,53 @@ def symv_upper(Xdata, v):
     return blas.dsymv(1.0, Xdata, v, lower=0)
 
 
+# Orthogonaliser of the Lanczos recurrence (TEST-ONLY switch).  KrylovKit's `KrylovDefaults.orth` is not the
+# same object across the versions Project.toml admits (0.5.2 - 0.9): modified Gram-Schmidt with a second full pass ("mgs2", the
+# restatement's default), its classical twin ("cgs2"), and the variants with ITERATIVE REFINEMENT that run the second pass
+# only while the norm dropped by more than eta = 1/sqrt(2) in the first ("mgsir", "cgsir"; KrylovKit orthonormal.jl).
+# tools/r06/orth_variants.py runs the committed golden instances under each and tables what moves (profiles/r06_orthogonaliser_variants.md).
+ORTH = "mgs2"
+
+
+def _second_passes(V, K, vnew, w, alpha, beta_in):
+    """Re-orthogonalisation of w against V[:, :K] and vnew after the recurrence's own subtractions.  Returns (w, alpha)."""
+    orth = ORTH
+    if orth == "mgs2":
+        s = 0.0
+        for j in range(K):
+            s = float(V[:, j] @ w)
+            w = w - s * V[:, j]
+        s = float(vnew @ w)
+        w = w - s * vnew
+        return w, alpha + s
+    if orth == "cgs2":
+        h = V[:, :K].T @ w
+        s = float(vnew @ w)
+        w = w - V[:, :K] @ h - s * vnew
+        return w, alpha + s
+    if orth in ("mgsir", "cgsir"):
+        eta = 1.0 / np.sqrt(2.0)
+        ab2 = alpha * alpha + beta_in * beta_in
+        beta = float(np.linalg.norm(w))
+        nold = np.sqrt(ab2 + beta * beta)
+        while np.finfo(float).eps < beta < eta * nold:
+            if orth == "mgsir":
+                for j in range(K):
+                    s = float(V[:, j] @ w)
+                    w = w - s * V[:, j]
+                s = float(vnew @ w)
+                w = w - s * vnew
+            else:
+                h = V[:, :K].T @ w
+                s = float(vnew @ w)
+                w = w - V[:, :K] @ h - s * vnew
+            alpha += s
+            nold = beta
+            beta = float(np.linalg.norm(w))
+        return w, alpha
+    raise ValueError(orth)
+
+
 def krylovkit_eigsolve(matvec, x0, howmany, krylovdim, maxiter, tol, eager=False):
     """KrylovKit.eigsolve(A, x0, howmany, :LR, Lanczos(orth, krylovdim, maxiter,
     tol, eager)) -- restated from the published algorithm (see module header).
@@ -165,14 +212,18 @@ def krylovkit_eigsolve(matvec, x0, howmany, krylovdim, maxiter, tol, eager=False
             coupling_set = False
             w = matvec(vnew)
             numops += 1
-            w = w - V[:, :K] @ T[:K, K]          # beta*v_K, or sum f_j v_j after restart
+            tk = T[:K, K]
+            w = w - V[:, :K] @ tk                # beta*v_K, or sum f_j v_j after restart
             alpha = float(vnew @ w)
             w = w - alpha * vnew
-            s = 0.0
-            for j in range(K + 1):               # second full modified G-S pass
-                s = float(V[:, j] @ w)
-                w = w - s * V[:, j]
-            alpha += s                           # correction along v_{K+1}
+            if ORTH == "mgs2":
+                s = 0.0
+                for j in range(K + 1):           # second full modified G-S pass
+                    s = float(V[:, j] @ w)
+                    w = w - s * V[:, j]
+                alpha += s                       # correction along v_{K+1}
+            else:
+                w, alpha = _second_passes(V, K, vnew, w, alpha, float(np.linalg.norm(tk)))
             T[K, K] = alpha
             beta = float(np.linalg.norm(w))
             r = w

@@ -394,7 +394,9 @@ k_lz_warm_sum(double* __restrict__ V0, const double* __restrict__ F, int ldf, in
     // eigenvalues are the ones the run converges last, so they get the larger share of the start vector
     if (wpow != 0.0 && lam != nullptr) {
         const int c = threadIdx.x;
-        sw[c] = (c < rp && lam[c] > 0.0 && lam[0] > 0.0) ? pow(lam[0] / lam[c], wpow) : 1.0;
+        // (the ratio is capped: a retained Ritz value at 1e-14 of the scale, or a denormal one, must not turn the start vector into
+        // that one near-null direction -- or into NaN after the normalisation)
+        sw[c] = (c < rp && lam[c] > 0.0 && lam[0] > 0.0) ? pow(fmin(lam[0] / lam[c], 1e6), wpow) : 1.0;
         __syncthreads();
     }
     const int i = blockIdx.x * TPB + threadIdx.x;

@@ -1611,8 +1611,8 @@ inline void Solver::run() {
         g_frob = sharded() ? std::sqrt(sums[6]) : P.frob;
         g_conic = maxs[0] > 0.5;
     }
-    if (sharded() && (opt.check_dual_feas || opt.support_path == 0 || !opt.line_search_flag))
-        throw std::domain_error("block-sharded solve: check_dual_feas / dense vector passes / no linesearch not implemented");
+    if (sharded() && (opt.support_path == 0 || !opt.line_search_flag))
+        throw std::domain_error("block-sharded solve: dense vector passes / no linesearch not implemented");
     if (opt.max_iter <= 0) max_iter_local = g_conic ? opt.max_iter_conic : opt.max_iter_lp;
     else max_iter_local = opt.max_iter;
     ada_count = 0;
@@ -1688,7 +1688,7 @@ inline void Solver::run() {
             // single-workgroup Jacobi takes 950 us, at side 50 5.9 ms against
             // 1.1 ms for one rocSOLVER call; two blocks of side 10 and 5: 1.4x faster batched; seven of side 2: 6.4x) and,
             // round 5, the one-workgroup LDS-resident sign projection (small_sign.hip.hpp) for sides 3 .. 64
-            if (opt.small_block_batch != 0 && B.n <= (opt.small_block_batch > 0 || small_sign ? 64 : 32) &&
+            if (opt.small_block_batch != 0 && B.n <= (small_sign ? std::max(small_jacobi_max, std::min(64, small_sign_cap)) : (opt.small_block_batch > 0 ? 64 : 32)) &&
                 B.n <= opt.min_size_krylov_eigs && !sharded())
                 small_blocks.push_back((int)idx);
             else
@@ -1868,6 +1868,11 @@ inline void Solver::run() {
             std::vector<double> cc(P.c_orig);
             if (stop_reason == 6) std::fill(cc.begin(), cc.end(), 0.0);
             dual_feasibility = dual_feas_host(y, cc, nullptr, nullptr, nullptr);
+            if (sharded()) {                             // every shard tests its own columns: the model's value is the largest
+                std::vector<double> sums, maxs = {dual_feasibility};
+                reduce(sums, maxs);
+                dual_feasibility = maxs[0];
+            }
         }
         if (opt.log_verbose && opt.log_freq > 0 && k % opt.log_freq == 0)
             std::printf("|%9lld| %+.4e %+.4e %.2e %.2e %.2e %.2e %4lld %8.2f\n", k, h_pobj.at(k), h_dobj.at(k),

@@ -120,8 +120,17 @@ k_small_sign_project(double* __restrict__ x, const long long* __restrict__ offs,
         A[i * ld + j] = (i == j) ? v : v * INV_SQRT2;
     }
     __syncthreads();
-    const double f2 = ss_fro2(A, np, ld, s_red, &s_sc[0]);
+    double f2 = ss_fro2(A, np, ld, s_red, &s_sc[0]);
     const int N = n * (n + 1) / 2;
+    // a block of denormal-tiny entries (|A|_F^2 below ~1e-250: 1 / f2 would overflow): the projection is positively
+    // homogeneous, so the block is scaled by an exact power of two for the iteration and the result scaled back
+    double unscale = 1.0;
+    if (f2 > 0.0 && f2 < 1e-250) {
+        for (int t = tid; t < np * ld; t += SS_TPB) A[t] *= 0x1p+500;
+        __syncthreads();
+        f2 = ss_fro2(A, np, ld, s_red, &s_sc[0]);
+        unscale = 0x1p-500;
+    }
     if (!(f2 > 0.0)) {                                       // the zero matrix (or non-finite input: left alone)
         if (f2 == 0.0) for (int t = tid; t < N; t += SS_TPB) xp[t] = 0.0;
         if (tid == 0) {
@@ -203,7 +212,7 @@ k_small_sign_project(double* __restrict__ x, const long long* __restrict__ offs,
         for (int reg = 0; reg < 4; ++reg) {
             const int r = 16 * tI + l4 + 4 * reg, c = 16 * tJ + l15;
             if (r <= c && c < n) {
-                const double v = 0.5 * (A[r * ld + c] + acc[reg]);
+                const double v = 0.5 * (A[r * ld + c] + acc[reg]) * unscale;
                 xp[(long long)c * (c + 1) / 2 + r] = (r == c) ? v : v * SQRT2;
             }
         }

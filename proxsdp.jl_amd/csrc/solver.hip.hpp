@@ -549,6 +549,7 @@ private:
     int small_maxn = 0;
     int small_jacobi_max = 64;                 // small blocks up to this side: batched Jacobi; above: k_small_sign_project
     int small_sign_maxn = 0;                   // largest side served by k_small_sign_project (0: none)
+    int small_sign_cap = 0;                    // largest side whose dynamic LDS the device grants (setup_device; 64 on gfx950)
     // per-iteration read-backs written by the kernels straight into pinned host memory: only where the iteration leaves little
     // dirty data behind (a kernel that stores to host memory ends with a system-scope release)
     bool zero_copy_small() const { return P.n <= (1 << 16); }
@@ -731,6 +732,19 @@ inline void Solver::setup_device() {
             hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_lz_cycle<64>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kb * 1024) == hipSuccess) {
             cycle_lds_cap = kb * 1024;
+            break;
+        }
+        (void)hipGetLastError();
+    }
+    // one-launch small-block projection: 4 matrices of side x (side + 2) doubles in LDS (132 KiB at side 64).  Probed here so
+    // that a device / partition that does not grant it sends the larger of those blocks to the tiled engines instead of
+    // failing the solve
+    small_sign_cap = 0;
+    for (int sd : {64, 56, 48, 40, 32, 24, 16}) {
+        const size_t bytes = dev::small_sign_lds_bytes(sd);
+        if (bytes <= 48 * 1024 || hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_small_sign_project),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess) {
+            small_sign_cap = sd;
             break;
         }
         (void)hipGetLastError();

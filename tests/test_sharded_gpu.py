@@ -31,7 +31,7 @@ def _coupled_model():
                      G=sp.vstack([pr.G, g]).tocsc(), h=np.append(pr.h, 0.5), c=pr.c, psd=pr.psd, name="two-maxcut-coupled")
 
 
-def _worker(rank, world, port, q, coupled=False, backend="gloo"):
+def _worker(rank, world, port, q, coupled=False, backend="gloo", extra=None):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     from proxsdp_jl_amd import replicas, sharded
@@ -45,7 +45,7 @@ def _worker(rank, world, port, q, coupled=False, backend="gloo"):
     model = _coupled_model() if coupled else _model()
     comm = sharded.make_native_comm(dist, rank, world, device_id=rank) if native else None
     opt, sol, maps = sharded.solve_sharded(model, dist, rank, world, device_id=rank if backend != "gloo" else 0,
-                                           collective_device=dev, native_comm=comm, max_iter=300)
+                                           collective_device=dev, native_comm=comm, max_iter=300, **(extra or {}))
     if native:
         assert sol.stats["rccl_reductions"] >= sol.iter, "native RCCL path not taken"
         B.rccl_comm_destroy(comm)
@@ -92,6 +92,34 @@ def test_two_shards_reproduce_the_single_process_solve(coupled, backend):
         assert np.allclose(tr[:, :3], ref.trace[:, [1, 2, 7]], rtol=1e-9, atol=1e-12)
         x[vars_] = primal
     assert np.allclose(x, ref.primal, rtol=0, atol=1e-9)
+
+
+def test_two_shards_with_check_dual_feas_stop_where_the_single_process_solve_stops():
+    """Round 6: `check_dual_feas` (pdhg.jl:154-173: the stop rule also asks for dual feasibility, tested every
+    check_dual_feas_freq iterations) inside a block-sharded solve -- every shard tests its own columns and the largest value over
+    the shards is the model's.  Two gloo ranks sharing the GPU against the single-process solve of the coupled model: same stop
+    iteration (later than without the option), same status, objectives and trace."""
+    assert B.device_count() > 0
+    pr = _coupled_model()
+    kw = dict(check_dual_feas=1, check_dual_feas_freq=25, tol_feasibility_dual=1e-3)
+    ref = Optimizer(max_iter=300, support_path=1, **kw).optimize(pr, trace_capacity=300)
+    plain = Optimizer(max_iter=300, support_path=1).optimize(pr)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 300) + 71
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, True, "gloo", kw)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted((q.get(timeout=600) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    print("stop with / without check_dual_feas:", ref.iter, plain.iter, "status", ref.status)
+    for (rank, status, it, obj, dobj, gap, frank, vars_, primal, tr) in out:
+        assert status == ref.status and it == ref.iter
+        assert abs(obj - ref.objval) <= 1e-9 * (1 + abs(ref.objval))
+        assert np.array_equal(tr[:, 3], ref.trace[:len(tr), 11])
+        assert np.allclose(tr[:, :3], ref.trace[:len(tr)][:, [1, 2, 7]], rtol=1e-9, atol=1e-12)
 
 
 def _devptr_worker(port, q):
