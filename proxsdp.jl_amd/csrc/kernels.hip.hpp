@@ -1737,8 +1737,18 @@ k_spmv_csr_thread(const int* __restrict__ rowptr, const int* __restrict__ col, c
     int r = blockIdx.x * TPB + threadIdx.x;
     if (r >= nrows) return;
     if (rowptr[r + 1] - rowptr[r] > long_thresh) return;      // segmented path
+    // (four entries' loads in flight at a time -- a row of a few hundred entries walked one dependent round trip after the
+    // other cost 64 us per launch on theta6; the additions keep the scalar loop's order, FP contraction is off here)
     double acc = 0.0;
-    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) acc += val[k] * x[col[k]];
+    int k = rowptr[r];
+    const int k1 = rowptr[r + 1];
+    for (; k + 4 <= k1; k += 4) {
+        const int c0 = col[k], c1 = col[k + 1], c2 = col[k + 2], c3 = col[k + 3];
+        const double v0 = val[k], v1 = val[k + 1], v2 = val[k + 2], v3 = val[k + 3];
+        const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+        acc += v0 * x0; acc += v1 * x1; acc += v2 * x2; acc += v3 * x3;
+    }
+    for (; k < k1; ++k) acc += val[k] * x[col[k]];
     y[r] = acc;
 }
 __global__ void __launch_bounds__(TPB)
@@ -1829,12 +1839,19 @@ __device__ __forceinline__ double wave_col_dot_inorder(const int* __restrict__ r
         __builtin_amdgcn_wave_barrier();
         const int cnt = min(LC_GROUP, k1 - kb);
         int e = 0;
-        for (; e + 16 <= cnt; e += 16) {
-            double q[16];
+        if (cnt >= 16) {
+            double q[16], qn[16];
 #pragma unroll
-            for (int t = 0; t < 16; ++t) q[t] = stage[e + t];     // the same address in every lane: LDS broadcast
+            for (int t = 0; t < 16; ++t) q[t] = stage[t];         // the same address in every lane: LDS broadcast
+            for (; e + 16 <= cnt; e += 16) {
+                const int en = min(e + 16, LC_GROUP - 16);        // (the next 16 are read while these are added; the last read is a repeat)
 #pragma unroll
-            for (int t = 0; t < 16; ++t) acc = acc + q[t];
+                for (int t = 0; t < 16; ++t) qn[t] = stage[en + t];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) acc = acc + q[t];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) q[t] = qn[t];
+            }
         }
         for (; e < cnt; ++e) acc = acc + stage[e];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
