@@ -23,6 +23,9 @@ for fam, cls in (("gpp", "SDPLIB_gp"), ("mcp", "SDPLIB_mc")):
 jobs += [("MIMO", str(n), (lambda n=n: P.mimo(n, seed=0))) for n in (100, 500, 1000)]
 lines = ["| class | prob_ref | status | iterations | time s | obj | rank | lin_feas | sdp_feas (lambda_min) |", "|---|---|---|---|---|---|---|---|---|"]
 Optimizer(max_iter=5).optimize(P.maxcut(120, seed=0))          # (first-call set-up of the process, outside every row)
+Optimizer(max_iter=5).optimize(P.randsdp(5, 5, seed=7))         # (... incl. rocSOLVER's small-size code objects: the exit path's first dsyevd
+                                                                #  of a block of side 5 took 7.3 s on a fresh box, profiles/r06_runbench.md)
+t_all = time.time()
 for cls, ref, build in jobs:
     pr = build()
     s = Optimizer(time_limit=300.0).optimize(pr)
@@ -35,6 +38,9 @@ for cls, ref, build in jobs:
     line = f"| {cls} | {ref} | {TERMINATION[s.status]} | {s.iter} | {s.time:.2f} | {s.objval:.6g} | {s.final_rank} | {lin:.2e} | {sdp:.2e} |"
     print(line, flush=True)
     lines.append(line)
-out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out", "r05_runbench.md")
+lines.append("")
+lines.append("Sum of the solve times: %.1f s (wall clock of the loop incl. model building: %.1f s)" % (sum(float(l.split("|")[5]) for l in lines[2:-1]), time.time() - t_all))
+print(lines[-1])
+out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out", "r06_runbench.md")
 os.makedirs(os.path.dirname(out), exist_ok=True)
 open(out, "w").write("\n".join(lines) + "\n")

@@ -23,7 +23,7 @@ for name, mk in cases:
         continue
     pr = mk()
     res = {}
-    for knob in (0, 2):
+    for knob in (0, 2, -1):
         s = Optimizer(time_limit=120.0, lanczos_cycle_kernel=knob).optimize(pr, trace_capacity=20000)
         res[knob] = s
         st = s.stats
