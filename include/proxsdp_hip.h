@@ -232,8 +232,15 @@ typedef struct proxsdp_options {
     int32_t lanczos_cycle_kernel;/* 1 = run a whole Lanczos cycle (operator form) in ONE persistent launch whose <= 32
                                   * workgroups sit on one XCD, keep their rows of the basis in LDS and exchange partial
                                   * dots through that XCD's L2, instead of two launches per step (same arithmetic per
-                                  * step; falls back to the step kernels if its bounded spins time out).  -1 auto = 0 =
-                                  * off: measured gain 1.3x per step, +5 % iterations/s. */
+                                  * step; falls back to the step kernels if its bounded spins time out): measured gain
+                                  * 1.3x per step, +5 % iterations/s, off in auto.
+                                  * 2 (round 6) = ONE WORKGROUP per Lanczos cycle for blocks of side <= 512 (csrc/
+                                  * lanczos_block1.hip.hpp: basis in registers, operator and records in LDS, the restart
+                                  * rotation in the prologue; the step kernels' arithmetic term by term: BIT-IDENTICAL
+                                  * results); applies to the operator form with <= 16 factor columns and to a packed
+                                  * triangle that fits in LDS (side <= ~140), Krylov dimension <= 31 -- anything else runs
+                                  * the step kernels.  -1 auto = 2 for sides <= 256 (where it is 2.2-2.6x faster per step),
+                                  * step kernels beyond; 0 = step kernels always. */
     int32_t lanczos_warm_start;  /* 0 (default): every KrylovKit projection starts from the fixed start vector, as the
                                   * reference does (krylovkit_reset_resid = false).  1: start from the normalised sum of
                                   * the previous projection's Ritz vectors (+ 1e-3 x the fixed vector).  Changes the
