@@ -2021,6 +2021,8 @@ k_primal_update_S(double* __restrict__ x, const int* __restrict__ supp, const do
 struct TrialBatch {                 // up to 4 linesearch candidates per launch
     double bt[4], theta[4], tau[4], sigma[4];
     int nc;
+    int plain;                      // 1: dual_step! without linesearch (pdhg.jl:584-609) -- y+ and M'y+ are kept as computed, not
+                                    // through linesearch!'s in-place norm + revert
 };
 
 // candidates of y+ (pdhg.jl:547-553): grid.y = candidate; part[c][0][wg] = |y+ - y|^2 partials
@@ -2040,7 +2042,7 @@ k_dual_trial_batch(const double* __restrict__ y, const double* __restrict__ Mx, 
         const double proj = (i < p) ? bh[i] : fmin(ybar / bt, bh[i]);
         const double yn = ybar - bt * proj;
         const double d = yn - yi;
-        yout[i] = d + yi;                      // in-place norm + revert (pdhg.jl:561,575): fl(fl(y+ - y_old) + y_old)
+        yout[i] = tb.plain ? yn : d + yi;      // in-place norm + revert (pdhg.jl:561,575): fl(fl(y+ - y_old) + y_old)
         // roww: 0 for a coupling row another shard accounts for (block-sharded solve), else 1
         ss += (roww != nullptr ? roww[i] : 1.0) * (d * d);
     }
@@ -2053,7 +2055,7 @@ __global__ void __launch_bounds__(TPB)
 k_spmvT_S_batch(const int* __restrict__ colptr, const int* __restrict__ row, const double* __restrict__ val,
                 const int* __restrict__ supp, int ns, const double* __restrict__ ycand, long long ystride,
                 double* __restrict__ MtyScand, long long mstride, const double* __restrict__ MtyS_old,
-                double* __restrict__ part, long long cstride) {
+                double* __restrict__ part, long long cstride, int plain = 0) {
     __shared__ double sm[NWAVE];
     __shared__ LongCols lc;
     const int c = blockIdx.y;
@@ -2067,7 +2069,7 @@ k_spmvT_S_batch(const int* __restrict__ colptr, const int* __restrict__ row, con
         const double acc = col_dot(lc, col, colptr, row, val, y);
         const double o = MtyS_old[s];
         const double d = acc - o;
-        out[s] = d + o;                        // pdhg.jl:560,574
+        out[s] = plain ? acc : d + o;          // pdhg.jl:560,574 (plain: dual_step!'s mul!(Mty, Mt, y), pdhg.jl:606)
         ss += d * d;
     }
     const double tot = block_sum(ss, sm);

@@ -38,6 +38,8 @@ constexpr int B1_NC = 8;                 // basis columns held per wave (column 
 constexpr int B1_NPV = 4;                // factor columns held per wave: rank of the previous projection <= 16
 constexpr int B1_MAXNT = 8;              // side <= 512
 constexpr int B1_KMAX = 31;              // Krylov dimension (k_lz_rotate is the scalar kernel below K = 32)
+constexpr int B1_FOLD_LD = 72;           // column sums through LDS (b1_fold4): 64 rows + 2 x 4 padding per column ...
+constexpr int B1_FOLD_STAGE = 4 * B1_FOLD_LD;   // ... four columns per wave
 
 struct Block1Args {
     const double* xp;                    // packed block of the iterate (packed operator)
@@ -57,7 +59,7 @@ struct Block1Args {
 
 // LDS plan (doubles).  Per virtual workgroup scratch is a union over the phases.
 struct B1Lds {
-    int vec, nw, X, Pp, Ap, eb, tp, apf, ellc, ellf, hp, hn, q, u, h2, hsum, al, be, f, D, red, common, vw, vw_stride, total;
+    int vec, nw, X, Pp, Ap, eb, tp, apf, ellc, ellf, hp, hn, q, u, h2, hsum, al, be, f, D, red, common, vw, vw_stride, fold, total;
 };
 __host__ __device__ inline B1Lds b1_lds_plan(int nt, int npad, bool fop, long long xN, int ell_w_lds) {
     B1Lds L{};
@@ -80,6 +82,7 @@ __host__ __device__ inline B1Lds b1_lds_plan(int nt, int npad, bool fop, long lo
     L.common = take(NWAVE * 4 * 64);             // s_t | s_p of virtual workgroup 0; the rotation's U in the prologue
     L.vw_stride = 4 * NWAVE * LZ_ROWS;           // [0, 512): closing row sums / recurrence row sums | [512, 1024): (E v) partials / tile row+col sums
     L.vw = take(B1_NV * L.vw_stride);
+    L.fold = take(B1_NV * NWAVE * B1_FOLD_STAGE);   // per wave: four columns x 64 rows (padded) of products for the column sums
     L.total = o;
     return L;
 }
@@ -147,6 +150,30 @@ __device__ __forceinline__ void b1_set_slot(double (&v)[B1_NC], int cn, double n
     ((v[Cs] = (Cs == cn) ? nv : v[Cs]), ...);
 }
 
+// Column sums of FOUR columns of products over the wave's 64 rows, with the additions of the step kernels' fold network
+// (fold16_all: per column a balanced tree that pairs the rows by bit 3, then 2, 1, 0, then 4, then 5 -- addition is commutative,
+// so the tree alone fixes the bits), computed through an LDS transpose instead of 17 DPP exchanges of 64-bit values: the fold
+// network is ~140 instructions per use, this ~30, and one CU issues every instruction of the step (profiles/r06_medium_blocks.md).
+// Lane (c, a, m) = (lane >> 4, (lane >> 2) & 3, lane & 3) reads rows 16 a + m + {0, 4, 8, 12} of column c: levels "bit 3" and
+// "bit 2" are in the lane, "bit 1" / "bit 0" between lanes m, "bit 4" / "bit 5" between lanes a.  Returns the sum of column
+// lane >> 4 (in every lane of that 16-group).  Rows are stored with two doubles of padding per 16 (bank conflicts).
+__device__ __forceinline__ double b1_fold4(double t0, double t1, double t2, double t3, double* __restrict__ stage, int lane) {
+    const int wr = lane + 2 * (lane >> 4);
+    __builtin_amdgcn_wave_barrier();
+    stage[wr] = t0; stage[B1_FOLD_LD + wr] = t1; stage[2 * B1_FOLD_LD + wr] = t2; stage[3 * B1_FOLD_LD + wr] = t3;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const double* rd = stage + (lane >> 4) * B1_FOLD_LD + 18 * ((lane >> 2) & 3) + (lane & 3);
+    const double x0 = rd[0], x4 = rd[4], x8 = rd[8], x12 = rd[12];
+    double y = (x0 + x8) + (x4 + x12);            // bit 3, then bit 2
+    y += lane_xor<2>(y);                          // bit 1
+    y += lane_xor<1>(y);                          // bit 0
+    y += lane_xor<4>(y);                          // bit 4 (a ^ 1)
+    y += lane_xor<8>(y);                          // bit 5 (a ^ 2)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return y;
+}
+
 // RG = row groups per virtual workgroup (1: side <= 256, 2: side <= 512);  FOP = operator form
 template <int RG, bool FOP>
 __global__ void __launch_bounds__(B1_TPB)
@@ -183,6 +210,7 @@ k_lz_block1(Block1Args a) {
     double* const s_com = b1_sm + L.common;
     double* const s_vw = b1_sm + L.vw + vb * L.vw_stride;
     double* const s_vwB = s_vw + 2 * NWAVE * LZ_ROWS;
+    double* const s_fold = b1_sm + L.fold + (vb * NWAVE + wv) * B1_FOLD_STAGE;
 
     if (a.ctl->stop) return;
     const long long tk0 = (a.dbg != nullptr && threadIdx.x == 0) ? (long long)wall_clock64() : 0;
@@ -391,12 +419,10 @@ k_lz_block1(Block1Args a) {
                 }
             }
             s_vwB[r * (NWAVE * LZ_ROWS) + wv * LZ_ROWS + lane] = e;
-            double t[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) t[c] = (c < B1_NPV) ? vrp[r][c < B1_NPV ? c : 0] * vi : 0.0;
-            const double ts = fold16_all(t, lane);
-            const int cc = wv + 4 * lane;
-            if (lane < 16 && cc < a.rp) s_tp[g * 64 + cc] = ts;
+            static_assert(B1_NPV == 4, "one fold of four columns");
+            const double ts = b1_fold4(vrp[r][0] * vi, vrp[r][1] * vi, vrp[r][2] * vi, vrp[r][3] * vi, s_fold, lane);
+            const int cc = wv + 4 * (lane >> 4);
+            if ((lane & 15) == 0 && cc < a.rp) s_tp[g * 64 + cc] = ts;
         }
     };
     auto S1 = [&]() {                            // wave 0 of every virtual workgroup
@@ -510,12 +536,17 @@ k_lz_block1(Block1Args a) {
                 const double rr = wave_sum(wp * wp);
                 if (lane == 0) hn_out[g] = rr;
             }
-            double t[16];
+            static_assert(B1_NC == 8, "two folds of four columns");
 #pragma unroll
-            for (int c = 0; c < 16; ++c) t[c] = (c < B1_NC && wv + 4 * c <= k) ? vr[r][c < B1_NC ? c : 0] * wp : 0.0;
-            const double hs = fold16_all(t, lane);
-            const int jc = wv + 4 * lane;
-            if (lane < 16 && jc <= k) hp_out[g * 64 + jc] = hs;
+            for (int hf = 0; hf < 2; ++hf) {
+                if (wv + 16 * hf > k) break;                              // (wave-uniform: none of these four columns exists yet)
+                double t[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) t[c] = (wv + 4 * (4 * hf + c) <= k) ? vr[r][4 * hf + c] * wp : 0.0;
+                const double hs = b1_fold4(t[0], t[1], t[2], t[3], s_fold, lane);
+                const int jc = wv + 4 * (4 * hf + (lane >> 4));
+                if ((lane & 15) == 0 && jc <= k) hp_out[g * 64 + jc] = hs;
+            }
         }
     };
 

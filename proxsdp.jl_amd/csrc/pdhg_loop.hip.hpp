@@ -1057,7 +1057,8 @@ inline int Solver::linesearch_dense() {
 // ---- support-aware path: setup and the batched linesearch + residual
 inline void Solver::setup_support() {
     use_support = false;
-    if (opt.support_path == 0 || !opt.line_search_flag) return;
+    // (without linesearch the support path runs on request -- support_path = 1 -- and inside a block-sharded solve, which is built on it)
+    if (opt.support_path == 0 || (!opt.line_search_flag && opt.support_path < 0)) return;
     if (!P.socs.empty() || !one_blocks.empty() || P.blocks.empty()) return;
     std::vector<int> supp;
     for (int64_t k = 0; k < P.n; ++k)
@@ -1186,7 +1187,10 @@ inline int Solver::linesearch_residual_support() {
     const long long cstride = 11LL * PSTRIDE;
     const long long ystride = std::max<int64_t>(P.Q, 1), mstride = std::max(ns, 1);
     const double xold_coef = (iter == 1 && opt.advanced_initialization) ? 0.0 : 1.0;
-    primal_step = primal_step * std::sqrt(1.0 + theta);
+    // line_search_flag = false (round 6; the sharded loop needs this path): ONE candidate, dual_step! (pdhg.jl:584-609) -- y+ = y +
+    // sigma (2 Mx - Mx_old) with the solver's own dual_step, accepted as it is; primal_step, dual_step and theta are left alone
+    const bool ls = opt.line_search_flag;
+    if (ls) primal_step = primal_step * std::sqrt(1.0 + theta);
     int trials = 0;
     bool accepted = false;
     const double* s_acc = nullptr;
@@ -1226,24 +1230,25 @@ inline int Solver::linesearch_residual_support() {
         g_any_below_full = maxs[mi++] > 0.5;
         g_elapsed = maxs[mi++];
     };
-    while (!accepted && trials < opt.max_linsearch_steps) {
+    while (!accepted && (!ls || trials < opt.max_linsearch_steps)) {
         dev::TrialBatch tb{};
         double tau_c = primal_step;
         int nc = 0;
-        for (; nc < NC && trials + nc < opt.max_linsearch_steps; ++nc) {
+        for (; ls && nc < NC && trials + nc < opt.max_linsearch_steps; ++nc) {
             tb.tau[nc] = tau_c;
             tb.theta[nc] = tau_c / primal_step_old;
             tb.bt[nc] = beta * tau_c;
             tb.sigma[nc] = beta * tau_c;
             tau_c *= opt.linsearch_decay;
         }
+        if (!ls) { nc = 1; tb.tau[0] = primal_step; tb.theta[0] = 1.0; tb.bt[0] = dual_step; tb.sigma[0] = dual_step; tb.plain = 1; }
         tb.nc = nc;
         hipLaunchKernelGGL(dev::k_dual_trial_batch, dim3(gq, nc), dim3(dev::TPB), 0, stream,
                            ybuf[yc].p, Mxbuf[1 - mxc].p, Mxbuf[mxc].p, bh_d.p, (int)P.p, (int)P.Q, tb,
                            ycand_d.p, ystride, bpart.p, cstride, (const double*)roww_d.p);
         hipLaunchKernelGGL(dev::k_spmvT_S_batch, dim3(gs, nc), dim3(dev::TPB), 0, stream,
                            csc_ptr.p, csc_row.p, csc_val.p, supp_d.p, ns, ycand_d.p, ystride,
-                           MtyS_cand.p, mstride, MtyS_cur.p, bpart.p + PSTRIDE, cstride);
+                           MtyS_cand.p, mstride, MtyS_cur.p, bpart.p + PSTRIDE, cstride, tb.plain);
         hipLaunchKernelGGL(dev::k_residual_xy_batch, dim3(std::max(gs, gq), nc, 2), dim3(dev::TPB), 0, stream,
                            xbuf[1 - xc].p, supp_d.p, ns, xsave_d.p, xold_coef, MtyS_cand.p, mstride, MtyS_cur.p,
                            cS_d.p, gs,
@@ -1261,6 +1266,13 @@ inline int Solver::linesearch_residual_support() {
         PX_HIP(hipMemcpyAsync(hbscal.data(), bscal.p, (NC * 11 + 2) * sizeof(double), hipMemcpyDeviceToHost, stream));
         wait_stream();
         reduce_candidates(nc);
+        if (!ls) {
+            trials = 1; accepted = true; s_acc = hbscal.data();
+            hipLaunchKernelGGL(dev::k_copy2, dim3(grid_for((long long)P.Q + ns)), dim3(dev::TPB), 0, stream,
+                               ybuf[1 - yc].p, (const double*)ycand_d.p, (long long)P.Q,
+                               MtyS_cur.p, (const double*)MtyS_cand.p, (long long)ns);
+            break;
+        }
         for (int c = 0; c < nc; ++c) {
             ++trials;
             const double* sc = hbscal.data() + 11 * c;
@@ -1304,7 +1316,7 @@ inline int Solver::linesearch_residual_support() {
         }
     }
     primal_step_old = primal_step;
-    dual_step = beta * primal_step;
+    if (ls) dual_step = beta * primal_step;
     st.linesearch_trials += trials;
     // ---- residuals and gap from the accepted candidate's scalars
     const double tr0 = now_s();
@@ -1611,8 +1623,8 @@ inline void Solver::run() {
         g_frob = sharded() ? std::sqrt(sums[6]) : P.frob;
         g_conic = maxs[0] > 0.5;
     }
-    if (sharded() && (opt.support_path == 0 || !opt.line_search_flag))
-        throw std::domain_error("block-sharded solve: dense vector passes / no linesearch not implemented");
+    // (a block-sharded solve always runs the support-aware batched path: the library-only knob support_path is overridden below;
+    //  round 6: check_dual_feas and line_search_flag = false are served there too)
     if (opt.max_iter <= 0) max_iter_local = g_conic ? opt.max_iter_conic : opt.max_iter_lp;
     else max_iter_local = opt.max_iter;
     ada_count = 0;

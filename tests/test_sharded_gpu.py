@@ -122,6 +122,45 @@ def test_two_shards_with_check_dual_feas_stop_where_the_single_process_solve_sto
         assert np.allclose(tr[:, :3], ref.trace[:len(tr)][:, [1, 2, 7]], rtol=1e-9, atol=1e-12)
 
 
+def test_two_shards_without_linesearch_reproduce_the_single_process_solve():
+    """Round 6: `line_search_flag = false` (dual_step!, pdhg.jl:584-609, fixed steps adapted by the residual
+    balance) inside a block-sharded solve.  The sharded loop is built on the support path, which now serves that option with ONE
+    candidate taken as it is (no in-place-norm revert).  Checked three ways: the support path against the dense vector passes in one
+    process (same iterations, traces to 1e-10), both against the oracle, and two gloo ranks against the single-process solve."""
+    import oracle
+    assert B.device_count() > 0
+    pr = _coupled_model()
+    kw = dict(line_search_flag=0)
+    dense = Optimizer(max_iter=300, support_path=0, **kw).optimize(pr, trace_capacity=300)
+    ref = Optimizer(max_iter=300, support_path=1, **kw).optimize(pr, trace_capacity=300)
+    assert ref.iter == dense.iter and ref.status == dense.status
+    assert np.allclose(ref.trace[:, [1, 2, 3, 4, 7]], dense.trace[:, [1, 2, 3, 4, 7]], rtol=1e-10, atol=1e-12)
+    o = oracle.Options(); o.max_iter = 300; o.line_search_flag = False
+    orc = oracle.solve(pr, o, trace=True)
+    m = min(len(orc.trace), len(ref.trace))
+    exp = np.array([[t["prim_obj"], t["dual_obj"], t["primal_step"]] for t in orc.trace[:m]])
+    assert int(orc.iter) == int(ref.iter)
+    assert np.allclose(ref.trace[:m][:, [1, 2, 7]], exp, rtol=1e-7, atol=1e-9)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 300) + 97
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, True, "gloo", kw)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted((q.get(timeout=600) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    x = np.zeros(pr.n)
+    for (rank, status, it, obj, dobj, gap, frank, vars_, primal, tr) in out:
+        assert status == ref.status and it == ref.iter
+        assert abs(obj - ref.objval) <= 1e-9 * (1 + abs(ref.objval))
+        assert np.all(tr[:, 3] == 1)                                              # one "trial" per iteration
+        assert np.allclose(tr[:, :3], ref.trace[:len(tr)][:, [1, 2, 7]], rtol=1e-9, atol=1e-12)
+        x[vars_] = primal
+    assert np.allclose(x, ref.primal, rtol=0, atol=1e-9)
+
+
 def _devptr_worker(port, q):
     os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch
