@@ -25,6 +25,9 @@ lines = ["| class | prob_ref | status | iterations | time s | obj | rank | lin_f
 Optimizer(max_iter=5).optimize(P.maxcut(120, seed=0))          # (first-call set-up of the process, outside every row)
 Optimizer(max_iter=5).optimize(P.randsdp(5, 5, seed=7))         # (... incl. rocSOLVER's small-size code objects: the exit path's first dsyevd
                                                                 #  of a block of side 5 took 7.3 s on a fresh box, profiles/r06_runbench.md)
+Optimizer(max_iter=3, full_eig_decomp=1, full_eig_sign=0).optimize(P.maxcut(500, seed=0))   # (... and its dsyevd at side 500: the exit path of
+                                                                # mcp500-1 falls back to it -- 3 to 17 s of library loading on a fresh box,
+                                                                # counted in that row's time in the first calls of round 6)
 t_all = time.time()
 for cls, ref, build in jobs:
     pr = build()
