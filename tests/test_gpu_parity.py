@@ -1380,6 +1380,47 @@ def test_sensorloc_benchmark_family_takes_the_oracles_iterations(n):
     assert np.allclose(sol.primal, ref.primal, atol=1e-6)
 
 
+def _long_column_model(n=120, copies=6, seed=3):
+    """Max-Cut n plus `copies` x (n - 1) redundant equality rows X_00 + X_jj = 2 (consistent with diag = 1) and as many inequality
+    rows X_00 - X_jj <= 0.5: the column of X_00 carries 2 * copies * (n - 1) + 1 entries (1429 at the defaults), every other diagonal
+    column 2 * copies + 1 -- the shape that made one thread of the transposed products walk thousands of entries (sensor
+    localisation's identity block, profiles/r06_medium_blocks.md)."""
+    pr = P.maxcut(n, seed=seed)
+    diag = np.array([j * (j + 1) // 2 + j for j in range(n)])
+    rows, cols, vals = [], [], []
+    r = 0
+    for _ in range(copies):
+        for j in range(1, n):
+            rows += [r, r]; cols += [diag[0], diag[j]]; vals += [1.0, 1.0]; r += 1
+    A2 = sp.csr_matrix((vals, (rows, cols)), shape=(r, pr.n))
+    G2 = sp.csr_matrix((np.array(vals) * np.tile([1.0, -1.0], r), (rows, cols)), shape=(r, pr.n))
+    return P.Problem(n=pr.n, A=sp.vstack([pr.A, A2]).tocsc(), b=np.concatenate([pr.b, np.full(r, 2.0)]),
+                     G=sp.vstack([pr.G, G2]).tocsc() if pr.G.shape[0] else G2.tocsc(), h=np.concatenate([pr.h, np.full(r, 0.5)]),
+                     c=pr.c, psd=pr.psd, name="maxcut-long-column")
+
+
+@pytest.mark.parametrize("support", [0, 1])
+def test_long_columns_of_the_constraint_matrix_follow_the_oracle(support):
+    """Round 6: columns of M beyond 192 entries are summed by a wave -- products in parallel, additions in the scalar loop's order
+    (kernels.hip.hpp `wave_col_dot_inorder`) -- in the transposed products of both vector paths (`k_spmv_csc_norm_batch`: dense
+    passes, `k_spmvT_S_batch`: support path).  A model with one column of 1429 entries against the oracle: identical linesearch
+    trials and mat-vec counts, traces to 1e-9; and the two paths against each other."""
+    import oracle
+    pr = _long_column_model()
+    assert np.diff(pr.A.indptr).max() + np.diff(pr.G.indptr).max() > 1400
+    o = oracle.Options(); o.max_iter = 80
+    mv, prev = [], [0]
+    ref = oracle.solve(pr, o, trace=True, proj_callback=lambda it, xin, xout, p, arc: (mv.append(arc[0].matvecs - prev[0]), prev.__setitem__(0, arc[0].matvecs)))
+    sol = Optimizer(max_iter=80, support_path=support).optimize(pr, trace_capacity=80)
+    exp = np.array([[t["prim_obj"], t["dual_obj"], t["gap"], t["feas"], t["primal_step"], t["trials"]] for t in ref.trace])
+    m = min(len(exp), len(sol.trace))
+    assert m >= 60
+    assert np.array_equal(sol.trace[:m, 11], exp[:m, 5])
+    assert np.array_equal(sol.trace[:m, 13], np.array(mv[:m], float))
+    scale = 1.0 + np.abs(exp[:m, :5]).max(axis=0)
+    assert (np.abs(sol.trace[:m][:, [1, 2, 3, 4, 7]] - exp[:m, :5]) / scale).max() <= 1e-9
+
+
 @pytest.mark.parametrize("n", [150, 200, 300, 400])
 def test_sensorloc_larger_sizes_take_the_committed_oracle_counts(n, golden_dir):
     """SENSORLOC at sizes where the oracle takes minutes to an hour (tests/golden/sensorloc_oracle.json, made by

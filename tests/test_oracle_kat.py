@@ -313,3 +313,32 @@ def test_sensorloc_generator_and_oracle_solve():
     assert r.status == 1 and abs(r.objval) <= 1e-12
     X = P.unpack_psd(r.primal, 32)
     assert np.abs(X[:2, 2:] - pr.x_true).max() <= 1e-2
+
+
+def test_orthogonaliser_variants_of_the_eigen_layer_leave_the_counts_alone():
+    """Round 6: KrylovKit is not on disk and the versions Project.toml admits differ in their default
+    orthogonaliser.  The oracle's test-only switch `oracle.eig.ORTH` restates the four candidates; on a non-degenerate instance the
+    mat-vec count of every iteration, the restart total and the trace are the same under all of them (the full study, incl. the
+    metric instance's headline window: profiles/r06_orthogonaliser_variants_*.md)."""
+    import numpy as np
+    import oracle
+    from oracle import eig as oeig
+    from proxsdp_jl_amd import problems as P
+    pr = P.maxcut(130, seed=5)
+    runs = {}
+    try:
+        for v in ("mgs2", "cgs2", "mgsir", "cgsir"):
+            oeig.ORTH = v
+            o = oracle.Options(); o.max_iter = 60
+            mv, prev = [], [0, 0]
+            def cb(it, xin, xout, p, arc, mv=mv, prev=prev):
+                mv.append((arc[0].matvecs - prev[0], arc[0].restarts - prev[1])); prev[0], prev[1] = arc[0].matvecs, arc[0].restarts
+            r = oracle.solve(pr, o, trace=True, proj_callback=cb)
+            runs[v] = (mv, np.array([[t["prim_obj"], t["dual_obj"], t["primal_step"], t["trials"]] for t in r.trace]))
+    finally:
+        oeig.ORTH = "mgs2"
+    base_mv, base_tr = runs["mgs2"]
+    assert sum(m for m, _ in base_mv) > 1000
+    for v, (mv, tr) in runs.items():
+        assert mv == base_mv, v
+        assert np.allclose(tr, base_tr, rtol=1e-9, atol=1e-10), v
