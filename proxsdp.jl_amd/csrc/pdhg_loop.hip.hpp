@@ -866,8 +866,10 @@ inline void Solver::cache_solution(const std::vector<double>& cvec) {
     }
     res.status = stop_reason;
     merge_block_stats();
-    std::snprintf(res.status_string, sizeof(res.status_string), "%s%s", stop_reason_string.c_str(),
-                  st.dense_truncated_projections > 0 ? " [Krylov dimension > 255: dense eigensolver served those projections]" : "");
+    // (a caller who forces equilibration gets the reference's aliased -- not contractive -- scaling iteration by default: say so)
+    std::snprintf(res.status_string, sizeof(res.status_string), "%s%s%s", stop_reason_string.c_str(),
+                  st.dense_truncated_projections > 0 ? " [Krylov dimension > 255: dense eigensolver served those projections]" : "",
+                  (P.equilibrated && opt.equilibration_reference_aliasing) ? " [equilibration: the reference's aliased scaling, equilibration_reference_aliasing = 1]" : "");
     if (res.primal)    for (int64_t i = 0; i < P.n; ++i) res.primal[i] = x[P.inv[i]];
     if (res.dual_cone) for (int64_t i = 0; i < P.n; ++i) res.dual_cone[i] = dcone[P.inv[i]];
     if (res.dual_eq)   for (int64_t i = 0; i < P.p; ++i) res.dual_eq[i] = deq[i];
