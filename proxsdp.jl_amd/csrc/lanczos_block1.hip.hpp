@@ -583,6 +583,96 @@ k_lz_block1(Block1Args a) {
             Omeas(k, wi);
             __syncthreads();
         } else {
+          if constexpr (RG == 1) {
+            // ---- packed operator (resident in LDS: side <= ~140, at most two rounds of tiles): the closing work of step k-1 rides with
+            // the tile rounds of step k -- symv_reduce cut at its two barriers (A: products, row sums, folds | B: the waves' column sums /
+            // shares meet | C: slots written) -- 8-9 barriers per step instead of 11-13
+            struct TileSt { int tile, I, J, gi, j0; bool act, diag; double vi, cs, aw; };
+            auto tileA = [&](int rd, TileSt& T) {
+                T.tile = rd * B1_NV + vb; T.act = T.tile < ntile; T.I = T.J = 0; T.vi = T.cs = T.aw = 0.0;
+                if (!T.act) { T.gi = T.j0 = 0; T.diag = false; return; }
+                tile_coords(T.tile, T.I, T.J);
+                T.gi = T.I * TILE + lane; T.j0 = T.J * TILE + wv * CPW; T.diag = (T.I == T.J);
+                double t[CPW];
+                symv_load(s_X, a.n, T.tile, lane, wv, t);
+                double* s_row = s_vwB + (rd & 1) * (NWAVE * TILE);
+                const double* vJ = s_vec + T.j0;
+                T.vi = s_vec[T.gi];
+                double racc = 0.0;
+#pragma unroll
+                for (int c = 0; c < CPW; ++c) {
+                    racc += t[c] * vJ[c];
+                    t[c] *= T.vi;
+                    if (T.diag && T.gi == T.j0 + c) t[c] = 0.0;
+                }
+                s_row[wv * TILE + lane] = racc;
+                T.aw = T.diag ? 0.0 : wave_sum(T.vi * racc);
+                fold_stage<8>(t, lane);
+                fold_stage<4>(t, lane);
+                fold_stage<2>(t, lane);
+                fold_stage<1>(t, lane);
+                T.cs = add_xor32(add_xor16(t[0]));
+            };
+            auto tileB = [&](int rd, const TileSt& T) {
+                if (!T.act) return;
+                double* s_col = s_vw + 256 + (rd & 1) * TILE;
+                if (T.diag) { if (lane < CPW) s_col[wv * CPW + lane] = T.cs; }
+                else if (lane == 0) s_col[wv] = T.aw;
+            };
+            auto tileC = [&](int rd, const TileSt& T) {
+                if (!T.act) return;
+                const double* s_row = s_vwB + (rd & 1) * (NWAVE * TILE);
+                const double* s_col = s_vw + 256 + (rd & 1) * TILE;
+                if (T.diag) {
+                    if (wv == 0) {
+                        const double rs = (s_row[lane] + s_row[TILE + lane]) + (s_row[2 * TILE + lane] + s_row[3 * TILE + lane]);
+                        s_Pp[T.I * npad + T.gi] = rs + s_col[lane];
+                        const double aa = wave_sum(T.vi * (rs + s_col[lane]));
+                        if (lane == 0) s_Ap[T.tile] = aa;
+                    }
+                } else {
+                    if (wv == 0) {
+                        const double rs = (s_row[lane] + s_row[TILE + lane]) + (s_row[2 * TILE + lane] + s_row[3 * TILE + lane]);
+                        s_Pp[T.J * npad + T.gi] = rs;
+                        if (lane == 0) s_Ap[T.tile] = 2.0 * ((s_col[0] + s_col[1]) + (s_col[2] + s_col[3]));
+                    }
+                    if (lane < CPW) s_Pp[T.I * npad + T.j0 + lane] = T.cs;
+                }
+            };
+            TileSt T0{}, T1{};
+            if (hasF && vb == 0) F0(k - 1);
+            if (hasSO) tileA(0, T0);
+            __syncthreads();
+            if (hasF && vb == 0 && tid < 64) F1(k - 1);
+            if (hasSO) tileB(0, T0);
+            __syncthreads();
+            if (hasF) {
+                beta = F2(k - 1);
+                if (beta <= a.tol) { stop_k = k; break; }
+            }
+            if (hasSO) { tileC(0, T0); if (rounds > 1) tileA(1, T1); }
+            __syncthreads();
+            if (hasF && wv == 0) F3(k - 1, beta);
+            if (hasSO && rounds > 1) tileB(1, T1);
+            __syncthreads();
+            if (hasF) kdone = k;
+            if (!hasSO) break;
+            if (hasF) F4(k);
+            if (rounds > 1) tileC(1, T1);
+            for (int rd = 2; rd < rounds; ++rd) {
+                const int tile = rd * B1_NV + vb;
+                const bool act = tile < ntile;
+                double t[CPW];
+                if (act) symv_load(s_X, a.n, tile, lane, wv, t);
+                else {
+#pragma unroll
+                    for (int c = 0; c < CPW; ++c) t[c] = 0.0;
+                }
+                b1_symv_reduce(act, npad, s_vec, s_Pp, tile, lane, wv, t, s_vwB + (rd & 1) * (NWAVE * TILE),
+                               s_vw + 256 + (rd & 1) * TILE, s_Ap);
+            }
+            if (rounds > 1) __syncthreads();
+          } else {
             if (hasF) {
                 if (vb == 0) F0(k - 1);
                 __syncthreads();
@@ -610,6 +700,7 @@ k_lz_block1(Block1Args a) {
                                s_vw + (rd & 1) * TILE, s_Ap);
             }
             __syncthreads();
+          }
             const double be_km = first ? 1.0 : s_be[max(k - 1, 0)];
             const double binv = first ? 1.0 : 1.0 / be_km;
             if (vb == 0) Ored();
