@@ -13,6 +13,7 @@ for a in sys.argv[3:]:
 if name.startswith("sensorloc"): pr = P.sensorloc(int(name[9:]), seed=0)
 elif name.startswith("maxcut"): pr = P.maxcut(int(name[6:]), seed=2)
 elif name.startswith("mimo"): pr = P.mimo(int(name[4:]), seed=0)
+elif name.startswith("blocks:"): pr = P.sdplib_blocks(os.path.join(data, name[7:] + ".dat-s"))      # the file's block structure kept
 else: pr = P.sdplib(os.path.join(data, name + ".dat-s"))
 s = Optimizer(max_iter=iters, **kw).optimize(pr)
 st = s.stats
