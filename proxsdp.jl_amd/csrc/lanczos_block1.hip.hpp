@@ -23,8 +23,16 @@
 // dsymv at :678) and its basistransform!, as k_symv_finish / k_fop_finish + k_lz_orth + k_lz_rotate do.  The K x K
 // eigensolve and the restart logic stay on the host (Solver::lz_after_cycle), unchanged.
 //
-// Limits (Solver::block1_plan): side <= 512 (8 row groups), Krylov dimension <= 31, operator form with <= 16 factor columns
-// and no hub-row overflow list, or the packed triangle resident in LDS (side <= ~140); anything else takes the step kernels.
+// Limits (Solver::block1_plan): side <= 512 (8 row groups; auto: <= 256, one row group per virtual workgroup -- with two, a step
+// costs what two launches cost), Krylov dimension <= 31, operator form with <= 16 factor columns and no hub-row overflow list, or
+// the packed triangle resident in LDS (side <= ~140); anything else takes the step kernels.
+//
+// Measured (profiles/r06_medium_blocks.md): 4.3-4.8 us per step on the operator form, 7.6 us on the packed operator, against ~12 us
+// for the two launches; prologue (rotation + operator staging) 5-8 us, epilogue 0.6-1.1 us.  The bound is VALU issue of ONE CU:
+// ~600 instructions per wave and step for 16 waves on 4 SIMDs.  Two things that cost a factor each while this was written: a
+// `for c: if (c == cn) v[c] = x` loop over a register array is turned into one indexed store and demotes the array (the Krylov
+// basis) to scratch memory (-> b1_set_slot); a global store inside the step loop has to be acknowledged before the next barrier
+// (-> everything is written once, in the epilogue).
 #pragma once
 #include "kernels.hip.hpp"
 #include <utility>
