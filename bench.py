@@ -40,7 +40,9 @@ optimum of the instance (tests/golden/maxcut_n4000_tight.json), and
 "config_maxcut_n1000" (BASELINE config 2 on both sides, incl. solve to tol
 against the committed oracle solve), and compact legs of BASELINE configs 3 / 4 / 5
 ("config_randsdp", "config_mimo_x8", "config_sdplib": what `--workload ...` runs,
-shorter windows, each with its roofline and cpu_baseline or the reason it has none).  cpu_baseline.parity_on_the_sample compares
+shorter windows, each with its roofline and cpu_baseline or the reason it has none), and "medium_blocks" (round 6: whole default-options
+solves of PSD sides 101 .. 250 -- the window of the reference's own benchmark script -- in microseconds per iteration beside round 5's).
+cpu_baseline.parity_on_the_sample compares
 the oracle's sample iterations with the headline solve's own first iterations.
 """
 import argparse
