@@ -1380,6 +1380,26 @@ def test_sensorloc_benchmark_family_takes_the_oracles_iterations(n):
     assert np.allclose(sol.primal, ref.primal, atol=1e-6)
 
 
+def test_block_cycle_kernel_in_a_multi_block_model_with_one_stream_per_block():
+    """Blocks of different sides are projected concurrently, one worker thread and stream per block (run_blocks): each block's
+    one-workgroup cycle kernel, its deferred rotation and its pinned staging buffers are its own.  Two Max-Cut blocks (sides 120 and
+    150, operator form) and a third whose objective is dense on its block (side 90: the packed operator, resident in LDS): the
+    step kernels and the one-workgroup kernel give the same bits."""
+    a_, b_ = P.maxcut(120, seed=1), P.maxcut(150, seed=2)
+    c_ = P.maxcut(90, seed=3)
+    rng = np.random.default_rng(7)
+    c_.c[:] = c_.c + 0.05 * rng.standard_normal(c_.n)               # dense objective: this block's update is not sparse
+    pr = P.block_diag_problems([a_, b_, c_], name="three-blocks")
+    kw = dict(max_iter=300, min_size_krylov_eigs=50)
+    r0 = Optimizer(lanczos_cycle_kernel=0, **kw).optimize(pr, trace_capacity=300)
+    r2 = Optimizer(lanczos_cycle_kernel=2, **kw).optimize(pr, trace_capacity=300)
+    assert r0.stats["cycle_launches"] == 0 and r2.stats["cycle_launches"] > 600
+    cols = [c for c in range(r0.trace.shape[1]) if c != 12]
+    assert r0.iter == r2.iter and np.array_equal(r0.trace[:, cols], r2.trace[:, cols])
+    assert np.array_equal(r0.primal, r2.primal) and np.array_equal(r0.dual_eq, r2.dual_eq)
+    assert r0.stats["lanczos_matvecs"] == r2.stats["lanczos_matvecs"] and r0.stats["lanczos_restarts"] == r2.stats["lanczos_restarts"]
+
+
 def _long_column_model(n=120, copies=6, seed=3):
     """Max-Cut n plus `copies` x (n - 1) redundant equality rows X_00 + X_jj = 2 (consistent with diag = 1) and as many inequality
     rows X_00 - X_jj <= 0.5: the column of X_00 carries 2 * copies * (n - 1) + 1 entries (1429 at the defaults), every other diagonal
